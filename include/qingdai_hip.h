@@ -1,0 +1,176 @@
+/*
+ * include/qingdai_hip.h -- C-ABI of libqingdai_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the per-timestep lat-lon grid update of PyGCM-for-Qingdai.
+ * The reference has no FFI for this path: its seam is Python level
+ *  --
+ *   (1) the class surface  pygcm/dynamics.py:22-23,260  SpectralModel(...).time_step(Teq, dt, albedo=None)
+ *                          pygcm/ocean.py:28-34,265     WindDrivenSlabOcean(...).step(dt, u, v, Q_net, ice_mask)
+ *                          + the free functions of physics/energy/humidity/forcing the driver calls
+ *                            (scripts/run_simulation.py:25,36), and
+ *   (2) the operator seam  pygcm/jax_compat.py:111,135,190
+ *                          laplacian_sphere / hyperdiffuse / advect_semilag gated by is_enabled().
+ * Every entry point below names the reference interface it replaces.  Plain C:
+ * handles, pointers, sizes; no C++ or torch types.  All arrays are C-order
+ * float64 [n_lat][n_lon] (uint8 for masks) in HOST memory, borrowed for the call.
+ * The library owns all device memory.  Return 0 = OK, negative = error (see
+ * qd_last_error); nothing throws or aborts.  One HIP stream per handle; a handle
+ * is not thread-safe.  Steps are asynchronous: qd_download / qd_sync / qd_reduce
+ * synchronise.
+ */
+#ifndef QINGDAI_HIP_H
+#define QINGDAI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QD_ABI_VERSION 1
+
+typedef struct qd_ctx* qd_handle;
+
+/* Grid + latitude-band descriptor.  Single GPU: row0 = 0, n_rows = n_lat, halo = 0.
+ * Multi GPU (one process per GPU): rows [row0, row0 + n_rows) of the global grid are
+ * owned; `halo` extra rows are kept on each side and refreshed by qd_halo_* (RCCL). */
+typedef struct qd_grid_desc {
+    int32_t n_lat, n_lon;
+    int32_t row0, n_rows, halo;
+    int32_t device;            /* HIP device ordinal */
+    int32_t rank, world;       /* band index / number of bands */
+} qd_grid_desc;
+
+/* Field ids: one per array attribute of the reference classes (+ static maps). */
+enum qd_field {
+    /* SpectralModel prognostic state (dynamics.py:56-66,84) */
+    QD_F_U = 0, QD_F_V, QD_F_H, QD_F_TS, QD_F_Q, QD_F_CLOUD, QD_F_HICE,
+    /* per-step inputs assigned by the driver (run_simulation.py:1943-1944,2191) */
+    QD_F_ISR, QD_F_ISR_A, QD_F_ISR_B, QD_F_TEQ, QD_F_ALBEDO,
+    /* diagnostics written by time_step (dynamics.py:294-297,353,411) */
+    QD_F_OLR, QD_F_EFLUX, QD_F_PCOND, QD_F_LH, QD_F_LHREL, QD_F_CLOUD_EFF,
+    /* static maps (dynamics.py:25-31; topography.py:295-346) */
+    QD_F_FRICTION, QD_F_CSMAP, QD_F_BASE_ALBEDO, QD_F_ELEVATION,
+    /* WindDrivenSlabOcean state + forcing (ocean.py:86-94,265-270) */
+    QD_F_UO, QD_F_VO, QD_F_ETA, QD_F_SST, QD_F_QNET,
+    /* driver-side diagnostics (run_simulation.py:1778,1876,1884,2144) */
+    QD_F_PRECIP, QD_F_CLOUD_FROM_P, QD_F_CLOUD_SRC,
+    /* land hydrology reservoirs (run_simulation.py:1289-1290; hydrology.py) */
+    QD_F_W_LAND, QD_F_S_SNOW, QD_F_C_SNOW,
+    QD_F_COUNT_F64,
+    /* uint8 masks */
+    QD_F_LAND_MASK = 100, QD_F_ICE_MASK = 101
+};
+
+/* Every env-derived scalar the reference reads inside the step,
+ * as one POD.  NaN in a double = "environment variable unset".  Field names equal
+ * qingdai_amd.params.QdParams and oracle/qd_oracle/params.py. */
+typedef struct qd_params {
+    /* SpectralModel ctor: dynamics.py:22-41 */
+    double g, H, tau_rad, greenhouse_factor, a, omega;
+    double t_freeze, rho_i, L_f, Cs_ocean, Cs_land, Cs_ice;
+    /* humidity.py:58-82 */
+    double C_E, rho_a, h_mbl, L_v, p0, ocean_evap_scale, land_evap_scale, ice_evap_scale, tau_cond;
+    /* energy.py:55-74; dynamics.py:316-386 */
+    double sw_a0, sw_kc, lw_eps0, lw_kc, t_floor, c_sfc;
+    double energy_w, rh0, k_q, k_p, pcond_ref, hice_ref, eps_default, ch, cp_a;
+    double atm_h, gh_factor_lw, eps_ocean, eps_land, eps_ice, lw_tau0, lw_ktau;
+    /* dynamics.py:534-658 */
+    double sigma4, k4_u, k4_v, k4_h, k4_q, k4_cloud, spec_cutoff, spec_damp, diff_factor;
+    /* ocean.py:49-75,380-443,519-533 */
+    double H_ocean, rho_w, cp_w, g_ocean, CD, r_bot, rho_a_ocean, vcap, tau_scale;
+    double polar_sponge_lat, polar_sponge_gain, K_h, sigma4_ocean, ocean_cfl, ocean_max_u;
+    double ocean_k4_u, ocean_k4_v, ocean_k4_eta, ocean_adv_alpha, ocean_ice_qfac, eta_cap, ts_min, ts_max;
+    /* driver physics: run_simulation.py:1605-1613,1777,1866-1934 */
+    double D_crit, k_precip, alpha_water, alpha_ice, alpha_cloud, p_betadiv, pq_min, p_blend;
+    double pref, cmax, w_mem, w_p, w_src, cloud_from_p_floor, cloud_adv_alpha, cloud_smooth_sigma;
+    /* integer switches */
+    int32_t seaice_enabled, cloud_couple, lw_v2, gh_lock, polar_freeze_fix_s, polar_freeze_fix_n;
+    int32_t mom_scheme;        /* 0 geos, 1 primitive (QD_MOM_SCHEME) */
+    int32_t diff_enable, filter_type; /* 0 combo, 1 hyper4, 2 shapiro, 3 spectral, 4 other */
+    int32_t diff_every, k4_nsub, diff_q, diff_cloud, shapiro_every, shapiro_n, spec_every;
+    int32_t ocean_k4_nsub, ocean_diff_every, ocean_shapiro_n, ocean_shapiro_every;
+    int32_t ocean_outlier;     /* 0 mean4, 1 clamp */
+    int32_t ocean_use_qnet, ocean_polar_fix;
+    int32_t p_hybrid_fallback, cloud_advect, use_topo_albedo, has_csmap;
+    int32_t _pad;
+} qd_params;
+
+/* ---- lifetime ------------------------------------------------------------------ */
+int qd_abi_version(void);
+/* SpectralModel.__init__ / WindDrivenSlabOcean.__init__ (dynamics.py:22-88, ocean.py:28-97):
+ * allocates every field on `desc->device`, fills the reference's initial state
+ * (u=v=0, h=H+300 sin^2, T_s=288, q=RH0*q_sat(T_s), ocean at rest, SST=288). */
+int qd_create(const qd_grid_desc* desc, const qd_params* params, double q_init_rh, qd_handle* out);
+int qd_destroy(qd_handle h);
+const char* qd_last_error(qd_handle h);   /* h may be NULL: error of the last failed qd_create */
+
+/* ---- attribute surface: `gcm.u = arr` / `arr = gcm.u` (run_simulation.py:1441-1447,1900,2253) */
+int qd_upload(qd_handle h, int field, const void* host_global, size_t bytes);
+int qd_download(qd_handle h, int field, void* host_global, size_t bytes);
+/* the reference re-reads its env every step (dynamics.py:330-650); callers re-send on change */
+int qd_set_params(qd_handle h, const qd_params* params, size_t sizeof_params);
+int qd_get_step_counter(qd_handle h, int64_t* atmos_counter, int64_t* ocean_counter);
+int qd_set_step_counter(qd_handle h, int64_t atmos_counter, int64_t ocean_counter);
+
+/* ---- the path ------------------------------------------------------------------- */
+/* forcing.py:78-103,138-165: isr_A, isr_B, isr (and Teq from the ALBEDO field when with_teq)
+ * from ten host scalars: per star (flux, declination, right ascension) + theta (+ sigma). */
+int qd_forcing(qd_handle h, const double star_a[3], const double star_b[3], double theta, int with_teq);
+/* benchmark_jax.py:129: albedo = where(land == 0, ocean_albedo, base_albedo) */
+int qd_simple_albedo(qd_handle h, double ocean_albedo);
+/* SpectralModel.time_step(Teq, dt, albedo) (dynamics.py:260-667); Teq/ISR/ALBEDO fields must be current */
+int qd_atmos_step(qd_handle h, double dt, int has_albedo);
+/* run_simulation.py:2197-2253 + ocean.py:265-533: Q_net from SW/LW/SH/LH, ice mask from h_ice,
+ * WindDrivenSlabOcean.step, then T_s <- SST over open ocean.  compute_qnet=0 uses the QNET field
+ * and ICE_MASK as uploaded; inject_sst=0 skips the write-back. */
+int qd_ocean_step(qd_handle h, double dt, int compute_qnet, int use_ice_mask, int inject_sst);
+/* run_simulation.py:1766-1934,2063-2146: hybrid precipitation, cloud-from-precip, cloud source,
+ * cloud blend + advection, dynamic albedo (physics.py:12-354). */
+int qd_driver_physics(qd_handle h, double dt);
+/* benchmark_jax.py:124-158 as one resident loop of n steps: forcing -> albedo -> time_step [-> ocean
+ * coupling].  flags bit0 = with_ocean, bit1 = with_driver_physics (else the simple ocean/land albedo of
+ * benchmark_jax.py:129), bit2 = pass albedo to time_step.  `stars` holds n rows of 7 host scalars
+ * (flux_A, decl_A, ra_A, flux_B, decl_B, ra_B, theta), evaluated by the caller as forcing.py:85-125 does. */
+int qd_step_n(qd_handle h, int n, double dt, int flags, const double* stars);
+int qd_last_ocean_nsub(qd_handle h, int* n_sub);
+int qd_sync(qd_handle h);
+
+/* ---- operator seam: jax_compat.py:111-216 (host in, host out; global arrays) ------ */
+/* cos floor kinds: 0 = max(cos,0.2) atmosphere, 1 = max(cos,0.5) ocean */
+int qd_op_laplacian(qd_handle h, const double* F, int cos_kind, double* out);
+/* k4_row: n_lat per-row coefficients, or NULL with scalar k4 */
+int qd_op_hyperdiffuse(qd_handle h, const double* F, const double* k4_row, double k4_scalar, double dt,
+                       int n_substeps, int cos_kind, double* out);
+/* cos floor kinds: 0 = max(1e-6,cos) atmosphere, 1 = max(cos,0.5) ocean / driver cloud */
+int qd_op_advect(qd_handle h, const double* field, const double* u, const double* v, double dt,
+                 int cos_kind, double* out);
+int qd_op_shapiro(qd_handle h, const double* F, int n, double* out);                /* dynamics.py:215-231 */
+int qd_op_divergence(qd_handle h, const double* u, const double* v, double* out);   /* grid.py:41-68 */
+int qd_op_vorticity(qd_handle h, const double* u, const double* v, double* out);    /* grid.py:70-88 */
+int qd_op_gaussian(qd_handle h, const double* F, double sigma, int mode_wrap, double* out); /* physics.py:44 */
+int qd_op_median_positive(qd_handle h, const double* x, double dflt, double* out);  /* dynamics.py:344-348 */
+
+/* ---- reductions for diagnostics (energy.py:494-538, ocean.py:535-561) -------------- */
+enum qd_reduce_op { QD_R_SUM = 0, QD_R_COSWEIGHTED_MEAN = 1, QD_R_MAX = 2, QD_R_MIN = 3, QD_R_MAXABS = 4 };
+int qd_reduce(qd_handle h, int field, int op, double* out);
+
+/* ---- multi-GPU: latitude bands, RCCL halo exchange ------------------ */
+int qd_comm_unique_id(void* id128, size_t bytes);                 /* rank 0: ncclGetUniqueId */
+int qd_comm_init(qd_handle h, const void* id128, size_t bytes);   /* all ranks: ncclCommInitRank */
+int qd_comm_barrier(qd_handle h);
+int qd_comm_allreduce_max(qd_handle h, double* inout, int n);     /* bench timing: max over ranks */
+
+/* ---- profiling hooks ----------------------------------------------------------------- */
+/* mean device time (ms) of the kernels tagged `name` since the last reset, measured with
+ * hipEvents on the handle's stream when timing is enabled. */
+int qd_timing_enable(qd_handle h, int on);           /* 0 off, 1 every kernel group */
+int qd_timing_select(qd_handle h, const char* name); /* time only the group `name` (implies on) */
+int qd_timing_get(qd_handle h, const char* name, double* mean_ms, int64_t* launches);
+int qd_timing_reset(qd_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QINGDAI_HIP_H */

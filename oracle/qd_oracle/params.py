@@ -35,7 +35,7 @@ def defaults(**over):
         c_sfc=2.0e7,
         energy_w=0.0, cloud_couple=1, rh0=0.6, k_q=0.3, k_p=0.4,
         pcond_ref=NAN, lw_v2=1, hice_ref=0.5, eps_default=0.97,
-        ch=1.5e-3, cp_a=1004.0, bowen_land=0.7, bowen_ocean=0.3,
+        ch=1.5e-3, cp_a=1004.0,   # (QD_BOWEN_* only feed a value the path discards: energy.py:444-448)
         atm_h=NAN,  # QD_ATM_H; unset -> h_mbl (dynamics.py:472)
         gh_lock=1, gh_factor_lw=0.582,  # energy.py:122-127 default (driver exports 0.40)
         eps_ocean=0.98, eps_land=0.96, eps_ice=0.99,

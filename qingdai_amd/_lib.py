@@ -1,0 +1,102 @@
+"""
+qingdai_amd/_lib.py -- ctypes binding of libqingdai_hip.so (include/qingdai_hip.h).
+
+There is no CPU fallback: if the HIP library is missing or no GPU is visible the
+product raises.  (The oracle under oracle/ is test infrastructure and is never
+imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+from .params import qd_params
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqingdai_hip.so")
+
+# field ids (enum qd_field)
+FIELDS = ["U", "V", "H", "TS", "Q", "CLOUD", "HICE", "ISR", "ISR_A", "ISR_B", "TEQ", "ALBEDO",
+          "OLR", "EFLUX", "PCOND", "LH", "LHREL", "CLOUD_EFF", "FRICTION", "CSMAP", "BASE_ALBEDO", "ELEVATION",
+          "UO", "VO", "ETA", "SST", "QNET", "PRECIP", "CLOUD_FROM_P", "CLOUD_SRC", "W_LAND", "S_SNOW", "C_SNOW"]
+F = {n: i for i, n in enumerate(FIELDS)}
+F["LAND_MASK"] = 100
+F["ICE_MASK"] = 101
+R_SUM, R_COSMEAN, R_MAX, R_MIN, R_MAXABS = 0, 1, 2, 3, 4
+
+# every symbol include/qingdai_hip.h declares
+SYMBOLS = [
+    "qd_abi_version", "qd_create", "qd_destroy", "qd_last_error", "qd_upload", "qd_download", "qd_set_params",
+    "qd_get_step_counter", "qd_set_step_counter", "qd_forcing", "qd_simple_albedo", "qd_atmos_step",
+    "qd_ocean_step", "qd_driver_physics", "qd_step_n", "qd_last_ocean_nsub", "qd_sync",
+    "qd_op_laplacian", "qd_op_hyperdiffuse", "qd_op_advect", "qd_op_shapiro", "qd_op_divergence",
+    "qd_op_vorticity", "qd_op_gaussian", "qd_op_median_positive", "qd_reduce",
+    "qd_comm_unique_id", "qd_comm_init", "qd_comm_barrier", "qd_comm_allreduce_max",
+    "qd_timing_enable", "qd_timing_select", "qd_timing_get", "qd_timing_reset",
+]
+
+
+class qd_grid_desc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("n_lat", "n_lon", "row0", "n_rows", "halo", "device", "rank", "world")]
+
+
+_lib = None
+
+
+class QdError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library; fail loudly when it is absent (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise QdError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                      f"or `make -C qingdai_amd/csrc` (hipcc, gfx950). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    vp, dp, i32, i64, dbl, sz = (ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int64,
+                                 ctypes.c_double, ctypes.c_size_t)
+    lib.qd_abi_version.restype = i32
+    lib.qd_create.argtypes = [ctypes.POINTER(qd_grid_desc), ctypes.POINTER(qd_params), dbl, ctypes.POINTER(vp)]
+    lib.qd_destroy.argtypes = [vp]
+    lib.qd_last_error.argtypes = [vp]
+    lib.qd_last_error.restype = ctypes.c_char_p
+    lib.qd_upload.argtypes = [vp, i32, vp, sz]
+    lib.qd_download.argtypes = [vp, i32, vp, sz]
+    lib.qd_set_params.argtypes = [vp, ctypes.POINTER(qd_params), sz]
+    lib.qd_get_step_counter.argtypes = [vp, ctypes.POINTER(i64), ctypes.POINTER(i64)]
+    lib.qd_set_step_counter.argtypes = [vp, i64, i64]
+    lib.qd_forcing.argtypes = [vp, dp, dp, dbl, i32]
+    lib.qd_simple_albedo.argtypes = [vp, dbl]
+    lib.qd_atmos_step.argtypes = [vp, dbl, i32]
+    lib.qd_ocean_step.argtypes = [vp, dbl, i32, i32, i32]
+    lib.qd_driver_physics.argtypes = [vp, dbl]
+    lib.qd_step_n.argtypes = [vp, i32, dbl, i32, dp]
+    lib.qd_last_ocean_nsub.argtypes = [vp, ctypes.POINTER(i32)]
+    lib.qd_sync.argtypes = [vp]
+    lib.qd_op_laplacian.argtypes = [vp, vp, i32, vp]
+    lib.qd_op_hyperdiffuse.argtypes = [vp, vp, vp, dbl, dbl, i32, i32, vp]
+    lib.qd_op_advect.argtypes = [vp, vp, vp, vp, dbl, i32, vp]
+    lib.qd_op_shapiro.argtypes = [vp, vp, i32, vp]
+    lib.qd_op_divergence.argtypes = [vp, vp, vp, vp]
+    lib.qd_op_vorticity.argtypes = [vp, vp, vp, vp]
+    lib.qd_op_gaussian.argtypes = [vp, vp, dbl, i32, vp]
+    lib.qd_op_median_positive.argtypes = [vp, vp, dbl, dp]
+    lib.qd_reduce.argtypes = [vp, i32, i32, dp]
+    lib.qd_comm_unique_id.argtypes = [vp, sz]
+    lib.qd_comm_init.argtypes = [vp, vp, sz]
+    lib.qd_comm_barrier.argtypes = [vp]
+    lib.qd_comm_allreduce_max.argtypes = [vp, dp, i32]
+    lib.qd_timing_enable.argtypes = [vp, i32]
+    lib.qd_timing_select.argtypes = [vp, ctypes.c_char_p]
+    lib.qd_timing_get.argtypes = [vp, ctypes.c_char_p, dp, ctypes.POINTER(i64)]
+    lib.qd_timing_reset.argtypes = [vp]
+    for s in SYMBOLS:
+        fn = getattr(lib, s)
+        if s not in ("qd_last_error",):
+            fn.restype = i32
+    lib.qd_last_error.restype = ctypes.c_char_p
+    _lib = lib
+    return lib

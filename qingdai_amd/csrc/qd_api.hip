@@ -1,0 +1,528 @@
+// qd_api.hip -- the C-ABI of include/qingdai_hip.h: context, memory, tables, operator seam.
+#include "qd_internal.h"
+#include <cstring>
+#include <cstdio>
+#include <algorithm>
+
+thread_local std::string g_qd_create_err;
+
+int qd_fail(qd_ctx* c, const char* what, hipError_t e) {
+    std::string m = what ? what : "error";
+    if (e != hipSuccess) { m += ": "; m += hipGetErrorString(e); }
+    if (c) c->err = m; else g_qd_create_err = m;
+    return -1;
+}
+
+static hipEvent_t qd_get_event(qd_ctx* c) {
+    if (!c->ev_free.empty()) { hipEvent_t e = c->ev_free.back(); c->ev_free.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    hipEventCreate(&e);
+    return e;
+}
+QdScope::QdScope(qd_ctx* c_, const char* n) : c(c_), name(n) {
+    on = c->timing == 1 || (c->timing == 2 && c->timing_sel == n);
+    if (on) { e0 = qd_get_event(c); e1 = qd_get_event(c); hipEventRecord(e0, c->stream); }
+}
+QdScope::~QdScope() {
+    if (on) { hipEventRecord(e1, c->stream); c->pending.push_back({e0, e1, name}); }
+}
+static void qd_resolve_timers(qd_ctx* c) {
+    if (c->pending.empty()) return;
+    hipStreamSynchronize(c->stream);
+    for (auto& p : c->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) { QdTimer& t = c->timers[p.name]; t.total_ms += ms; t.n += 1; }
+        c->ev_free.push_back(p.e0); c->ev_free.push_back(p.e1);
+    }
+    c->pending.clear();
+}
+
+double* qd_scratch(qd_ctx* c, int i) { return c->scratch[i]; }
+void qd_swap(qd_ctx* c, int field, int si) { std::swap(c->f[field], c->scratch[si]); }
+
+// ------------------------------------------------------------------ tables
+static double* dev_table(qd_ctx* c, const std::vector<double>& v) {
+    double* d = nullptr;
+    if (hipMalloc(&d, v.size() * sizeof(double)) != hipSuccess) return nullptr;
+    hipMemcpy(d, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice);
+    c->tab_alloc.push_back(d);
+    return d;
+}
+
+static std::vector<double> linspace(double a, double b, int n) {
+    // numpy.linspace: start + arange(n) * step, last sample forced to `stop`
+    std::vector<double> v(n);
+    const double step = (b - a) / (double)(n - 1);
+    for (int i = 0; i < n; ++i) v[i] = a + (double)i * step;
+    if (n > 1) v[n - 1] = b;
+    return v;
+}
+
+static int build_tables(qd_ctx* c) {
+    const int nlat = c->geo.nlat, nlon = c->geo.nlon;
+    const double d2r = M_PI / 180.0;
+    std::vector<double> lat = linspace(-90.0, 90.0, nlat), lon = linspace(0.0, 360.0, nlon);
+    c->dlat = (lat[1] - lat[0]) * d2r;        // np.deg2rad(lat[1]-lat[0])   grid.py:37-38
+    c->dlon = (lon[1] - lon[0]) * d2r;
+    std::vector<double> cr(nlat), sr(nlat), c6(nlat), c3(nlat), c02(nlat), c05(nlat), fc(nlat), wa(nlat), rx(nlat);
+    const qd_params& p = c->p;
+    for (int i = 0; i < nlat; ++i) {
+        const double phi = lat[i] * d2r;
+        cr[i] = std::cos(phi); sr[i] = std::sin(phi);
+        c6[i] = std::max(cr[i], 1e-6); c3[i] = std::max(cr[i], 1e-3);
+        c02[i] = std::max(cr[i], 0.2); c05[i] = std::max(cr[i], 0.5);
+        fc[i] = 2 * p.omega * sr[i];
+        wa[i] = std::max(cr[i], 0.0);
+        const double lat_deg = std::fabs(phi * (180.0 / M_PI));          // ocean.py:332
+        double s = (lat_deg - p.polar_sponge_lat) / std::max(1e-6, 90.0 - p.polar_sponge_lat);
+        s = std::min(std::max(s, 0.0), 1.0);
+        rx[i] = p.polar_sponge_gain * (s * s);
+    }
+    std::vector<double> lr(nlon), sl(nlon), cl(nlon);
+    for (int j = 0; j < nlon; ++j) { lr[j] = lon[j] * d2r; sl[j] = std::sin(lr[j]); cl[j] = std::cos(lr[j]); }
+    QdTabs& T = c->tabs;
+    T.cos_raw = dev_table(c, cr); T.sin_raw = dev_table(c, sr); T.cos6 = dev_table(c, c6); T.cos3 = dev_table(c, c3);
+    T.cos02 = dev_table(c, c02); T.cos05 = dev_table(c, c05); T.fcor = dev_table(c, fc); T.warea = dev_table(c, wa);
+    T.r_extra = dev_table(c, rx);
+    T.lon_rad = dev_table(c, lr); T.sin_lon = dev_table(c, sl); T.cos_lon = dev_table(c, cl);
+    if (!T.cos_raw || !T.lon_rad || !T.cos_lon) return -1;
+    double ws = 0.0;
+    for (int i = 0; i < nlat; ++i) ws += wa[i] * nlon;
+    c->wsum_all = ws;
+    return 0;
+}
+
+// k4 row maps: sigma4 * min(a dphi, a dlam cos)^4 / max(1e-12, dt)   (dynamics.py:557-570, ocean.py:343-352)
+int qd_build_k4_tables(qd_ctx* c, double dt, bool ocean, double sub_dt) {
+    const int nlat = c->geo.nlat;
+    const qd_params& p = c->p;
+    const double d2r = M_PI / 180.0;
+    std::vector<double> lat = linspace(-90.0, 90.0, nlat);
+    auto isset = [](double x) { return !(x != x); };
+    if (!ocean) {
+        if (c->k4_atm_dt == dt) return 0;
+        std::vector<double> tab((size_t)5 * nlat);
+        const double scale[5] = {1.0, 1.0, 0.5, 0.5, 0.25};
+        const double ov[5] = {p.k4_u, p.k4_v, p.k4_h, p.k4_q, p.k4_cloud};
+        bool anypos[5] = {false, false, false, false, false};
+        for (int i = 0; i < nlat; ++i) {
+            const double cs = std::max(std::cos(lat[i] * d2r), 1e-3);
+            const double dxm = std::min(p.a * c->dlat, p.a * c->dlon * cs);
+            const double base = p.sigma4 * std::pow(dxm, 4.0) / std::max(1e-12, dt);
+            for (int f = 0; f < 5; ++f) {
+                const double k = (scale[f] == 1.0) ? base : scale[f] * base;
+                tab[(size_t)f * nlat + i] = k;
+                if (k > 0.0) anypos[f] = true;
+            }
+        }
+        for (int f = 0; f < 5; ++f) {
+            const bool pos = isset(ov[f]) ? (ov[f] > 0.0) : anypos[f];
+            bool apply = pos;                                    // _hyperdiffuse early-outs when k4 <= 0
+            // q / cloud are only *called* when k4>0 or QD_DIFF_Q/CLOUD=1 (dynamics.py:589-594); the call
+            // itself still early-outs for k4<=0, so `pos` decides in every case.
+            c->k4_atm_skip[f] = apply ? 0 : 1;
+        }
+        QD_HIP(c, hipMemcpy(c->k4_atm, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+        c->k4_atm_dt = dt;
+    } else {
+        if (c->k4_ocn_dt == sub_dt) return 0;
+        std::vector<double> tab((size_t)3 * nlat);
+        const double ov[3] = {p.ocean_k4_u, p.ocean_k4_v, p.ocean_k4_eta};
+        bool anypos[3] = {false, false, false};
+        for (int i = 0; i < nlat; ++i) {
+            const double cs = std::max(std::cos(lat[i] * d2r), 0.5);
+            const double dxm = std::min(p.a * c->dlat, p.a * c->dlon * cs);
+            const double base = p.sigma4_ocean * std::pow(dxm, 4.0) / std::max(1e-12, sub_dt);
+            tab[i] = base; tab[(size_t)nlat + i] = base; tab[(size_t)2 * nlat + i] = 0.5 * base;
+            if (base > 0) { anypos[0] = anypos[1] = true; }
+            if (0.5 * base > 0) anypos[2] = true;
+        }
+        for (int f = 0; f < 3; ++f) c->k4_ocn_skip[f] = (isset(ov[f]) ? (ov[f] > 0.0) : anypos[f]) ? 0 : 1;
+        QD_HIP(c, hipMemcpy(c->k4_ocn, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+        c->k4_ocn_dt = sub_dt;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------ init kernels
+__global__ void __launch_bounds__(QD_BLOCK)
+k_init_state(QdGeom G, QdTabs T, double H, double q0, double* __restrict__ h, double* __restrict__ Ts,
+             double* __restrict__ q, double* __restrict__ sst) {
+    const int j = blockIdx.x * QD_BLOCK + threadIdx.x;
+    if (j >= G.nlon) return;
+    const int l = blockIdx.y;                 // every local row incl. halo
+    int g = l + G.row0 - G.halo;
+    if (g < 0) g += G.nlat; if (g >= G.nlat) g -= G.nlat;
+    const size_t o = (size_t)l * G.nlon + j;
+    const double s = T.sin_raw[g];
+    h[o] = H + 300 * (s * s);                 // dynamics.py:60-62
+    Ts[o] = 288.0; q[o] = q0; sst[o] = 288.0;
+}
+
+static double host_qsat(double T, double p0) {
+    double T_c = std::min(std::max(T - 273.15, -80.0), 60.0);
+    double e_s = 610.94 * std::exp(17.625 * T_c / (T_c + 243.04));
+    double denom = std::max(p0 - (1.0 - 0.622) * e_s, 1.0);
+    return std::min(std::max(0.622 * e_s / denom, 0.0), 0.5);
+}
+
+// ------------------------------------------------------------------ lifetime
+extern "C" int qd_abi_version(void) { return QD_ABI_VERSION; }
+
+extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double q_init_rh, qd_handle* out) {
+    if (!d || !params || !out) return qd_fail(nullptr, "qd_create: null argument");
+    if (d->n_lat < 5 || d->n_lon < 4) return qd_fail(nullptr, "qd_create: grid too small (need n_lat>=5, n_lon>=4)");
+    if (d->row0 < 0 || d->n_rows < 1 || d->row0 + d->n_rows > d->n_lat || d->halo < 0)
+        return qd_fail(nullptr, "qd_create: bad latitude band");
+    const bool full = (d->row0 == 0 && d->n_rows == d->n_lat);
+    if (full && d->halo != 0) return qd_fail(nullptr, "qd_create: a whole-globe handle takes halo = 0");
+    if (!full && d->halo < 5) return qd_fail(nullptr, "qd_create: band handles need halo >= 5 rows");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return qd_fail(nullptr, "qd_create: no HIP device visible");
+    if (d->device < 0 || d->device >= ndev) return qd_fail(nullptr, "qd_create: bad device ordinal");
+    qd_ctx* c = new qd_ctx();
+    c->desc = *d; c->p = *params;
+    c->geo = QdGeom{d->n_lat, d->n_lon, d->row0, d->n_rows, d->halo, full ? 1 : 0};
+    auto bail = [&](const char* w, hipError_t e) { qd_fail(nullptr, w, e); qd_destroy(c); return -1; };
+    hipError_t e;
+    if ((e = hipSetDevice(d->device)) != hipSuccess) return bail("hipSetDevice", e);
+    if ((e = hipStreamCreate(&c->stream)) != hipSuccess) return bail("hipStreamCreate", e);
+    const size_t cells = c->geo.cells();
+    for (int f = 0; f < QD_F_COUNT_F64; ++f) {
+        if ((e = hipMalloc(&c->f[f], cells * sizeof(double))) != hipSuccess) return bail("hipMalloc field", e);
+        hipMemsetAsync(c->f[f], 0, cells * sizeof(double), c->stream);
+    }
+    for (int s = 0; s < QD_NSCRATCH; ++s) {
+        if ((e = hipMalloc(&c->scratch[s], cells * sizeof(double))) != hipSuccess) return bail("hipMalloc scratch", e);
+        hipMemsetAsync(c->scratch[s], 0, cells * sizeof(double), c->stream);
+    }
+    if ((e = hipMalloc(&c->land, cells)) != hipSuccess) return bail("hipMalloc mask", e);
+    if ((e = hipMalloc(&c->icemask, cells)) != hipSuccess) return bail("hipMalloc mask", e);
+    hipMemsetAsync(c->land, 0, cells, c->stream); hipMemsetAsync(c->icemask, 0, cells, c->stream);
+    if (build_tables(c)) return bail("table allocation", hipErrorOutOfMemory);
+    if ((e = hipMalloc(&c->k4_atm, (size_t)5 * d->n_lat * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc(&c->k4_ocn, (size_t)3 * d->n_lat * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
+    c->red_blocks = 8 * c->geo.lrows() + 64;
+    if ((e = hipMalloc(&c->red_partial, (size_t)c->red_blocks * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc(&c->dscal, QD_S_COUNT * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc(&c->dcount, 8 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc(&c->hist, 2 * QD_HIST_BINS * sizeof(unsigned int))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc(&c->sel_state, 8 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+    hipMemsetAsync(c->dscal, 0, QD_S_COUNT * sizeof(double), c->stream);
+    hipMemsetAsync(c->dcount, 0, 8 * sizeof(unsigned long long), c->stream);
+    if ((e = hipHostMalloc((void**)&c->hpin, 64 * sizeof(double))) != hipSuccess) return bail("hipHostMalloc", e);
+    // reference initial state
+    const double q0 = std::min(std::max(q_init_rh, 0.0), 1.0) * host_qsat(288.0, params->p0);
+    hipLaunchKernelGGL(k_init_state, dim3((d->n_lon + QD_BLOCK - 1) / QD_BLOCK, c->geo.lrows()), dim3(QD_BLOCK), 0,
+                       c->stream, c->geo, c->tabs, params->H, q0, c->f[QD_F_H], c->f[QD_F_TS], c->f[QD_F_Q], c->f[QD_F_SST]);
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail("init", e);
+    *out = c;
+    return 0;
+}
+
+extern "C" int qd_destroy(qd_handle c) {
+    if (!c) return 0;
+    hipSetDevice(c->desc.device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (int f = 0; f < QD_F_COUNT_F64; ++f) if (c->f[f]) hipFree(c->f[f]);
+    for (int s = 0; s < QD_NSCRATCH; ++s) if (c->scratch[s]) hipFree(c->scratch[s]);
+    for (double* t : c->tab_alloc) hipFree(t);
+    if (c->land) hipFree(c->land); if (c->icemask) hipFree(c->icemask);
+    if (c->k4_atm) hipFree(c->k4_atm); if (c->k4_ocn) hipFree(c->k4_ocn);
+    if (c->red_partial) hipFree(c->red_partial); if (c->dscal) hipFree(c->dscal);
+    if (c->dcount) hipFree(c->dcount); if (c->hist) hipFree(c->hist); if (c->sel_state) hipFree(c->sel_state);
+    if (c->hpin) hipHostFree(c->hpin);
+    if (c->stage) hipHostFree(c->stage);
+    qd_resolve_timers(c);
+    for (hipEvent_t e : c->ev_free) hipEventDestroy(e);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+extern "C" const char* qd_last_error(qd_handle c) { return c ? c->err.c_str() : g_qd_create_err.c_str(); }
+
+// ------------------------------------------------------------------ upload / download
+// Host arrays are GLOBAL [n_lat][n_lon]; the handle copies its band (+ halo rows, period-n_lat
+// at the poles) in, and its owned rows out.
+static int band_copy_in(qd_ctx* c, void* dst, const void* host, size_t esz) {
+    const QdGeom& G = c->geo;
+    const size_t rowb = (size_t)G.nlon * esz;
+    if (G.full) return hipMemcpyAsync(dst, host, rowb * G.nlat, hipMemcpyHostToDevice, c->stream) == hipSuccess ? 0 : -1;
+    for (int l = 0; l < G.lrows(); ++l) {
+        int g = l + G.row0 - G.halo;
+        if (g < 0) g += G.nlat; if (g >= G.nlat) g -= G.nlat;
+        if (hipMemcpyAsync((char*)dst + (size_t)l * rowb, (const char*)host + (size_t)g * rowb, rowb,
+                           hipMemcpyHostToDevice, c->stream) != hipSuccess) return -1;
+    }
+    return 0;
+}
+
+extern "C" int qd_upload(qd_handle c, int field, const void* host, size_t bytes) {
+    if (!c || !host) return -1;
+    hipSetDevice(c->desc.device);
+    const size_t n = (size_t)c->geo.nlat * c->geo.nlon;
+    if (field == QD_F_LAND_MASK || field == QD_F_ICE_MASK) {
+        if (bytes != n) return qd_fail(c, "qd_upload: mask size mismatch");
+        uint8_t* dst = field == QD_F_LAND_MASK ? c->land : c->icemask;
+        if (band_copy_in(c, dst, host, 1)) return qd_fail(c, "qd_upload: copy failed");
+    } else {
+        if (field < 0 || field >= QD_F_COUNT_F64) return qd_fail(c, "qd_upload: unknown field");
+        if (bytes != n * sizeof(double)) return qd_fail(c, "qd_upload: size mismatch (expect n_lat*n_lon float64)");
+        if (band_copy_in(c, c->f[field], host, sizeof(double))) return qd_fail(c, "qd_upload: copy failed");
+        if (field == QD_F_CLOUD_EFF) c->cloud_eff_valid = 1;
+    }
+    QD_HIP(c, hipStreamSynchronize(c->stream));    // host buffer is only borrowed for the call
+    if (field == QD_F_LAND_MASK) {
+        // area-weighted ocean weight sum for the eta mean removal (ocean.py:372-374)
+        const uint8_t* m = (const uint8_t*)host;
+        const int nlat = c->geo.nlat, nlon = c->geo.nlon;
+        double ws = 0.0;
+        for (int i = 0; i < nlat; ++i) {
+            const double w = std::max(std::cos((-90.0 + 180.0 * i / (double)(nlat - 1)) * (M_PI / 180.0)), 0.0);
+            int cnt = 0;
+            for (int j = 0; j < nlon; ++j) cnt += (m[(size_t)i * nlon + j] == 0);
+            ws += w * cnt;
+        }
+        c->wsum_ocean = ws;
+    }
+    return 0;
+}
+
+extern "C" int qd_download(qd_handle c, int field, void* host, size_t bytes) {
+    if (!c || !host) return -1;
+    hipSetDevice(c->desc.device);
+    const QdGeom& G = c->geo;
+    const size_t n = (size_t)G.nlat * G.nlon;
+    const void* src; size_t esz;
+    if (field == QD_F_LAND_MASK || field == QD_F_ICE_MASK) { src = field == QD_F_LAND_MASK ? c->land : c->icemask; esz = 1; }
+    else {
+        if (field < 0 || field >= QD_F_COUNT_F64) return qd_fail(c, "qd_download: unknown field");
+        src = c->f[field]; esz = sizeof(double);
+    }
+    if (bytes != n * esz) return qd_fail(c, "qd_download: size mismatch");
+    const size_t rowb = (size_t)G.nlon * esz;
+    QD_HIP(c, hipMemcpyAsync((char*)host + (size_t)G.row0 * rowb, (const char*)src + (size_t)G.halo * rowb,
+                             rowb * G.nrows, hipMemcpyDeviceToHost, c->stream));
+    QD_HIP(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int qd_set_params(qd_handle c, const qd_params* p, size_t sz) {
+    if (!c || !p) return -1;
+    if (sz != sizeof(qd_params)) return qd_fail(c, "qd_set_params: struct size mismatch (ABI drift)");
+    const bool tabs_stale = (p->omega != c->p.omega) || (p->polar_sponge_lat != c->p.polar_sponge_lat) ||
+                            (p->polar_sponge_gain != c->p.polar_sponge_gain);
+    c->p = *p;
+    c->k4_atm_dt = -1; c->k4_ocn_dt = -1;
+    if (tabs_stale) {
+        hipSetDevice(c->desc.device);
+        hipStreamSynchronize(c->stream);
+        for (double* t : c->tab_alloc) hipFree(t);
+        c->tab_alloc.clear();
+        if (build_tables(c)) return qd_fail(c, "qd_set_params: table rebuild failed");
+    }
+    return 0;
+}
+
+extern "C" int qd_get_step_counter(qd_handle c, int64_t* a, int64_t* o) {
+    if (!c) return -1; if (a) *a = c->atm_counter; if (o) *o = c->ocn_counter; return 0;
+}
+extern "C" int qd_set_step_counter(qd_handle c, int64_t a, int64_t o) {
+    if (!c) return -1; c->atm_counter = a; c->ocn_counter = o; return 0;
+}
+extern "C" int qd_sync(qd_handle c) {
+    if (!c) return -1;
+    hipSetDevice(c->desc.device);
+    QD_HIP(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+extern "C" int qd_last_ocean_nsub(qd_handle c, int* n) { if (!c || !n) return -1; *n = c->last_nsub; return 0; }
+
+// ------------------------------------------------------------------ the path
+extern "C" int qd_forcing(qd_handle c, const double sa[3], const double sb[3], double theta, int with_teq) {
+    if (!c || !sa || !sb) return -1;
+    hipSetDevice(c->desc.device);
+    return qd_forcing_impl(c, sa, sb, theta, with_teq);
+}
+extern "C" int qd_simple_albedo(qd_handle c, double ocean_albedo) {
+    if (!c) return -1;
+    hipSetDevice(c->desc.device);
+    return qd_simple_albedo_impl(c, ocean_albedo);
+}
+extern "C" int qd_atmos_step(qd_handle c, double dt, int has_albedo) {
+    if (!c) return -1;
+    hipSetDevice(c->desc.device);
+    int rc = qd_atmos_step_impl(c, dt, has_albedo);
+    if (rc) return rc;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return qd_fail(c, "qd_atmos_step: launch", e);
+    return 0;
+}
+extern "C" int qd_ocean_step(qd_handle c, double dt, int compute_qnet, int use_ice_mask, int inject_sst) {
+    if (!c) return -1;
+    hipSetDevice(c->desc.device);
+    int rc = qd_ocean_step_impl(c, dt, compute_qnet, use_ice_mask, inject_sst);
+    if (rc) return rc;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return qd_fail(c, "qd_ocean_step: launch", e);
+    return 0;
+}
+extern "C" int qd_driver_physics(qd_handle c, double dt) {
+    if (!c) return -1;
+    hipSetDevice(c->desc.device);
+    int rc = qd_driver_physics_impl(c, dt);
+    if (rc) return rc;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return qd_fail(c, "qd_driver_physics: launch", e);
+    return 0;
+}
+
+extern "C" int qd_step_n(qd_handle c, int n, double dt, int flags, const double* stars) {
+    if (!c || !stars) return -1;
+    hipSetDevice(c->desc.device);
+    const int with_ocean = flags & 1, with_phys = flags & 2, pass_alb = flags & 4;
+    for (int s = 0; s < n; ++s) {
+        const double* st = stars + (size_t)7 * s;
+        int rc;
+        if (with_phys) { if ((rc = qd_driver_physics_impl(c, dt))) return rc; }
+        else if ((rc = qd_simple_albedo_impl(c, 0.08))) return rc;
+        if ((rc = qd_forcing_impl(c, st, st + 3, st[6], 1))) return rc;
+        if ((rc = qd_atmos_step_impl(c, dt, pass_alb ? 1 : 0))) return rc;
+        if (with_ocean && (rc = qd_ocean_step_impl(c, dt, 1, 1, 1))) return rc;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return qd_fail(c, "qd_step_n: launch", e);
+    return 0;
+}
+
+// ------------------------------------------------------------------ operator seam
+static int seam_in(qd_ctx* c, double* dst, const double* host) {
+    if (band_copy_in(c, dst, host, sizeof(double))) return qd_fail(c, "operator seam: upload failed");
+    return 0;
+}
+static int seam_out(qd_ctx* c, const double* src, double* host) {
+    const QdGeom& G = c->geo;
+    const size_t rowb = (size_t)G.nlon * sizeof(double);
+    QD_HIP(c, hipMemcpyAsync((char*)host + (size_t)G.row0 * rowb, (const char*)src + (size_t)G.halo * rowb,
+                             rowb * G.nrows, hipMemcpyDeviceToHost, c->stream));
+    QD_HIP(c, hipStreamSynchronize(c->stream));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return qd_fail(c, "operator seam: kernel", e);
+    return 0;
+}
+
+extern "C" int qd_op_laplacian(qd_handle c, const double* F, int cos_kind, double* out) {
+    if (!c || !F || !out) return -1;
+    hipSetDevice(c->desc.device);
+    double* in = c->scratch[10];
+    if (seam_in(c, in, F)) return -1;
+    QdFieldList fl; fl.n = 1; fl.in[0] = in; fl.out[0] = c->scratch[11]; fl.aux[0] = nullptr; fl.k4row[0] = nullptr; fl.k4s[0] = 0;
+    qd_launch_laplacian(c, fl, cos_kind ? c->tabs.cos05 : c->tabs.cos02);
+    return seam_out(c, c->scratch[11], out);
+}
+
+extern "C" int qd_op_hyperdiffuse(qd_handle c, const double* F, const double* k4_row, double k4_scalar, double dt,
+                                  int n_substeps, int cos_kind, double* out) {
+    if (!c || !F || !out) return -1;
+    hipSetDevice(c->desc.device);
+    double* in = c->scratch[10];
+    if (seam_in(c, in, F)) return -1;
+    double* tab = c->scratch[12];           // borrow a slab for the row map
+    int skip = 0;
+    double ov = NAN;
+    if (k4_row) {
+        bool anypos = false;
+        for (int i = 0; i < c->geo.nlat; ++i) anypos |= (k4_row[i] > 0.0);
+        skip = anypos ? 0 : 1;
+        QD_HIP(c, hipMemcpyAsync(tab, k4_row, c->geo.nlat * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        QD_HIP(c, hipStreamSynchronize(c->stream));
+    } else { ov = k4_scalar; skip = (k4_scalar > 0.0) ? 0 : 1; }
+    double* fl[1] = {in};
+    double* save10 = c->scratch[10];
+    qd_hyperdiffuse_fields(c, fl, 1, tab, &skip, &ov, dt, n_substeps, cos_kind ? c->tabs.cos05 : c->tabs.cos02);
+    int rc = seam_out(c, fl[0], out);
+    // restore scratch bookkeeping: slot 10 must keep owning a distinct slab
+    if (fl[0] != save10) { for (int s = 0; s < QD_NSCRATCH; ++s) if (c->scratch[s] == save10 && s != 10) { c->scratch[s] = fl[0]; break; } c->scratch[10] = save10; }
+    return rc;
+}
+
+extern "C" int qd_op_advect(qd_handle c, const double* field, const double* u, const double* v, double dt,
+                            int cos_kind, double* out) {
+    if (!c || !field || !u || !v || !out) return -1;
+    hipSetDevice(c->desc.device);
+    if (seam_in(c, c->scratch[10], field) || seam_in(c, c->scratch[11], u) || seam_in(c, c->scratch[12], v)) return -1;
+    qd_launch_advect(c, c->scratch[11], c->scratch[12], cos_kind ? c->tabs.cos05 : c->tabs.cos6, dt,
+                     c->scratch[10], c->scratch[13], nullptr, nullptr, 1.0, 0);
+    return seam_out(c, c->scratch[13], out);
+}
+
+extern "C" int qd_op_shapiro(qd_handle c, const double* F, int n, double* out) {
+    if (!c || !F || !out) return -1;
+    hipSetDevice(c->desc.device);
+    if (seam_in(c, c->scratch[10], F)) return -1;
+    double* fl[1] = {c->scratch[10]};
+    double* save10 = c->scratch[10];
+    qd_shapiro_fields(c, fl, 1, n);
+    int rc = seam_out(c, fl[0], out);
+    if (fl[0] != save10) { for (int s = 0; s < QD_NSCRATCH; ++s) if (c->scratch[s] == save10 && s != 10) { c->scratch[s] = fl[0]; break; } c->scratch[10] = save10; }
+    return rc;
+}
+
+static int seam_divvort(qd_ctx* c, const double* u, const double* v, double* out, int vort) {
+    if (!c || !u || !v || !out) return -1;
+    hipSetDevice(c->desc.device);
+    if (seam_in(c, c->scratch[10], u) || seam_in(c, c->scratch[11], v)) return -1;
+    qd_launch_divvort(c, c->scratch[10], c->scratch[11], c->scratch[12], vort);
+    return seam_out(c, c->scratch[12], out);
+}
+extern "C" int qd_op_divergence(qd_handle c, const double* u, const double* v, double* out) { return seam_divvort(c, u, v, out, 0); }
+extern "C" int qd_op_vorticity(qd_handle c, const double* u, const double* v, double* out) { return seam_divvort(c, u, v, out, 1); }
+
+extern "C" int qd_op_gaussian(qd_handle c, const double* F, double sigma, int mode_wrap, double* out) {
+    if (!c || !F || !out) return -1;
+    hipSetDevice(c->desc.device);
+    if (seam_in(c, c->scratch[10], F)) return -1;
+    if (qd_gaussian(c, c->scratch[10], c->scratch[11], c->scratch[12], sigma, mode_wrap)) return -1;
+    return seam_out(c, c->scratch[11], out);
+}
+
+extern "C" int qd_op_median_positive(qd_handle c, const double* x, double dflt, double* out) {
+    if (!c || !x || !out) return -1;
+    hipSetDevice(c->desc.device);
+    if (seam_in(c, c->scratch[10], x)) return -1;
+    qd_median_positive_dev(c, c->scratch[10], dflt, QD_S_MED_OUT, 0, 0.0);
+    QD_HIP(c, hipMemcpyAsync(c->hpin, c->dscal + QD_S_MED_OUT, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    QD_HIP(c, hipStreamSynchronize(c->stream));
+    *out = c->hpin[0];
+    return 0;
+}
+
+extern "C" int qd_reduce(qd_handle c, int field, int op, double* out) {
+    if (!c || !out) return -1;
+    if (field < 0 || field >= QD_F_COUNT_F64) return qd_fail(c, "qd_reduce: unknown field");
+    hipSetDevice(c->desc.device);
+    double v = 0;
+    const int op1 = (op == QD_R_COSWEIGHTED_MEAN) ? 1 : (op == QD_R_SUM ? 0 : (op == QD_R_MAX ? 2 : (op == QD_R_MIN ? 3 : 4)));
+    if (qd_reduce_field(c, c->f[field], op1, &v)) return -1;
+    if (op == QD_R_COSWEIGHTED_MEAN) v = v / (c->wsum_all + 1e-15);
+    *out = v;
+    return 0;
+}
+
+// ------------------------------------------------------------------ timing
+extern "C" int qd_timing_enable(qd_handle c, int on) { if (!c) return -1; c->timing = on ? 1 : 0; return 0; }
+extern "C" int qd_timing_select(qd_handle c, const char* name) {
+    if (!c || !name) return -1; c->timing = 2; c->timing_sel = name; return 0;
+}
+extern "C" int qd_timing_reset(qd_handle c) { if (!c) return -1; qd_resolve_timers(c); c->timers.clear(); return 0; }
+extern "C" int qd_timing_get(qd_handle c, const char* name, double* mean_ms, int64_t* launches) {
+    if (!c || !name) return -1;
+    hipSetDevice(c->desc.device);
+    qd_resolve_timers(c);
+    auto it = c->timers.find(name);
+    if (it == c->timers.end() || it->second.n == 0) { if (mean_ms) *mean_ms = 0; if (launches) *launches = 0; return 0; }
+    if (mean_ms) *mean_ms = it->second.total_ms / (double)it->second.n;
+    if (launches) *launches = it->second.n;
+    return 0;
+}

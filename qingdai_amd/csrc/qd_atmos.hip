@@ -1,0 +1,395 @@
+// qd_atmos.hip -- SpectralModel.time_step (pygcm/dynamics.py:260-667) on gfx950.
+//
+// Kernel sequence of one atmosphere step (global syncs force the cuts):
+//   k_column<PHASE>   humidity column (humidity.py:85-183) + Newton / explicit energy surface
+//                     temperature incl. sea ice (energy.py:77-449) + radiative / energy h forcing
+//                     -- pointwise, one pass over 11 inputs
+//   [radix-select]    median of P_cond>0 only when QD_PCOND_REF is unset (dynamics.py:344-348)
+//   k_advect          T_s, q semi-Lagrangian gather with the OLD winds, alpha=0.2 (dynamics.py:454-461)
+//   k_momentum        np.gradient(h) + geostrophic relaxation | primitive update (dynamics.py:482-530)
+//   k_laplacian / k_hyper_apply   del^4 on u,v,h,q,cloud batched in one launch each (dynamics.py:533-594)
+//   k_shapiro_pass    every QD_SHAPIRO_EVERY steps (dynamics.py:610-626)
+//   k_final           cloud gather with the NEW winds, decay, 0.998 damp, nan_to_num (dynamics.py:642-667)
+#include "qd_internal.h"
+#include "qd_device.h"
+
+#include "qd_fluxes.h"
+
+struct QdColPtrs {
+    const double *u, *v, *Teq, *isr, *albedo, *csmap;
+    double *h, *Ts, *q, *cloud, *hice;
+    double *E, *Pcond, *LH, *LHrel, *olr, *cloud_eff;
+    const uint8_t* land;
+    const double* pref;                // device scalar: P_ref for the tanh term
+    unsigned long long* npos;          // device counter of P_cond > 0 cells (phase 1)
+};
+
+// PHASE 0: whole column in one pass (P_ref known up front or not needed)
+// PHASE 1: humidity part only (writes q, E, P_cond, LH, LH_release; counts P_cond > 0)
+// PHASE 2: everything after the humidity part (reads the phase-1 outputs back)
+template <int PHASE, bool HAS_ALB>
+__global__ void __launch_bounds__(QD_BLOCK)
+k_column(QdGeom G, QdColP P, QdColPtrs A) {
+    const int j = blockIdx.x * QD_BLOCK + threadIdx.x;
+    if (j >= G.nlon) return;
+    const int i = G.row0 + blockIdx.y;
+    const size_t o = (size_t)qd_lrow(G, i) * G.nlon + j;
+
+    const double u = A.u[o], v = A.v[o], h = A.h[o], Ts = A.Ts[o];
+    const double hice = A.hice[o];
+    const bool land = (A.land[o] == 1);
+    const bool ocean = !land;
+    const double T_a = 288.0 + P.ga * h;
+    const double qsat_air = qd_qsat(T_a, P.p0);
+
+    double q, E, Pc, LH, LHrel;
+    if (PHASE != 2) {
+        // ---- humidity column: dynamics.py:282-297
+        const double fac = land ? P.s_land : ((hice > 1e-6) ? P.s_ice : P.s_ocean);
+        const double V = sqrt(u * u + v * v);
+        const double q0 = A.q[o];
+        const double deficit = qd_max(0.0, qd_qsat(Ts, P.p0) - q0);
+        E = qd_nn(P.rhoCE * V * deficit * fac);
+        LH = P.L_v * E;
+        const double q_evap = q0 + (E / P.M_col) * P.dt;
+        const double excess = qd_max(0.0, q_evap - qsat_air);
+        Pc = (excess / P.tau_c) * P.M_col;
+        double q_next = q_evap - (Pc / P.M_col) * P.dt;
+        q_next = qd_clip(qd_nn(q_next), 0.0, 0.5);
+        Pc = qd_nn(Pc);
+        LHrel = P.L_v * Pc;
+        q = qd_clip(qd_nn(q_next), 0.0, 0.5);
+        A.q[o] = q; A.E[o] = E; A.Pcond[o] = Pc; A.LH[o] = LH; A.LHrel[o] = LHrel;
+        if (PHASE == 1) {
+            const unsigned long long m = __ballot(Pc > 0.0);
+            if ((threadIdx.x & 63) == 0 && m) atomicAdd(A.npos, (unsigned long long)__popcll(m));
+            return;
+        }
+    } else {
+        q = A.q[o]; E = A.E[o]; Pc = A.Pcond[o]; LH = A.LH[o]; LHrel = A.LHrel[o];
+    }
+
+    // ---- Newton path: dynamics.py:304-322
+    const double Teq = A.Teq[o];
+    const double olr_old = P.sigma * qd_pow4(Ts);
+    const double net_old = P.sigma * qd_pow4(Teq) + P.gfs * qd_pow4(T_a) - olr_old;
+    const double Ts_newton = Ts + (net_old / P.c_sfc_safe) * P.dt;
+
+    double Ts_new, h_new = h;
+    QdFlux F;
+    if (HAS_ALB) {
+        // ---- cloud optical consistency: dynamics.py:329-353
+        const double cloud = A.cloud[o];
+        double cloud_eff;
+        if (P.couple) {
+            const double RH = qd_clip(q / qd_max(1e-12, qsat_air), 0.0, 1.5);
+            const double rh_excess = qd_max(0.0, RH - P.rh0);
+            const double P_ref = *A.pref;
+            const double p_term = tanh(P_ref > 0 ? Pc / P_ref : 0.0);
+            cloud_eff = qd_clip(cloud + P.k_q * rh_excess + P.k_p * p_term, 0.0, 1.0);
+        } else cloud_eff = cloud;
+        A.cloud_eff[o] = cloud_eff;
+        F = qd_surface_fluxes(P, A.isr[o], A.albedo[o], cloud_eff, Ts, T_a, u, v, land, hice);
+        double Ts_energy;
+        if (P.seaice) {
+            // ---- energy.py:291-420
+            double Q = F.SW_sfc - F.LW_sfc - F.SH - LH;
+            double Tn = Ts, hi = hice;
+            if (hi > 0.0 && ocean && Q > 0.0) {
+                const double dh_melt = (Q * P.dt) / P.rhoiLf;
+                const double dh_cap = qd_min(dh_melt, hi);
+                hi -= dh_cap;
+                Q = Q - (dh_cap * P.rho_i * P.L_f) / P.dt;
+            }
+            if (ocean && Q < 0.0 && Tn <= (P.t_freeze + 0.5)) {
+                hi += (-Q * P.dt) / P.rhoiLf;
+                Q = 0.0;
+                Tn = qd_min(Tn, P.t_freeze);
+            }
+            double Cs = land ? P.Cs_land : (hi > 0.0 ? P.Cs_ice : P.Cs_ocean);
+            Cs = (isfinite(Cs) && Cs > 1e3) ? Cs : 1e3;
+            Tn = Tn + (Q / Cs) * P.dt;
+            if ((i == 0 && P.fix_s) || (i == G.nlat - 1 && P.fix_n)) {
+                if (ocean && Q < 0.0 && Tn > P.t_freeze) Tn = P.t_freeze;
+            }
+            if (hi > 0.0 && ocean) Tn = qd_min(Tn, P.t_freeze);
+            Tn = qd_max(P.t_floor, Tn);
+            Ts_energy = qd_nn(Tn);
+            A.hice[o] = qd_nn(hi);
+        } else {
+            const double net = F.SW_sfc - F.LW_sfc - F.SH - LH;
+            double Cs;
+            if (P.has_csmap) { const double cm = A.csmap[o]; Cs = (isfinite(cm) && cm > 1e3) ? cm : 1e3; }
+            else Cs = P.c_sfc_safe;
+            Ts_energy = qd_nn(qd_max(P.t_floor, Ts + (net / Cs) * P.dt));
+        }
+        A.olr[o] = F.OLR;
+        Ts_new = (1.0 - P.w_energy) * Ts_newton + P.w_energy * Ts_energy;
+    } else {
+        A.olr[o] = olr_old;
+        Ts_new = Ts_newton;
+    }
+    A.Ts[o] = Ts_new;
+
+    // ---- radiative relaxation of h: dynamics.py:464-467; atmosphere energy -> h: 470-480
+    const double h_eq = P.h_eq_fac * Teq;
+    h_new = h + ((h_eq - h) / P.tau_rad) * P.dt;
+    if (HAS_ALB && P.atm_couple) {
+        const double F_atm = F.SW_atm + F.LW_atm + F.SH + LHrel;
+        h_new = qd_nn(h_new + P.atm_w * (F_atm / P.atm_denom) * P.dt);
+    }
+    A.h[o] = h_new;
+}
+
+// ------------------------------------------------------------------ momentum: dynamics.py:482-530
+struct QdMomP { double g, a, dt, dlat, dlon, f_min; int primitive; };
+
+__global__ void __launch_bounds__(QD_BLOCK)
+k_momentum(QdGeom G, QdTabs T, QdMomP P, const double* __restrict__ h, const double* __restrict__ fric,
+           double* __restrict__ u, double* __restrict__ v) {
+    const int j = blockIdx.x * QD_BLOCK + threadIdx.x;
+    if (j >= G.nlon) return;
+    const int i = G.row0 + blockIdx.y;
+    const int n = G.nlat, m = G.nlon;
+    const size_t b = (size_t)qd_lrow(G, i) * m;
+    const size_t o = b + j;
+    // np.gradient(h, dlon, axis=1): NOT periodic
+    double dh_dlon;
+    if (j == 0) dh_dlon = (h[b + 1] - h[b]) / P.dlon;
+    else if (j == m - 1) dh_dlon = (h[b + m - 1] - h[b + m - 2]) / P.dlon;
+    else dh_dlon = (h[b + j + 1] - h[b + j - 1]) / (2.0 * P.dlon);
+    double dh_dlat;
+    if (i == 0) dh_dlat = (h[(size_t)qd_lrow(G, 1) * m + j] - h[o]) / P.dlat;
+    else if (i == n - 1) dh_dlat = (h[o] - h[(size_t)qd_lrow(G, n - 2) * m + j]) / P.dlat;
+    else dh_dlat = (h[(size_t)qd_lrow(G, i + 1) * m + j] - h[(size_t)qd_lrow(G, i - 1) * m + j]) / (2.0 * P.dlat);
+    const double cosc = T.cos6[i];
+    const double f = T.fcor[i];
+    const double r = fric[o];
+    const double u0 = u[o], v0 = v[o];
+    if (P.primitive) {
+        const double PGF_x = -(P.g / (P.a * cosc)) * dh_dlon;
+        const double PGF_y = -(P.g / P.a) * dh_dlat;
+        const double du = (PGF_x + f * v0 - r * u0) * P.dt;
+        const double dv = (PGF_y - f * u0 - r * v0) * P.dt;
+        u[o] = qd_clip(u0 + du, -200.0, 200.0);
+        v[o] = qd_clip(v0 + dv, -200.0, 200.0);
+    } else {
+        const double sgn = (f >= 0.0) ? 1.0 : -1.0;
+        const double f_safe = (fabs(f) < P.f_min) ? sgn * P.f_min : f;
+        const double u_g = qd_clip(-(P.g / (f_safe * P.a * cosc)) * dh_dlat, -200.0, 200.0);
+        const double v_g = qd_clip((P.g / (f_safe * P.a)) * dh_dlon, -200.0, 200.0);
+        double un = u0 * 0.8 + u_g * 0.2;
+        double vn = v0 * 0.8 + v_g * 0.2;
+        un = un + (-r * un) * P.dt;
+        vn = vn + (-r * vn) * P.dt;
+        u[o] = un; v[o] = vn;
+    }
+}
+
+// ------------------------------------------------------------------ final: dynamics.py:642-667
+// cloud <- advect(cloud) with the post-filter winds, 2-day decay, then the global damp and the
+// nan_to_num scrub of every prognostic field.  Winds are read unscaled by the gather (it only
+// needs the cell's own u, v) and written back scaled in the same pass.
+__global__ void __launch_bounds__(QD_BLOCK)
+k_final(QdGeom G, const double* __restrict__ cosl, double dt, double a, double dlat, double dlon,
+        double* __restrict__ u, double* __restrict__ v, double* __restrict__ h, double* __restrict__ Ts,
+        double* __restrict__ q, const double* __restrict__ cloud_in, double* __restrict__ cloud_out,
+        double decay, double dfac) {
+    const int j = blockIdx.x * QD_BLOCK + threadIdx.x;
+    if (j >= G.nlon) return;
+    const int i = G.row0 + blockIdx.y;
+    const size_t o = (size_t)qd_lrow(G, i) * G.nlon + j;
+    const double uu = u[o], vv = v[o];
+    const QdBilin b = qd_departure(G, i, j, uu, vv, dt, a, cosl[i], dlat, dlon);
+    double c = qd_gather(cloud_in, G, b);
+    c = c * decay;
+    cloud_out[o] = qd_nn(c * dfac);
+    u[o] = qd_nn(uu * dfac);
+    v[o] = qd_nn(vv * dfac);
+    h[o] = qd_nn(h[o] * dfac);
+    q[o] = qd_nn(q[o] * dfac);
+    Ts[o] = qd_nn(Ts[o]);
+}
+
+// ------------------------------------------------------------------ forcing.py:78-165
+struct QdStar { double flux, sin_d, cos_d, alpha; };
+
+__global__ void __launch_bounds__(QD_BLOCK)
+k_forcing(QdGeom G, QdTabs T, QdStar A, QdStar B, double theta, double sigma, int with_teq,
+          double* __restrict__ isrA, double* __restrict__ isrB, double* __restrict__ isr,
+          const double* __restrict__ albedo, double* __restrict__ Teq) {
+    const int j = blockIdx.x * QD_BLOCK + threadIdx.x;
+    if (j >= G.nlon) return;
+    const int i = G.row0 + blockIdx.y;
+    const size_t o = (size_t)qd_lrow(G, i) * G.nlon + j;
+    const double sl = T.sin_raw[i], cl = T.cos_raw[i], lon = T.lon_rad[j];
+    const double hA = theta + lon - A.alpha;
+    const double hB = theta + lon - B.alpha;
+    const double czA = qd_max(0.0, sl * A.sin_d + cl * A.cos_d * cos(hA));
+    const double czB = qd_max(0.0, sl * B.sin_d + cl * B.cos_d * cos(hB));
+    const double a_ = A.flux * czA, b_ = B.flux * czB;
+    const double tot = a_ + b_;
+    isrA[o] = a_; isrB[o] = b_; isr[o] = tot;
+    if (with_teq) {
+        double num = tot * (1 - albedo[o]);
+        if (num < 0) num = 0;
+        Teq[o] = sqrt(sqrt(num / sigma));          // (num / SIGMA) ** 0.25
+    }
+}
+
+int qd_forcing_impl(qd_ctx* c, const double* sa, const double* sb, double theta, int with_teq) {
+    QdScope sc(c, "forcing");
+    QdStar A{sa[0], std::sin(sa[1]), std::cos(sa[1]), sa[2]};
+    QdStar B{sb[0], std::sin(sb[1]), std::cos(sb[1]), sb[2]};
+    hipLaunchKernelGGL(k_forcing, qd_grid2d(c->geo), dim3(QD_BLOCK), 0, c->stream, c->geo, c->tabs, A, B, theta,
+                       5.670374e-8, with_teq, c->f[QD_F_ISR_A], c->f[QD_F_ISR_B], c->f[QD_F_ISR],
+                       c->f[QD_F_ALBEDO], c->f[QD_F_TEQ]);
+    return 0;
+}
+
+__global__ void __launch_bounds__(QD_BLOCK)
+k_simple_albedo(QdGeom G, const uint8_t* __restrict__ land, const double* __restrict__ base, double ocean_albedo,
+                double* __restrict__ albedo) {
+    const int j = blockIdx.x * QD_BLOCK + threadIdx.x;
+    if (j >= G.nlon) return;
+    const size_t o = (size_t)qd_lrow(G, G.row0 + blockIdx.y) * G.nlon + j;
+    albedo[o] = (land[o] == 0) ? ocean_albedo : base[o];
+}
+
+int qd_simple_albedo_impl(qd_ctx* c, double ocean_albedo) {
+    hipLaunchKernelGGL(k_simple_albedo, qd_grid2d(c->geo), dim3(QD_BLOCK), 0, c->stream, c->geo, c->land,
+                       c->f[QD_F_BASE_ALBEDO], ocean_albedo, c->f[QD_F_ALBEDO]);
+    return 0;
+}
+
+// ------------------------------------------------------------------ host orchestration
+static inline bool qd_isset(double x) { return !(x != x); }
+
+QdColP qd_make_colp(const qd_ctx* c, double dt) {
+    const qd_params& p = c->p;
+    QdColP P;
+    P.ga = p.g / 1004.0;
+    P.M_col = std::max(1e-6, p.rho_a * p.h_mbl);
+    P.tau_c = std::max(1e-6, p.tau_cond);
+    P.L_v = p.L_v; P.p0 = p.p0; P.rhoCE = p.rho_a * p.C_E;
+    P.s_ocean = p.ocean_evap_scale; P.s_land = p.land_evap_scale; P.s_ice = p.ice_evap_scale;
+    P.sigma = 5.670374e-8;
+    P.gfs = p.greenhouse_factor * P.sigma;
+    P.c_sfc_safe = std::max(1e-12, p.c_sfc);
+    P.dt = dt;
+    P.rh0 = p.rh0; P.k_q = p.k_q; P.k_p = p.k_p;
+    P.sw_a0 = p.sw_a0; P.sw_kc = p.sw_kc; P.lw_eps0 = p.lw_eps0; P.lw_kc = p.lw_kc;
+    P.eps_clear = std::min(std::max(p.lw_eps0, 0.0), 1.0);
+    P.tau0 = p.lw_tau0; P.k_tau = p.lw_ktau;
+    P.hice_ref_safe = std::max(1e-6, p.hice_ref);
+    P.eps_ocean = p.eps_ocean; P.eps_land = p.eps_land; P.eps_ice = p.eps_ice; P.eps_default = p.eps_default;
+    P.g_lw = p.gh_factor_lw;
+    P.rhocpch = p.rho_a * p.cp_a * p.ch;
+    P.t_freeze = p.t_freeze; P.rho_i = p.rho_i; P.L_f = p.L_f; P.rhoiLf = p.rho_i * p.L_f;
+    P.Cs_ocean = p.Cs_ocean; P.Cs_land = p.Cs_land; P.Cs_ice = p.Cs_ice; P.t_floor = p.t_floor;
+    P.w_energy = std::min(1.0, std::max(0.0, p.energy_w));
+    P.h_eq_fac = 287.0 / p.g;
+    P.tau_rad = p.tau_rad;
+    const double H_atm = qd_isset(p.atm_h) ? p.atm_h : p.h_mbl;
+    P.atm_denom = std::max(1e-6, p.rho_a) * std::max(1.0, H_atm) * p.g;
+    P.atm_w = p.energy_w;
+    P.atm_couple = (p.energy_w > 0.0) ? 1 : 0;
+    P.couple = p.cloud_couple; P.lw_v2 = p.lw_v2; P.gh_lock = p.gh_lock; P.seaice = p.seaice_enabled;
+    P.fix_s = p.polar_freeze_fix_s; P.fix_n = p.polar_freeze_fix_n; P.has_csmap = p.has_csmap;
+    return P;
+}
+
+__global__ void k_set_scalar(double* p, double v) { if (threadIdx.x == 0 && blockIdx.x == 0) *p = v; }
+__global__ void k_zero_count(unsigned long long* p) { if (threadIdx.x == 0 && blockIdx.x == 0) *p = 0ull; }
+
+int qd_atmos_step_impl(qd_ctx* c, double dt, int has_albedo) {
+    const qd_params& p = c->p;
+    const QdGeom& G = c->geo;
+    const dim3 grid = qd_grid2d(G), blk(QD_BLOCK);
+    if (p.spec_every > 0 && (p.filter_type == 0 || p.filter_type == 3))
+        return qd_fail(c, "zonal-FFT filter (QD_SPEC_EVERY>0) is not available on the device path yet");
+    QdColP P = qd_make_colp(c, dt);
+    QdColPtrs A;
+    A.u = c->f[QD_F_U]; A.v = c->f[QD_F_V]; A.Teq = c->f[QD_F_TEQ]; A.isr = c->f[QD_F_ISR];
+    A.albedo = c->f[QD_F_ALBEDO]; A.csmap = c->f[QD_F_CSMAP];
+    A.h = c->f[QD_F_H]; A.Ts = c->f[QD_F_TS]; A.q = c->f[QD_F_Q]; A.cloud = c->f[QD_F_CLOUD]; A.hice = c->f[QD_F_HICE];
+    A.E = c->f[QD_F_EFLUX]; A.Pcond = c->f[QD_F_PCOND]; A.LH = c->f[QD_F_LH]; A.LHrel = c->f[QD_F_LHREL];
+    A.olr = c->f[QD_F_OLR]; A.cloud_eff = c->f[QD_F_CLOUD_EFF];
+    A.land = c->land; A.pref = c->dscal + QD_S_PREF; A.npos = c->dcount;
+
+    {
+        QdScope sc(c, "column");
+        if (!has_albedo) {
+            hipLaunchKernelGGL((k_column<0, false>), grid, blk, 0, c->stream, G, P, A);
+        } else if (!p.cloud_couple || qd_isset(p.pcond_ref)) {
+            hipLaunchKernelGGL(k_set_scalar, dim3(1), dim3(1), 0, c->stream, c->dscal + QD_S_PREF,
+                               qd_isset(p.pcond_ref) ? p.pcond_ref : 1e-6);
+            hipLaunchKernelGGL((k_column<0, true>), grid, blk, 0, c->stream, G, P, A);
+        } else {
+            hipLaunchKernelGGL((k_column<1, true>), grid, blk, 0, c->stream, G, P, A);
+            qd_median_positive_dev(c, c->f[QD_F_PCOND], 1e-6, QD_S_PREF, 0, 0.0);
+            hipLaunchKernelGGL((k_column<2, true>), grid, blk, 0, c->stream, G, P, A);
+        }
+        if (has_albedo) c->cloud_eff_valid = 1;
+    }
+    c->atm_counter += 1;
+    const int64_t sc_ = c->atm_counter;
+
+    // T_s, q gather with the OLD winds (dynamics.py:454-461)
+    {
+        QdScope sc(c, "advect_tsq");
+        double* oT = qd_scratch(c, 0); double* oq = qd_scratch(c, 1);
+        qd_launch_advect(c, c->f[QD_F_U], c->f[QD_F_V], c->tabs.cos6, dt, c->f[QD_F_TS], oT, c->f[QD_F_Q], oq, 0.2, 1);
+        qd_swap(c, QD_F_TS, 0); qd_swap(c, QD_F_Q, 1);
+    }
+    // momentum (dynamics.py:482-530)
+    {
+        QdScope sc(c, "momentum");
+        QdMomP M;
+        M.g = p.g; M.a = p.a; M.dt = dt; M.dlat = c->dlat; M.dlon = c->dlon;
+        M.f_min = 2.0 * p.omega * std::sin(5.0 * (M_PI / 180.0));
+        M.primitive = p.mom_scheme == 1;
+        hipLaunchKernelGGL(k_momentum, grid, blk, 0, c->stream, G, c->tabs, M, c->f[QD_F_H], c->f[QD_F_FRICTION],
+                           c->f[QD_F_U], c->f[QD_F_V]);
+    }
+    // del^4 (dynamics.py:533-594)
+    const int ft = p.filter_type;
+    if (p.diff_enable && (ft == 0 || ft == 1) && (sc_ % std::max(1, p.diff_every) == 0)) {
+        QdScope sc(c, "hyperdiffusion");
+        int rc = qd_build_k4_tables(c, dt, false, 0.0);
+        if (rc) return rc;
+        double* fl[5] = {c->f[QD_F_U], c->f[QD_F_V], c->f[QD_F_H], c->f[QD_F_Q], c->f[QD_F_CLOUD]};
+        const double ov[5] = {p.k4_u, p.k4_v, p.k4_h, p.k4_q, p.k4_cloud};
+        if (p.k4_nsub == 1) {
+            qd_hyperdiffuse_fields(c, fl, 5, c->k4_atm, c->k4_atm_skip, ov, dt, 1, c->tabs.cos02);
+        } else {
+            // u,v,h use QD_K4_NSUB sub-steps, q and cloud always one (dynamics.py:584-594)
+            int skip3[5] = {c->k4_atm_skip[0], c->k4_atm_skip[1], c->k4_atm_skip[2], 1, 1};
+            int skip2[5] = {1, 1, 1, c->k4_atm_skip[3], c->k4_atm_skip[4]};
+            qd_hyperdiffuse_fields(c, fl, 5, c->k4_atm, skip3, ov, dt, p.k4_nsub, c->tabs.cos02);
+            qd_hyperdiffuse_fields(c, fl, 5, c->k4_atm, skip2, ov, dt, 1, c->tabs.cos02);
+        }
+        c->f[QD_F_U] = fl[0]; c->f[QD_F_V] = fl[1]; c->f[QD_F_H] = fl[2]; c->f[QD_F_Q] = fl[3]; c->f[QD_F_CLOUD] = fl[4];
+    }
+    // Shapiro (dynamics.py:610-626): combo, shapiro AND hyper4 all trigger it
+    if ((ft == 0 || ft == 1 || ft == 2) && p.shapiro_every > 0 && (sc_ % p.shapiro_every == 0)) {
+        QdScope sc(c, "shapiro");
+        double* fl[3] = {c->f[QD_F_U], c->f[QD_F_V], c->f[QD_F_H]};
+        qd_shapiro_fields(c, fl, 3, p.shapiro_n);
+        c->f[QD_F_U] = fl[0]; c->f[QD_F_V] = fl[1]; c->f[QD_F_H] = fl[2];
+        const int n1 = std::max(1, p.shapiro_n - 1);
+        if (p.diff_q) { double* g1[1] = {c->f[QD_F_Q]}; qd_shapiro_fields(c, g1, 1, n1); c->f[QD_F_Q] = g1[0]; }
+        if (p.diff_cloud) { double* g1[1] = {c->f[QD_F_CLOUD]}; qd_shapiro_fields(c, g1, 1, n1); c->f[QD_F_CLOUD] = g1[0]; }
+    }
+    // cloud gather + decay + damp + scrub (dynamics.py:642-667)
+    {
+        QdScope sc(c, "final");
+        double* oc = qd_scratch(c, 0);
+        const double decay = 1 - dt / (2.0 * 24 * 3600);
+        hipLaunchKernelGGL(k_final, grid, blk, 0, c->stream, G, c->tabs.cos6, dt, p.a, c->dlat, c->dlon,
+                           c->f[QD_F_U], c->f[QD_F_V], c->f[QD_F_H], c->f[QD_F_TS], c->f[QD_F_Q],
+                           c->f[QD_F_CLOUD], oc, decay, p.diff_factor);
+        qd_swap(c, QD_F_CLOUD, 0);
+    }
+    return 0;
+}

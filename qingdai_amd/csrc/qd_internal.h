@@ -1,0 +1,196 @@
+// qd_internal.h -- shared definitions for libqingdai_hip.so (gfx950 only).
+//
+// Data layout in HBM: every field is a C-order float64 slab [n_rows + 2*halo][n_lon]
+// holding this handle's latitude band (global rows row0 .. row0+n_rows-1) plus `halo`
+// rows on each side.  Local row l <-> global row g = row0 - halo + l.  Single GPU:
+// row0 = 0, n_rows = n_lat, halo = 0 and the slab is the whole grid.
+// Per-row metrics (cos floors, Coriolis, k4 maps) are 1-D tables indexed by GLOBAL row.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <map>
+#include <cfloat>
+#include <cmath>
+
+#include "../../include/qingdai_hip.h"
+
+#define QD_NSCRATCH 16
+#define QD_BLOCK 256
+#define QD_MAXF 5            // fields per batched stencil launch
+#define QD_HIST_BINS 2048    // 11-bit radix-select digit
+
+struct QdGeom {
+    int nlat, nlon;          // global grid
+    int row0, nrows, halo;   // band
+    int full;                // 1: band == whole globe (row wrap/fold resolved by index arithmetic)
+    __host__ __device__ inline int lrows() const { return nrows + 2 * halo; }
+    __host__ __device__ inline size_t cells() const { return (size_t)lrows() * (size_t)nlon; }
+};
+
+// 1-D metric tables (device pointers).  All indexed by global row, except lon_*.
+struct QdTabs {
+    const double* cos_raw;   // cos(deg2rad(lat))
+    const double* sin_raw;   // sin(deg2rad(lat))
+    const double* cos6;      // max(cos, 1e-6)   dynamics.py:104,490  grid.py:50
+    const double* cos3;      // max(cos, 1e-3)   dynamics.py:559
+    const double* cos02;     // max(cos, 0.2)    dynamics.py:164
+    const double* cos05;     // max(cos, 0.5)    ocean.py:82, run_simulation.py:1145
+    const double* fcor;      // 2 Omega sin(lat) grid.py:90-96
+    const double* warea;     // max(cos,0)       energy.py:520, ocean.py:372
+    const double* r_extra;   // polar sponge gain * s^2   ocean.py:332-334
+    const double* lon_rad;   // deg2rad(lon) [n_lon]
+    const double* sin_lon;   // [n_lon]
+    const double* cos_lon;   // [n_lon]
+};
+
+// ---------------------------------------------------------------- device helpers
+__device__ __forceinline__ double qd_nn(double x) {          // np.nan_to_num
+    if (x != x) return 0.0;
+    if (x > DBL_MAX) return DBL_MAX;
+    if (x < -DBL_MAX) return -DBL_MAX;
+    return x;
+}
+__device__ __forceinline__ double qd_max(double a, double b) {   // np.maximum (NaN propagates)
+    return (a >= b || a != a) ? a : b;
+}
+__device__ __forceinline__ double qd_min(double a, double b) {   // np.minimum
+    return (a <= b || a != a) ? a : b;
+}
+__device__ __forceinline__ double qd_clip(double x, double lo, double hi) {  // np.clip
+    return qd_min(qd_max(x, lo), hi);
+}
+__device__ __forceinline__ double qd_pow4(double x) { double x2 = x * x; return x2 * x2; }
+
+// local row of global row g; in `full` mode rows outside [0,nlat) wrap with period nlat
+// (np.roll(axis=0) semantics); in band mode they address the halo.
+__device__ __forceinline__ int qd_lrow(const QdGeom& G, int g) {
+    if (G.full) {
+        if (g < 0) g += G.nlat; else if (g >= G.nlat) g -= G.nlat;
+        return g;
+    }
+    return g - G.row0 + G.halo;
+}
+// local row of a global row that is already inside [0, nlat) (advection departure rows):
+// band mode lets the polar bands reach the opposite pole through their period-nlat halo.
+__device__ __forceinline__ int qd_lrow_far(const QdGeom& G, int g) {
+    if (G.full) return g;
+    int l = g - G.row0 + G.halo;
+    if (l < 0) l += G.nlat; else if (l >= G.lrows()) l -= G.nlat;
+    if (l < 0) l = 0; if (l >= G.lrows()) l = G.lrows() - 1;   // never fault; flagged by host checks
+    return l;
+}
+__device__ __forceinline__ int qd_wrapc(int j, int n) {        // periodic column
+    return j < 0 ? j + n : (j >= n ? j - n : j);
+}
+
+// ---------------------------------------------------------------- host context
+struct QdTimer { double total_ms = 0; int64_t n = 0; };
+
+struct qd_ctx {
+    qd_grid_desc desc;
+    QdGeom geo;
+    qd_params p;
+    hipStream_t stream = nullptr;
+    double* f[QD_F_COUNT_F64] = {nullptr};
+    uint8_t* land = nullptr;
+    uint8_t* icemask = nullptr;
+    double* scratch[QD_NSCRATCH] = {nullptr};
+    // metric tables
+    std::vector<double*> tab_alloc;
+    QdTabs tabs;
+    double dlat = 0, dlon = 0;
+    double* k4_atm = nullptr;      // [5][nlat] rows: u,v,h,q,cloud
+    double* k4_ocn = nullptr;      // [3][nlat] rows: uo,vo,eta
+    double k4_atm_dt = -1, k4_ocn_dt = -1;
+    int k4_atm_skip[5] = {0}, k4_ocn_skip[3] = {0};
+    // reductions / scalars
+    double* red_partial = nullptr; // [4][max_blocks]
+    int red_blocks = 0;
+    double* dscal = nullptr;       // device scalars (see QD_S_*)
+    unsigned long long* dcount = nullptr;  // device counters
+    unsigned int* hist = nullptr;  // [2][QD_HIST_BINS]
+    unsigned long long* sel_state = nullptr; // radix-select state
+    double* hpin = nullptr;        // pinned host scalars
+    double wsum_ocean = 0, wsum_all = 0;
+    int64_t atm_counter = 0, ocn_counter = 0;
+    int cloud_eff_valid = 0;
+    int last_nsub = 0;
+    // host staging
+    void* stage = nullptr; size_t stage_bytes = 0;
+    // comm
+    void* comm = nullptr;
+    // timing
+    const char* lap_tag = "k_laplacian";       // timing-group names of the two del^4 kernels
+    const char* hyp_tag = "k_hyper_apply";     // (the ocean switches them to ocean_* around its calls)
+    int timing = 0;                 // 0 off, 1 all groups, 2 only `timing_sel`
+    std::string timing_sel;
+    std::map<std::string, QdTimer> timers;
+    struct Pending { hipEvent_t e0, e1; std::string name; };
+    std::vector<Pending> pending;   // recorded, not yet resolved (never synchronises inside a step)
+    std::vector<hipEvent_t> ev_free;
+    std::string err;
+};
+
+// device scalar slots
+enum { QD_S_PREF = 0, QD_S_ETA_MEAN, QD_S_MED_OUT, QD_S_PSCALE, QD_S_RENORM, QD_S_PQMEAN, QD_S_TMP0, QD_S_TMP1,
+       QD_S_COUNT = 16 };
+
+extern thread_local std::string g_qd_create_err;
+
+int qd_fail(qd_ctx* c, const char* what, hipError_t e = hipSuccess);
+#define QD_HIP(c, call) do { hipError_t _e = (call); if (_e != hipSuccess) return qd_fail((c), #call, _e); } while (0)
+
+struct QdScope {               // optional per-kernel-group timing with hipEvents on the handle's stream
+    qd_ctx* c; const char* name; hipEvent_t e0 = nullptr, e1 = nullptr; bool on = false;
+    QdScope(qd_ctx* c_, const char* n);
+    ~QdScope();
+};
+
+static inline dim3 qd_grid2d(const QdGeom& G, int fields = 1) {
+    return dim3((G.nlon + QD_BLOCK - 1) / QD_BLOCK, G.nrows, fields);
+}
+
+// ---- module entry points (host side launchers) ------------------------------------
+struct QdFieldList {
+    const double* in[QD_MAXF];
+    double* out[QD_MAXF];
+    const double* aux[QD_MAXF];   // e.g. original F for the hyper-apply pass
+    const double* k4row[QD_MAXF]; // per-row k4 (global row index) or nullptr
+    double k4s[QD_MAXF];
+    int n;
+};
+
+// qd_stencil.hip
+void qd_launch_laplacian(qd_ctx* c, const QdFieldList& fl, const double* coslat);
+void qd_launch_hyper_apply(qd_ctx* c, const QdFieldList& fl, const double* coslat, double sub_dt);
+int  qd_hyperdiffuse_fields(qd_ctx* c, double** fields, int n, const double* k4tab, const int* skip,
+                            const double* k4s_override, double dt, int nsub, const double* coslat);
+void qd_launch_shapiro_pass(qd_ctx* c, const QdFieldList& fl, int scrub);
+int  qd_shapiro_fields(qd_ctx* c, double** fields, int n, int npass);
+void qd_launch_advect(qd_ctx* c, const double* u, const double* v, const double* coslat, double dt,
+                      const double* f0, double* o0, const double* f1, double* o1, double alpha, int clipq);
+void qd_launch_divvort(qd_ctx* c, const double* u, const double* v, double* out, int vort);
+int  qd_gaussian(qd_ctx* c, const double* in, double* out, double* tmp, double sigma, int mode_wrap);
+
+// qd_reduce.hip
+int qd_reduce_field(qd_ctx* c, const double* x, int op, double* host_out);
+int qd_median_positive_dev(qd_ctx* c, const double* x, double dflt, int slot, int transform, double tparam);
+
+// qd_atmos.hip
+int qd_atmos_step_impl(qd_ctx* c, double dt, int has_albedo);
+int qd_forcing_impl(qd_ctx* c, const double* sa, const double* sb, double theta, int with_teq);
+int qd_simple_albedo_impl(qd_ctx* c, double ocean_albedo);
+
+// qd_ocean.hip
+int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask, int inject_sst);
+
+// qd_physics.hip
+int qd_driver_physics_impl(qd_ctx* c, double dt);
+
+// qd_api.hip
+int qd_build_k4_tables(qd_ctx* c, double dt, bool ocean, double sub_dt);
+double* qd_scratch(qd_ctx* c, int i);
+void qd_swap(qd_ctx* c, int field, int scratch_idx);

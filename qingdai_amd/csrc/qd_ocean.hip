@@ -1,0 +1,410 @@
+// qd_ocean.hip -- WindDrivenSlabOcean.step (pygcm/ocean.py:265-533) and the driver's ocean
+// coupling (scripts/run_simulation.py:2197-2253, benchmark_jax.py:134-158) on gfx950.
+//
+// Per outer step:   k_qnet (SW/LW/SH/LH -> Q_net, ice mask)      run_simulation.py:2199-2239
+//                   k_stress_max (wind stress + CFL maxima)       ocean.py:283-303
+//                   host reads two maxima -> n_sub                ocean.py:301-303
+// Per sub-step:     k_ocean_momentum                              ocean.py:306-336
+//                   k_laplacian / k_hyper_apply on uo,vo,eta      ocean.py:341-356
+//                   k_continuity (+ weighted eta sum)             ocean.py:365-377
+//                   k_sst_advect (eta mean removal folded in)     ocean.py:375,380-382
+//                   k_sst_diffuse_heat                            ocean.py:385-406,440
+//                   k_outlier                                     ocean.py:409-444
+// After:            k_polar_fill (2 workgroups), clamp + SST write-back   ocean.py:519-533
+#include "qd_internal.h"
+#include "qd_device.h"
+
+#include "qd_fluxes.h"
+
+QdColP qd_make_colp(const qd_ctx* c, double dt);   // qd_atmos.hip
+
+// ------------------------------------------------------------------ Q_net for the coupling
+__global__ void __launch_bounds__(QD_BLOCK)
+k_qnet(QdGeom G, QdColP P, const double* __restrict__ isr, const double* __restrict__ albedo,
+       const double* __restrict__ cloud, const double* __restrict__ Ts, const double* __restrict__ h,
+       const double* __restrict__ u, const double* __restrict__ v, const uint8_t* __restrict__ land,
+       const double* __restrict__ hice, const double* __restrict__ LH, double* __restrict__ qnet,
+       uint8_t* __restrict__ icemask) {
+    const int j = blockIdx.x * QD_BLOCK + threadIdx.x;
+    if (j >= G.nlon) return;
+    const size_t o = (size_t)qd_lrow(G, G.row0 + blockIdx.y) * G.nlon + j;
+    const double hh = h[o];
+    const double T_a = 288.0 + P.ga * hh;
+    const double hi = hice[o];
+    const QdFlux F = qd_surface_fluxes(P, isr[o], albedo[o], cloud[o], Ts[o], T_a, u[o], v[o], land[o] == 1, hi);
+    qnet[o] = F.SW_sfc - F.LW_sfc - F.SH - LH[o];
+    icemask[o] = (hi > 0.0) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------ wind stress + CFL maxima
+__device__ __forceinline__ double qd_wave_max_d(double x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { double y = __shfl_down(x, o, 64); x = (y > x) ? y : x; }
+    return x;
+}
+
+__global__ void __launch_bounds__(QD_BLOCK)
+k_stress_max(QdGeom G, const double* __restrict__ ua, const double* __restrict__ va,
+             const double* __restrict__ uo, const double* __restrict__ vo, double vcap, double rhoCD, double tau_scale,
+             double* __restrict__ taux, double* __restrict__ tauy, double* __restrict__ partial) {
+    __shared__ double sm[2][QD_BLOCK / 64];
+    const int i = G.row0 + blockIdx.y;
+    const size_t b = (size_t)qd_lrow(G, i) * G.nlon;
+    double mVa = 0.0, mUo = 0.0;
+    for (int j = threadIdx.x; j < G.nlon; j += QD_BLOCK) {
+        const size_t o = b + j;
+        const double u_o = uo[o], v_o = vo[o];
+        const double u_rel = ua[o] - u_o, v_rel = va[o] - v_o;
+        const double Va = sqrt(u_rel * u_rel + v_rel * v_rel);
+        const double Va_eff = qd_min(Va, vcap);
+        taux[o] = tau_scale * (rhoCD * Va_eff * u_rel);
+        tauy[o] = tau_scale * (rhoCD * Va_eff * v_rel);
+        const double so = sqrt(u_o * u_o + v_o * v_o);
+        mVa = Va > mVa ? Va : mVa;        // NaN never wins, like np.max on nan_to_num'd data
+        mUo = so > mUo ? so : mUo;
+    }
+    mVa = qd_wave_max_d(mVa); mUo = qd_wave_max_d(mUo);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { sm[0][w] = mVa; sm[1][w] = mUo; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < QD_BLOCK / 64; ++k) { mVa = sm[0][k] > mVa ? sm[0][k] : mVa; mUo = sm[1][k] > mUo ? sm[1][k] : mUo; }
+        partial[blockIdx.y] = mVa;
+        partial[gridDim.y + blockIdx.y] = mUo;
+    }
+}
+
+__global__ void __launch_bounds__(QD_BLOCK)
+k_max2_finish(const double* __restrict__ partial, int n, double* __restrict__ out) {
+    __shared__ double sm[2][QD_BLOCK / 64];
+    double a = 0.0, b = 0.0;
+    for (int k = threadIdx.x; k < n; k += QD_BLOCK) { a = partial[k] > a ? partial[k] : a; b = partial[n + k] > b ? partial[n + k] : b; }
+    a = qd_wave_max_d(a); b = qd_wave_max_d(b);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { sm[0][w] = a; sm[1][w] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < QD_BLOCK / 64; ++k) { a = sm[0][k] > a ? sm[0][k] : a; b = sm[1][k] > b ? sm[1][k] : b; }
+        out[0] = a; out[1] = b;
+    }
+}
+
+// ------------------------------------------------------------------ momentum: ocean.py:306-336
+struct QdOcnP { double a, g, dlat, dlon, sub_dt, rhoH, r_bot; };
+
+__global__ void __launch_bounds__(QD_BLOCK)
+k_ocean_momentum(QdGeom G, QdTabs T, QdOcnP P, const double* __restrict__ eta, const double* __restrict__ taux,
+                 const double* __restrict__ tauy, const uint8_t* __restrict__ land,
+                 double* __restrict__ uo, double* __restrict__ vo) {
+    const int j = blockIdx.x * QD_BLOCK + threadIdx.x;
+    if (j >= G.nlon) return;
+    const int i = G.row0 + blockIdx.y;
+    const size_t b = (size_t)qd_lrow(G, i) * G.nlon;
+    const size_t o = b + j;
+    const int jp = qd_wrapc(j + 1, G.nlon), jm = qd_wrapc(j - 1, G.nlon);
+    const double deta_dlam = (eta[b + jp] - eta[b + jm]) / (2.0 * P.dlon);
+    const double deta_dphi = (eta[(size_t)qd_lrow(G, i + 1) * G.nlon + j] - eta[(size_t)qd_lrow(G, i - 1) * G.nlon + j]) / (2.0 * P.dlat);
+    const double gx = deta_dlam / (P.a * T.cos05[i]);
+    const double gy = deta_dphi / P.a;
+    const double f = T.fcor[i];
+    const double u0 = uo[o], v0 = vo[o];
+    const double du = (f * v0 - P.g * gx + taux[o] / P.rhoH - P.r_bot * u0);
+    const double dv = (-f * u0 - P.g * gy + tauy[o] / P.rhoH - P.r_bot * v0);
+    double un = u0 + P.sub_dt * du;
+    double vn = v0 + P.sub_dt * dv;
+    if (land[o] == 1) { un = 0.0; vn = 0.0; }
+    const double rx = T.r_extra[i];
+    un = un - P.sub_dt * rx * un;
+    vn = vn - P.sub_dt * rx * vn;
+    uo[o] = un; vo[o] = vn;
+}
+
+// ------------------------------------------------------------------ continuity: ocean.py:365-374
+__device__ __forceinline__ double qd_wave_sum_d(double x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+    return x;
+}
+
+__global__ void __launch_bounds__(QD_BLOCK)
+k_continuity(QdGeom G, QdTabs T, double a, double dlat, double dlon, double msdtH, const double* __restrict__ uo,
+             const double* __restrict__ vo, const uint8_t* __restrict__ land, double* __restrict__ eta,
+             double* __restrict__ partial) {
+    __shared__ double sm[QD_BLOCK / 64];
+    const int i = G.row0 + blockIdx.y;
+    const size_t b = (size_t)qd_lrow(G, i) * G.nlon;
+    const double w = T.warea[i];
+    double acc = 0.0;
+    for (int j = threadIdx.x; j < G.nlon; j += QD_BLOCK) {
+        const size_t o = b + j;
+        const double div = qd_divvort_point(G, T, uo, vo, i, j, a, dlat, dlon, 0);
+        double e = eta[o] + msdtH * div;
+        const bool island = land[o] == 1;
+        if (island) e = 0.0;
+        eta[o] = e;
+        acc += e * (island ? 0.0 : w);          // eta * (w * ocean_mask)
+    }
+    acc = qd_wave_sum_d(acc);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) sm[wv] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = sm[0];
+        for (int k = 1; k < QD_BLOCK / 64; ++k) r += sm[k];
+        partial[blockIdx.y] = r;
+    }
+}
+
+__global__ void __launch_bounds__(QD_BLOCK)
+k_eta_mean(const double* __restrict__ partial, int n, double wsum, double* __restrict__ out) {
+    __shared__ double sm[QD_BLOCK / 64];
+    double acc = 0.0;
+    for (int k = threadIdx.x; k < n; k += QD_BLOCK) acc += partial[k];
+    acc = qd_wave_sum_d(acc);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) sm[wv] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = sm[0];
+        for (int k = 1; k < QD_BLOCK / 64; ++k) r += sm[k];
+        *out = r / (wsum + 1e-15);
+    }
+}
+
+// ------------------------------------------------------------------ SST advection: ocean.py:375,380-382
+__global__ void __launch_bounds__(QD_BLOCK)
+k_sst_advect(QdGeom G, const double* __restrict__ cos05, double sub_dt, double a, double dlat, double dlon,
+             const double* __restrict__ uo, const double* __restrict__ vo, const double* __restrict__ Ts,
+             double* __restrict__ Ts_out, double alpha, double* __restrict__ eta, const double* __restrict__ eta_mean,
+             int has_ocean) {
+    const int j = blockIdx.x * QD_BLOCK + threadIdx.x;
+    if (j >= G.nlon) return;
+    const int i = G.row0 + blockIdx.y;
+    const size_t o = (size_t)qd_lrow(G, i) * G.nlon + j;
+    if (has_ocean) eta[o] = eta[o] - *eta_mean;
+    const QdBilin b = qd_departure(G, i, j, uo[o], vo[o], sub_dt, a, cos05[i], dlat, dlon);
+    const double adv = qd_gather(Ts, G, b);
+    Ts_out[o] = (1.0 - alpha) * Ts[o] + alpha * adv;
+}
+
+// ------------------------------------------------------------------ diffusion + heating: ocean.py:385-406,440
+struct QdHeatP { double sub_dt, K_h, rcH, ice_qfac; int use_q, has_ice; };
+
+__global__ void __launch_bounds__(QD_BLOCK)
+k_sst_diffuse_heat(QdGeom G, const double* __restrict__ cos05, double dlat, double dlon, double a, QdHeatP P,
+                   const double* __restrict__ Ts1, double* __restrict__ Ts_out, const double* __restrict__ qnet,
+                   const uint8_t* __restrict__ land, const uint8_t* __restrict__ ice) {
+    const int j = blockIdx.x * QD_BLOCK + threadIdx.x;
+    if (j >= G.nlon) return;
+    const int i = G.row0 + blockIdx.y;
+    const size_t o = (size_t)qd_lrow(G, i) * G.nlon + j;
+    double T = Ts1[o];
+    if (P.K_h > 0.0) T = T + P.sub_dt * P.K_h * qd_lap_point<true>(Ts1, G, cos05, i, j, dlat, dlon, a);
+    if (P.use_q) {
+        const double heat = qnet[o] / P.rcH;
+        const bool ocean = land[o] == 0;
+        if (P.has_ice) {
+            const bool ic = ice[o] != 0;
+            if (ocean && !ic) T = T + P.sub_dt * heat;
+            if (P.ice_qfac > 0.0 && ocean && ic) T = T + P.sub_dt * P.ice_qfac * heat;
+        } else if (ocean) T = T + P.sub_dt * heat;
+    }
+    Ts_out[o] = qd_nn(T);
+}
+
+// ------------------------------------------------------------------ outliers + caps: ocean.py:409-444
+__global__ void __launch_bounds__(QD_BLOCK)
+k_outlier(QdGeom G, const double* __restrict__ uo, const double* __restrict__ vo, double* __restrict__ uo_out,
+          double* __restrict__ vo_out, double* __restrict__ eta, double cap, double eta_cap, int mean4) {
+    const int j = blockIdx.x * QD_BLOCK + threadIdx.x;
+    if (j >= G.nlon) return;
+    const int i = G.row0 + blockIdx.y;
+    const size_t b = (size_t)qd_lrow(G, i) * G.nlon;
+    const size_t o = b + j;
+    double u = qd_nn(uo[o]), v = qd_nn(vo[o]);
+    const double speed = sqrt(u * u + v * v);
+    if (mean4) {
+        if (speed > cap) {
+            const size_t bn = (size_t)qd_lrow(G, i + 1) * G.nlon, bs = (size_t)qd_lrow(G, i - 1) * G.nlon;
+            const int je = qd_wrapc(j + 1, G.nlon), jw = qd_wrapc(j - 1, G.nlon);
+            u = 0.25 * (qd_nn(uo[bn + j]) + qd_nn(uo[bs + j]) + qd_nn(uo[b + je]) + qd_nn(uo[b + jw]));
+            v = 0.25 * (qd_nn(vo[bn + j]) + qd_nn(vo[bs + j]) + qd_nn(vo[b + je]) + qd_nn(vo[b + jw]));
+        }
+        const double sp2 = sqrt(u * u + v * v);
+        const double sc2 = (sp2 > cap) ? cap / (sp2 + 1e-12) : 1.0;
+        u = u * sc2; v = v * sc2;
+    } else {
+        const double sc = (speed > cap) ? cap / (speed + 1e-12) : 1.0;
+        u = u * sc; v = v * sc;
+    }
+    uo_out[o] = u; vo_out[o] = v;
+    eta[o] = qd_clip(qd_nn(eta[o]), -eta_cap, eta_cap);
+}
+
+// ------------------------------------------------------------------ polar ring fills: ocean.py:197-262
+// one workgroup per pole row; fixed-order tree sums (deterministic)
+__device__ __forceinline__ double qd_block_sum_ocn(double x, double* sm) {
+    x = qd_wave_sum_d(x);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sm[wv] = x;
+    __syncthreads();
+    double r = sm[0];
+    for (int k = 1; k < QD_BLOCK / 64; ++k) r += sm[k];
+    return r;
+}
+
+__global__ void __launch_bounds__(QD_BLOCK)
+k_polar_fill(QdGeom G, QdTabs T, const uint8_t* __restrict__ land, double* __restrict__ Ts, double* __restrict__ uo,
+             double* __restrict__ vo) {
+    __shared__ double sm[QD_BLOCK / 64];
+    const bool north = blockIdx.x == 1;
+    const int i = north ? G.nlat - 1 : 0;
+    if (i < G.row0 || i >= G.row0 + G.nrows) return;      // this band does not own the pole
+    const size_t b = (size_t)qd_lrow(G, i) * G.nlon;
+    double cnt = 0, sT = 0, s0 = 0, s1 = 0;
+    for (int j = threadIdx.x; j < G.nlon; j += QD_BLOCK) {
+        if (land[b + j] != 0) continue;
+        cnt += 1.0;
+        sT += Ts[b + j];
+        const double sl = T.sin_lon[j], cl = T.cos_lon[j];
+        const double u = uo[b + j], v = vo[b + j];
+        // e_east = (-sin, cos, 0); e_north = (-cos, -sin, 0) at +90, (cos, sin, 0) at -90; z component is 0
+        const double nx = north ? -cl : cl, ny = north ? -sl : sl;
+        s0 += (-sl) * u + nx * v;
+        s1 += cl * u + ny * v;
+    }
+    cnt = qd_block_sum_ocn(cnt, sm);
+    sT = qd_block_sum_ocn(sT, sm);
+    s0 = qd_block_sum_ocn(s0, sm);
+    s1 = qd_block_sum_ocn(s1, sm);
+    if (cnt <= 0.0) return;
+    const double mT = sT / cnt, m0 = s0 / cnt, m1 = s1 / cnt;
+    for (int j = threadIdx.x; j < G.nlon; j += QD_BLOCK) {
+        if (land[b + j] != 0) continue;
+        const double sl = T.sin_lon[j], cl = T.cos_lon[j];
+        const double nx = north ? -cl : cl, ny = north ? -sl : sl;
+        Ts[b + j] = mT;
+        uo[b + j] = (-sl) * m0 + cl * m1;       // ee_all @ v3_mean (third component is zero)
+        vo[b + j] = nx * m0 + ny * m1;
+    }
+}
+
+__global__ void __launch_bounds__(QD_BLOCK)
+k_sst_clamp_inject(QdGeom G, double* __restrict__ sst, double tmin, double tmax, int inject,
+                   const uint8_t* __restrict__ land, const uint8_t* __restrict__ ice, int has_ice,
+                   double* __restrict__ Ts_atm) {
+    const int j = blockIdx.x * QD_BLOCK + threadIdx.x;
+    if (j >= G.nlon) return;
+    const size_t o = (size_t)qd_lrow(G, G.row0 + blockIdx.y) * G.nlon + j;
+    const double t = qd_clip(sst[o], tmin, tmax);
+    sst[o] = t;
+    // gcm.T_s = where(ocean & ~ice, ocean.Ts, gcm.T_s)    run_simulation.py:2252-2253
+    if (inject && land[o] == 0 && !(has_ice && ice[o] != 0)) Ts_atm[o] = t;
+}
+
+// ------------------------------------------------------------------ host orchestration
+int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask, int inject_sst) {
+    const qd_params& p = c->p;
+    const QdGeom& G = c->geo;
+    const dim3 grid = qd_grid2d(G), blk(QD_BLOCK), rows(1, G.nrows);
+    c->ocn_counter += 1;
+    const int64_t step = c->ocn_counter;
+    const double H = p.H_ocean;
+
+    if (compute_qnet) {
+        QdScope sc(c, "ocean_qnet");
+        QdColP P = qd_make_colp(c, dt);
+        // cloud optical field: cloud_eff_last when time_step produced one, else cloud_cover
+        const double* cl = c->cloud_eff_valid ? c->f[QD_F_CLOUD_EFF] : c->f[QD_F_CLOUD];
+        hipLaunchKernelGGL(k_qnet, grid, blk, 0, c->stream, G, P, c->f[QD_F_ISR], c->f[QD_F_ALBEDO], cl, c->f[QD_F_TS],
+                           c->f[QD_F_H], c->f[QD_F_U], c->f[QD_F_V], c->land, c->f[QD_F_HICE], c->f[QD_F_LH],
+                           c->f[QD_F_QNET], c->icemask);
+        use_ice_mask = 1;
+    }
+    double* taux = qd_scratch(c, 14);
+    double* tauy = qd_scratch(c, 15);
+    int n_sub;
+    {
+        QdScope sc(c, "ocean_stress");
+        hipLaunchKernelGGL(k_stress_max, rows, blk, 0, c->stream, G, c->f[QD_F_U], c->f[QD_F_V], c->f[QD_F_UO],
+                           c->f[QD_F_VO], p.vcap, p.rho_a_ocean * p.CD, p.tau_scale, taux, tauy, c->red_partial);
+        hipLaunchKernelGGL(k_max2_finish, dim3(1), blk, 0, c->stream, c->red_partial, G.nrows, c->dscal + QD_S_TMP0);
+        QD_HIP(c, hipMemcpyAsync(c->hpin, c->dscal + QD_S_TMP0, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        QD_HIP(c, hipStreamSynchronize(c->stream));
+        const double maxVa = c->hpin[0], maxUo = c->hpin[1];
+        // ocean.py:293-303
+        const double dx_lat = p.a * c->dlat;
+        const double min_cos = 0.5;                       // min of max(cos, 0.5) on a pole-to-pole grid
+        const double dx_lon_min = p.a * c->dlon * std::max(1e-3, min_cos);
+        const double dx_min = std::min(dx_lat, dx_lon_min);
+        const double cg = std::sqrt(p.g_ocean * H);
+        double uadv = std::max(maxUo, maxVa);
+        const double target = std::max(1e-3, p.ocean_cfl);
+        const double v = std::ceil(std::max(cg, uadv) * (dt / std::max(1e-12, dx_min)) / target);
+        n_sub = (v != v) ? 1 : (v > 500.0 ? 500 : (v < 1.0 ? 1 : (int)v));
+        c->last_nsub = n_sub;
+    }
+    const double sub_dt = dt / n_sub;
+    QdOcnP OP{p.a, p.g_ocean, c->dlat, c->dlon, sub_dt, p.rho_w * H, p.r_bot};
+    QdHeatP HP{sub_dt, p.K_h, p.rho_w * p.cp_w * H, p.ocean_ice_qfac, p.ocean_use_qnet ? 1 : 0, use_ice_mask ? 1 : 0};
+    const bool do_diff = (p.ocean_diff_every > 0) && (step % p.ocean_diff_every == 0);
+    const bool do_shap = (p.ocean_shapiro_n > 0) && (p.ocean_shapiro_every > 0) && (step % p.ocean_shapiro_every == 0);
+    if (do_diff) { int rc = qd_build_k4_tables(c, dt, true, sub_dt); if (rc) return rc; }
+    const double ov[3] = {p.ocean_k4_u, p.ocean_k4_v, p.ocean_k4_eta};
+
+    for (int s = 0; s < n_sub; ++s) {
+        {
+            QdScope sc(c, "ocean_momentum");
+            hipLaunchKernelGGL(k_ocean_momentum, grid, blk, 0, c->stream, G, c->tabs, OP, c->f[QD_F_ETA], taux, tauy,
+                               c->land, c->f[QD_F_UO], c->f[QD_F_VO]);
+        }
+        if (do_diff) {
+            QdScope sc(c, "ocean_hyperdiffusion");
+            double* fl[3] = {c->f[QD_F_UO], c->f[QD_F_VO], c->f[QD_F_ETA]};
+            c->lap_tag = "ocean_k_laplacian"; c->hyp_tag = "ocean_k_hyper_apply";
+            qd_hyperdiffuse_fields(c, fl, 3, c->k4_ocn, c->k4_ocn_skip, ov, sub_dt, p.ocean_k4_nsub, c->tabs.cos05);
+            c->lap_tag = "k_laplacian"; c->hyp_tag = "k_hyper_apply";
+            c->f[QD_F_UO] = fl[0]; c->f[QD_F_VO] = fl[1]; c->f[QD_F_ETA] = fl[2];
+        }
+        if (do_shap) {
+            double* fl[3] = {c->f[QD_F_UO], c->f[QD_F_VO], c->f[QD_F_ETA]};
+            qd_shapiro_fields(c, fl, 3, p.ocean_shapiro_n);
+            c->f[QD_F_UO] = fl[0]; c->f[QD_F_VO] = fl[1]; c->f[QD_F_ETA] = fl[2];
+        }
+        {
+            QdScope sc(c, "ocean_continuity");
+            hipLaunchKernelGGL(k_continuity, rows, blk, 0, c->stream, G, c->tabs, p.a, c->dlat, c->dlon, -sub_dt * H,
+                               c->f[QD_F_UO], c->f[QD_F_VO], c->land, c->f[QD_F_ETA], c->red_partial);
+            hipLaunchKernelGGL(k_eta_mean, dim3(1), blk, 0, c->stream, c->red_partial, G.nrows, c->wsum_ocean,
+                               c->dscal + QD_S_ETA_MEAN);
+        }
+        {
+            QdScope sc(c, "ocean_sst");
+            double* T1 = qd_scratch(c, 0);
+            hipLaunchKernelGGL(k_sst_advect, grid, blk, 0, c->stream, G, c->tabs.cos05, sub_dt, p.a, c->dlat, c->dlon,
+                               c->f[QD_F_UO], c->f[QD_F_VO], c->f[QD_F_SST], T1, p.ocean_adv_alpha, c->f[QD_F_ETA],
+                               c->dscal + QD_S_ETA_MEAN, c->wsum_ocean > 0.0 ? 1 : 0);
+            double* T2 = qd_scratch(c, 1);
+            hipLaunchKernelGGL(k_sst_diffuse_heat, grid, blk, 0, c->stream, G, c->tabs.cos05, c->dlat, c->dlon, p.a, HP,
+                               T1, T2, c->f[QD_F_QNET], c->land, c->icemask);
+            qd_swap(c, QD_F_SST, 1);
+        }
+        {
+            QdScope sc(c, "ocean_outlier");
+            double* u2 = qd_scratch(c, 2); double* v2 = qd_scratch(c, 3);
+            hipLaunchKernelGGL(k_outlier, grid, blk, 0, c->stream, G, c->f[QD_F_UO], c->f[QD_F_VO], u2, v2,
+                               c->f[QD_F_ETA], p.ocean_max_u, p.eta_cap, p.ocean_outlier == 0 ? 1 : 0);
+            qd_swap(c, QD_F_UO, 2); qd_swap(c, QD_F_VO, 3);
+        }
+    }
+    {
+        QdScope sc(c, "ocean_finish");
+        if (p.ocean_polar_fix)
+            hipLaunchKernelGGL(k_polar_fill, dim3(2), blk, 0, c->stream, G, c->tabs, c->land, c->f[QD_F_SST],
+                               c->f[QD_F_UO], c->f[QD_F_VO]);
+        hipLaunchKernelGGL(k_sst_clamp_inject, grid, blk, 0, c->stream, G, c->f[QD_F_SST], p.ts_min, p.ts_max,
+                           inject_sst, c->land, c->icemask, use_ice_mask ? 1 : 0, c->f[QD_F_TS]);
+    }
+    return 0;
+}

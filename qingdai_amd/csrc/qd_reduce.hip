@@ -1,0 +1,206 @@
+// qd_reduce.hip -- deterministic global reductions and exact median-of-positives (gfx950).
+//
+//   O13: np.median(x[x>0])  dynamics.py:344-348, physics.py:298-301, run_simulation.py:1866-1874
+//        area-weighted sums  physics.py:320-323,345-347; ocean.py:372-375; energy.py:520-525
+//        global max          ocean.py:298-299
+//
+// Sums use a fixed two-level tree (wave shuffles -> LDS -> one finishing workgroup) so the
+// result is bit-reproducible run to run; it is NOT numpy's pairwise order (stated tolerance
+// in tests).  The median is exact: an MSB-first radix select over the IEEE-754 bit patterns
+// of the positive entries (order-isomorphic to their values), 11 bits per pass, tracking the
+// two middle ranks at once for even counts.
+#include "qd_internal.h"
+
+__device__ __forceinline__ double qd_wave_sum(double x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+    return x;
+}
+__device__ __forceinline__ double qd_wave_max(double x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { double y = __shfl_down(x, o, 64); x = (y > x) ? y : x; }
+    return x;
+}
+
+// block-level reduce of (sum | max); result valid in thread 0
+template <int OP>
+__device__ __forceinline__ double qd_block_reduce(double x) {
+    __shared__ double sm[QD_BLOCK / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    x = (OP == 0) ? qd_wave_sum(x) : qd_wave_max(x);
+    __syncthreads();
+    if (lane == 0) sm[w] = x;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = sm[0];
+        for (int k = 1; k < QD_BLOCK / 64; ++k) r = (OP == 0) ? r + sm[k] : (sm[k] > r ? sm[k] : r);
+        x = r;
+    }
+    return x;
+}
+
+// op: 0 sum, 1 cos-weighted sum (x * warea[row]), 2 max, 3 min (as max of -x), 4 max|x|
+__global__ void __launch_bounds__(QD_BLOCK)
+k_reduce_stage1(QdGeom G, const double* __restrict__ x, const double* __restrict__ warea, int op,
+                double* __restrict__ partial) {
+    const int i = G.row0 + blockIdx.y;
+    const size_t b = (size_t)qd_lrow(G, i) * G.nlon;
+    double acc = (op >= 2) ? -DBL_MAX : 0.0;
+    for (int j = blockIdx.x * QD_BLOCK + threadIdx.x; j < G.nlon; j += gridDim.x * QD_BLOCK) {
+        const double v = x[b + j];
+        if (op == 0) acc += v;
+        else if (op == 1) acc += v * warea[i];
+        else if (op == 2) acc = v > acc ? v : acc;
+        else if (op == 3) acc = -v > acc ? -v : acc;
+        else { const double av = fabs(v); acc = av > acc ? av : acc; }
+    }
+    double r = (op >= 2) ? qd_block_reduce<1>(acc) : qd_block_reduce<0>(acc);
+    if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = r;
+}
+
+__global__ void __launch_bounds__(QD_BLOCK)
+k_reduce_stage2(const double* __restrict__ partial, int n, int ismax, double* __restrict__ out) {
+    double acc = ismax ? -DBL_MAX : 0.0;
+    for (int k = threadIdx.x; k < n; k += QD_BLOCK) {
+        const double v = partial[k];
+        acc = ismax ? (v > acc ? v : acc) : acc + v;
+    }
+    double r = ismax ? qd_block_reduce<1>(acc) : qd_block_reduce<0>(acc);
+    if (threadIdx.x == 0) *out = r;
+}
+
+// reduce a resident field into device scalar slot; optionally copy to host (synchronises)
+int qd_reduce_field(qd_ctx* c, const double* x, int op, double* host_out) {
+    const QdGeom& G = c->geo;
+    dim3 grid(1, G.nrows);
+    hipLaunchKernelGGL(k_reduce_stage1, grid, dim3(QD_BLOCK), 0, c->stream, G, x, c->tabs.warea, op, c->red_partial);
+    hipLaunchKernelGGL(k_reduce_stage2, dim3(1), dim3(QD_BLOCK), 0, c->stream, c->red_partial, G.nrows,
+                       op >= 2 ? 1 : 0, c->dscal + QD_S_TMP0);
+    if (host_out) {
+        QD_HIP(c, hipMemcpyAsync(c->hpin, c->dscal + QD_S_TMP0, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        QD_HIP(c, hipStreamSynchronize(c->stream));
+        double v = c->hpin[0];
+        if (op == 3) v = -v;
+        *host_out = v;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------ exact median of positives
+// sel_state layout (unsigned long long): [0] count of positives, [1] prefix_lo, [2] rank_lo,
+// [3] prefix_hi, [4] rank_hi, [5] bits resolved so far.
+//
+// `transform` lets the caller take the median of a derived field without materialising it:
+//   0: x itself
+//   1: max(0, -(x - tparam))       physics.py:296 (pos = max(0, -(div - D_crit)))
+__device__ __forceinline__ double qd_med_value(double x, int transform, double tparam) {
+    if (transform == 1) return qd_max(0.0, -(x - tparam));
+    return x;
+}
+
+__global__ void __launch_bounds__(QD_BLOCK)
+k_sel_init(unsigned long long* st, unsigned int* hist) {
+    for (int k = threadIdx.x; k < 2 * QD_HIST_BINS; k += QD_BLOCK) hist[k] = 0u;
+    if (threadIdx.x < 8) st[threadIdx.x] = 0ull;
+}
+
+// pass: histogram the next 11-bit digit of every positive element whose resolved prefix
+// matches prefix_lo (hist 0) / prefix_hi (hist 1).  First pass also counts positives.
+__global__ void __launch_bounds__(QD_BLOCK)
+k_sel_hist(QdGeom G, const double* __restrict__ x, int transform, double tparam,
+           const unsigned long long* __restrict__ st, unsigned int* __restrict__ hist, int shift, int width,
+           int first) {
+    __shared__ unsigned int sh[2 * QD_HIST_BINS];
+    for (int k = threadIdx.x; k < 2 * QD_HIST_BINS; k += QD_BLOCK) sh[k] = 0u;
+    __syncthreads();
+    const unsigned long long plo = st[1], phi = st[3];
+    const int i = G.row0 + blockIdx.y;
+    const size_t b = (size_t)qd_lrow(G, i) * G.nlon;
+    for (int j = blockIdx.x * QD_BLOCK + threadIdx.x; j < G.nlon; j += gridDim.x * QD_BLOCK) {
+        const double v = qd_med_value(x[b + j], transform, tparam);
+        if (!(v > 0.0)) continue;
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+        const int up = shift + width;                    // bits above the current digit
+        const unsigned long long hi_bits = up >= 64 ? 0ull : (bits >> up);
+        const unsigned int digit = (unsigned int)((bits >> shift) & ((1u << width) - 1u));
+        if (first || hi_bits == (up >= 64 ? 0ull : (plo >> up))) atomicAdd(&sh[digit], 1u);
+        if (!first && plo != phi && hi_bits == (phi >> up)) atomicAdd(&sh[QD_HIST_BINS + digit], 1u);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 2 * QD_HIST_BINS; k += QD_BLOCK) if (sh[k]) atomicAdd(&hist[k], sh[k]);
+}
+
+// single workgroup: locate the digit holding each target rank, extend the prefixes, clear hist.
+// Threads own 8 consecutive bins each; lane 0 / lane 1 walk the 256 chunk sums held in LDS for
+// the lower / upper middle rank.
+__global__ void __launch_bounds__(QD_BLOCK)
+k_sel_scan(unsigned long long* st, unsigned int* hist, int shift, int first) {
+    __shared__ unsigned int sh[2 * QD_HIST_BINS];
+    __shared__ unsigned int csum[2][QD_BLOCK];
+    __shared__ unsigned long long s_st[8];
+    const int t = threadIdx.x;
+    const int per = QD_HIST_BINS / QD_BLOCK;
+    for (int k = t; k < 2 * QD_HIST_BINS; k += QD_BLOCK) sh[k] = hist[k];
+    if (t < 8) s_st[t] = st[t];
+    __syncthreads();
+    for (int hsel = 0; hsel < 2; ++hsel) {
+        unsigned int s = 0;
+        for (int k = 0; k < per; ++k) s += sh[hsel * QD_HIST_BINS + t * per + k];
+        csum[hsel][t] = s;
+    }
+    __syncthreads();
+    if (t == 0 && first) {
+        unsigned long long n = 0;
+        for (int k = 0; k < QD_BLOCK; ++k) n += csum[0][k];
+        s_st[0] = n;
+        s_st[2] = n ? (n - 1) / 2 : 0;   // lower middle rank (0-based)
+        s_st[4] = n / 2;                 // upper middle rank
+        s_st[1] = 0; s_st[3] = 0;
+    }
+    __syncthreads();
+    const bool same = (s_st[1] == s_st[3]);
+    if (t < 2 && s_st[0] > 0) {
+        const int hsel = (t == 1 && !same) ? 1 : 0;
+        unsigned long long r = s_st[t == 0 ? 2 : 4], cum = 0;
+        int ch = 0;
+        for (; ch < QD_BLOCK; ++ch) { if (cum + csum[hsel][ch] > r) break; cum += csum[hsel][ch]; }
+        if (ch >= QD_BLOCK) ch = QD_BLOCK - 1;
+        int d = ch * per;
+        for (; d < ch * per + per; ++d) { const unsigned int hv = sh[hsel * QD_HIST_BINS + d]; if (cum + hv > r) break; cum += hv; }
+        if (d >= ch * per + per) d = ch * per + per - 1;
+        st[t == 0 ? 2 : 4] = r - cum;
+        st[t == 0 ? 1 : 3] = s_st[t == 0 ? 1 : 3] | ((unsigned long long)d << shift);
+        if (t == 0 && first) st[0] = s_st[0];
+    }
+    if (t == 0 && first && s_st[0] == 0) st[0] = 0;
+    __syncthreads();
+    for (int k = t; k < 2 * QD_HIST_BINS; k += QD_BLOCK) hist[k] = 0u;
+}
+
+__global__ void k_sel_finish(const unsigned long long* st, double dflt, double* out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (st[0] == 0) { *out = dflt; return; }
+        const double lo = __longlong_as_double((long long)st[1]);
+        const double hi = __longlong_as_double((long long)st[3]);
+        *out = (st[0] & 1ull) ? lo : (lo + hi) / 2.0;     // np.median: mean of the two middles
+    }
+}
+
+// median of the positive entries of x (after `transform`) -> device scalar slot; `dflt` if none
+int qd_median_positive_dev(qd_ctx* c, const double* x, double dflt, int slot, int transform, double tparam) {
+    const QdGeom& G = c->geo;
+    hipLaunchKernelGGL(k_sel_init, dim3(1), dim3(QD_BLOCK), 0, c->stream, c->sel_state, c->hist);
+    // digits from the top: bits 63..53, 52..42, 41..31, 30..20 (11 wide), 19..10, 9..0 (10 wide)
+    const int shifts[6] = {53, 42, 31, 20, 10, 0};
+    const int widths[6] = {11, 11, 11, 11, 10, 10};
+    dim3 grid(1, G.nrows);
+    for (int p = 0; p < 6; ++p) {
+        const int shift = shifts[p];
+        hipLaunchKernelGGL(k_sel_hist, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam,
+                           c->sel_state, c->hist, shift, widths[p], p == 0 ? 1 : 0);
+        hipLaunchKernelGGL(k_sel_scan, dim3(1), dim3(QD_BLOCK), 0, c->stream, c->sel_state, c->hist, shift,
+                           p == 0 ? 1 : 0);
+    }
+    hipLaunchKernelGGL(k_sel_finish, dim3(1), dim3(64), 0, c->stream, c->sel_state, dflt, c->dscal + slot);
+    return 0;
+}

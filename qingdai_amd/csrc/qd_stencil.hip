@@ -1,0 +1,252 @@
+// qd_stencil.hip -- lat-lon stencil / gather operators (gfx950).
+//
+//   O1 spherical Laplacian          dynamics.py:144-173, ocean.py:100-117, jax_compat.py:111-132
+//   O2 del^4 hyperdiffusion         dynamics.py:175-212, ocean.py:119-152, jax_compat.py:135-187
+//   O3 Shapiro 1-2-1                dynamics.py:215-231, ocean.py:154-164
+//   O5 semi-Lagrangian gather       dynamics.py:90-118, ocean.py:166-194, run_simulation.py:1131-1158
+//   O11 divergence / vorticity      grid.py:41-88
+//   O12 Gaussian blur               physics.py:44,69,111,159,330; run_simulation.py:1931
+//
+// Launch shape: one workgroup row-segment per (blockIdx.x, row = blockIdx.y, field = blockIdx.z):
+// lanes run along longitude so every load is a coalesced f64 row segment and the per-row
+// metrics (cos floors, k4, pole one-sidedness) are wave-uniform scalars.
+#include "qd_internal.h"
+#include "qd_device.h"
+
+// ------------------------------------------------------------------ Laplacian (device)
+__global__ void __launch_bounds__(QD_BLOCK)
+k_laplacian(QdGeom G, QdFieldList fl, const double* __restrict__ cosf, double dphi, double dlam, double a) {
+    const int j = blockIdx.x * QD_BLOCK + threadIdx.x;
+    if (j >= G.nlon) return;
+    const int i = G.row0 + blockIdx.y;
+    const int f = blockIdx.z;
+    const size_t o = (size_t)qd_lrow(G, i) * G.nlon + j;
+    fl.out[f][o] = qd_lap_point<true>(fl.in[f], G, cosf, i, j, dphi, dlam, a);
+}
+
+// second Laplacian + explicit update: out = nan_to_num( nan_to_num(F) - k4 * L(L1) * sub_dt )
+__global__ void __launch_bounds__(QD_BLOCK)
+k_hyper_apply(QdGeom G, QdFieldList fl, const double* __restrict__ cosf, double dphi, double dlam, double a,
+              double sub_dt) {
+    const int j = blockIdx.x * QD_BLOCK + threadIdx.x;
+    if (j >= G.nlon) return;
+    const int i = G.row0 + blockIdx.y;
+    const int f = blockIdx.z;
+    const size_t o = (size_t)qd_lrow(G, i) * G.nlon + j;
+    const double L2 = qd_lap_point<true>(fl.in[f], G, cosf, i, j, dphi, dlam, a);
+    const double k4 = fl.k4row[f] ? fl.k4row[f][i] : fl.k4s[f];
+    const double F0 = qd_nn(fl.aux[f][o]);
+    fl.out[f][o] = qd_nn(F0 - (k4 * L2) * sub_dt);
+}
+
+void qd_launch_laplacian(qd_ctx* c, const QdFieldList& fl, const double* coslat) {
+    QdScope sc(c, c->lap_tag);
+    hipLaunchKernelGGL(k_laplacian, qd_grid2d(c->geo, fl.n), dim3(QD_BLOCK), 0, c->stream,
+                       c->geo, fl, coslat, c->dlat, c->dlon, c->p.a);
+}
+void qd_launch_hyper_apply(qd_ctx* c, const QdFieldList& fl, const double* coslat, double sub_dt) {
+    QdScope sc(c, c->hyp_tag);
+    hipLaunchKernelGGL(k_hyper_apply, qd_grid2d(c->geo, fl.n), dim3(QD_BLOCK), 0, c->stream,
+                       c->geo, fl, coslat, c->dlat, c->dlon, c->p.a, sub_dt);
+}
+
+// _hyperdiffuse on up to QD_MAXF resident fields, in place (pointer swap with scratch).
+// k4tab: [n][nlat] per-row maps; skip[f] != 0 -> field untouched (k4 <= 0 early-out);
+// k4s_override[f] not NaN -> scalar coefficient instead of the row map.
+int qd_hyperdiffuse_fields(qd_ctx* c, double** fields, int n, const double* k4tab, const int* skip,
+                           const double* k4s_override, double dt, int nsub, const double* coslat) {
+    if (dt <= 0.0) return 0;
+    QdFieldList a; a.n = 0;
+    int idx[QD_MAXF];
+    for (int f = 0; f < n; ++f) {
+        if (skip && skip[f]) continue;
+        idx[a.n] = f;
+        a.in[a.n] = fields[f];
+        a.out[a.n] = qd_scratch(c, a.n);                 // L1
+        a.aux[a.n] = fields[f];
+        bool sc = k4s_override && !(k4s_override[f] != k4s_override[f]);
+        a.k4row[a.n] = sc ? nullptr : k4tab + (size_t)f * c->geo.nlat;
+        a.k4s[a.n] = sc ? k4s_override[f] : 0.0;
+        a.n++;
+    }
+    if (a.n == 0) return 0;
+    const int ns = nsub < 1 ? 1 : nsub;
+    const double sub_dt = dt / ns;
+    for (int s = 0; s < ns; ++s) {
+        qd_launch_laplacian(c, a, coslat);
+        QdFieldList b = a;
+        for (int k = 0; k < a.n; ++k) {
+            b.in[k] = a.out[k];                           // L1
+            b.out[k] = qd_scratch(c, QD_MAXF + k);        // new F
+            b.aux[k] = a.in[k];
+        }
+        qd_launch_hyper_apply(c, b, coslat, sub_dt);
+        // new F becomes the field: copy pointer roles (swap field storage with scratch slot)
+        for (int k = 0; k < a.n; ++k) {
+            double* newF = b.out[k];
+            double* oldF = fields[idx[k]];
+            fields[idx[k]] = newF;
+            c->scratch[QD_MAXF + k] = oldF;
+            a.in[k] = newF; a.aux[k] = newF;
+        }
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------ Shapiro
+__global__ void __launch_bounds__(QD_BLOCK)
+k_shapiro_pass(QdGeom G, QdFieldList fl, int scrub) {
+    const int j = blockIdx.x * QD_BLOCK + threadIdx.x;
+    if (j >= G.nlon) return;
+    const int i = G.row0 + blockIdx.y;
+    const int f = blockIdx.z;
+    const double* __restrict__ F = fl.in[f];
+    const int jm = qd_wrapc(j - 1, G.nlon), jp = qd_wrapc(j + 1, G.nlon);
+    const int rm = i > 0 ? i - 1 : 0, rp = i < G.nlat - 1 ? i + 1 : G.nlat - 1;   // mode='nearest'
+    double lc[3];
+    const int rows[3] = {rm, i, rp};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const size_t b = (size_t)qd_lrow(G, rows[k]) * G.nlon;
+        double xm = F[b + jm], x0 = F[b + j], xp = F[b + jp];
+        if (scrub) { xm = qd_nn(xm); x0 = qd_nn(x0); xp = qd_nn(xp); }
+        lc[k] = (xm * 0.25 + x0 * 0.5) + xp * 0.25;          // lon pass, mode='wrap'
+    }
+    fl.out[f][(size_t)qd_lrow(G, i) * G.nlon + j] = (lc[0] * 0.25 + lc[1] * 0.5) + lc[2] * 0.25;
+}
+
+void qd_launch_shapiro_pass(qd_ctx* c, const QdFieldList& fl, int scrub) {
+    hipLaunchKernelGGL(k_shapiro_pass, qd_grid2d(c->geo, fl.n), dim3(QD_BLOCK), 0, c->stream, c->geo, fl, scrub);
+}
+
+int qd_shapiro_fields(qd_ctx* c, double** fields, int n, int npass) {
+    if (npass < 1) npass = 1;
+    QdFieldList a; a.n = n;
+    for (int p = 0; p < npass; ++p) {
+        for (int k = 0; k < n; ++k) { a.in[k] = fields[k]; a.out[k] = qd_scratch(c, k); a.aux[k] = nullptr; a.k4row[k] = nullptr; a.k4s[k] = 0; }
+        qd_launch_shapiro_pass(c, a, p == 0);
+        for (int k = 0; k < n; ++k) { double* t = fields[k]; fields[k] = c->scratch[k]; c->scratch[k] = t; }
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------ semi-Lagrangian gather
+// out = (1-alpha)*F + alpha*advect(F)   (alpha == 1: plain replace); second field optional;
+// clipq: second field gets clip(nan_to_num(.), 0, 0.5) (dynamics.py:461)
+__global__ void __launch_bounds__(QD_BLOCK)
+k_advect(QdGeom G, const double* __restrict__ u, const double* __restrict__ v, const double* __restrict__ cosl,
+         double dt, double a, double dlat, double dlon,
+         const double* __restrict__ f0, double* __restrict__ o0,
+         const double* __restrict__ f1, double* __restrict__ o1, double alpha, int clipq) {
+    const int j = blockIdx.x * QD_BLOCK + threadIdx.x;
+    if (j >= G.nlon) return;
+    const int i = G.row0 + blockIdx.y;
+    const size_t o = (size_t)qd_lrow(G, i) * G.nlon + j;
+    const QdBilin b = qd_departure(G, i, j, u[o], v[o], dt, a, cosl[i], dlat, dlon);
+    const bool blend = (alpha != 1.0);
+    {
+        const double adv = qd_gather(f0, G, b);
+        o0[o] = blend ? (1.0 - alpha) * f0[o] + alpha * adv : adv;
+    }
+    if (f1) {
+        const double adv = qd_gather(f1, G, b);
+        double x = blend ? (1.0 - alpha) * f1[o] + alpha * adv : adv;
+        if (clipq) x = qd_clip(qd_nn(x), 0.0, 0.5);
+        o1[o] = x;
+    }
+}
+
+void qd_launch_advect(qd_ctx* c, const double* u, const double* v, const double* coslat, double dt,
+                      const double* f0, double* o0, const double* f1, double* o1, double alpha, int clipq) {
+    hipLaunchKernelGGL(k_advect, qd_grid2d(c->geo), dim3(QD_BLOCK), 0, c->stream, c->geo, u, v, coslat, dt,
+                       c->p.a, c->dlat, c->dlon, f0, o0, f1, o1, alpha, clipq);
+}
+
+// ------------------------------------------------------------------ divergence / vorticity
+// div  = 1/(a cos6) * [ d(u)/dlam + d(v cos)/dphi ]        grid.py:41-68
+// vort = 1/(a cos6) * [ d(v)/dlam - d(u cos)/dphi ]        grid.py:70-88
+// both axes roll-periodic, lat derivative zeroed on the two pole rows
+__global__ void __launch_bounds__(QD_BLOCK)
+k_divvort(QdGeom G, QdTabs T, const double* __restrict__ u, const double* __restrict__ v, double* __restrict__ out,
+          double a, double dlat, double dlon, int vort) {
+    const int j = blockIdx.x * QD_BLOCK + threadIdx.x;
+    if (j >= G.nlon) return;
+    const int i = G.row0 + blockIdx.y;
+    out[(size_t)qd_lrow(G, i) * G.nlon + j] =
+        vort ? qd_divvort_point(G, T, v, u, i, j, a, dlat, dlon, 1) : qd_divvort_point(G, T, u, v, i, j, a, dlat, dlon, 0);
+}
+
+void qd_launch_divvort(qd_ctx* c, const double* u, const double* v, double* out, int vort) {
+    hipLaunchKernelGGL(k_divvort, qd_grid2d(c->geo), dim3(QD_BLOCK), 0, c->stream, c->geo, c->tabs, u, v, out,
+                       c->p.a, c->dlat, c->dlon, vort);
+}
+
+// ------------------------------------------------------------------ Gaussian blur (separable)
+#define QD_GAUSS_MAXR 24
+struct QdGaussW { double w[QD_GAUSS_MAXR + 1]; int r; };   // w[k] = weight at offset k (symmetric)
+
+__device__ __forceinline__ int qd_ext(int i, int n, int mode_wrap) {
+    if (mode_wrap) { i %= n; return i < 0 ? i + n : i; }
+    // 'reflect': d c b a | a b c d | d c b a
+    const int p = 2 * n;
+    i %= p; if (i < 0) i += p;
+    return i >= n ? p - 1 - i : i;
+}
+
+// scipy correlate1d symmetric branch: tmp = x0*w0; for k = r..1: tmp += (x[-k] + x[+k]) * w[k]
+__global__ void __launch_bounds__(QD_BLOCK)
+k_gauss_axis(QdGeom G, const double* __restrict__ in, double* __restrict__ out, QdGaussW W, int axis, int mode_wrap) {
+    const int j = blockIdx.x * QD_BLOCK + threadIdx.x;
+    if (j >= G.nlon) return;
+    const int i = G.row0 + blockIdx.y;
+    const size_t o = (size_t)qd_lrow(G, i) * G.nlon + j;
+    double tmp = in[o] * W.w[0];
+    if (axis == 0) {
+        for (int k = W.r; k >= 1; --k) {
+            const double lo = in[(size_t)qd_lrow(G, qd_ext(i - k, G.nlat, mode_wrap)) * G.nlon + j];
+            const double hi = in[(size_t)qd_lrow(G, qd_ext(i + k, G.nlat, mode_wrap)) * G.nlon + j];
+            tmp += (lo + hi) * W.w[k];
+        }
+    } else {
+        const size_t b = (size_t)qd_lrow(G, i) * G.nlon;
+        for (int k = W.r; k >= 1; --k) {
+            const double lo = in[b + qd_ext(j - k, G.nlon, mode_wrap)];
+            const double hi = in[b + qd_ext(j + k, G.nlon, mode_wrap)];
+            tmp += (lo + hi) * W.w[k];
+        }
+    }
+    out[o] = tmp;
+}
+
+// gaussian_filter(in, sigma, mode): axis 0 then axis 1.  out may alias in; tmp is a distinct slab.
+int qd_gaussian(qd_ctx* c, const double* in, double* out, double* tmp, double sigma, int mode_wrap) {
+    if (!(sigma > 1e-15)) {
+        if (out != in) hipMemcpyAsync(out, in, c->geo.cells() * sizeof(double), hipMemcpyDeviceToDevice, c->stream);
+        return 0;
+    }
+    QdGaussW W;
+    const int r = (int)(4.0 * sigma + 0.5);
+    if (r > QD_GAUSS_MAXR) return qd_fail(c, "gaussian radius too large");
+    W.r = r;
+    // scipy _gaussian_kernel1d: exp(-0.5/sigma^2 * x^2) / sum, summed in array order -r..r
+    std::vector<double> phi(2 * r + 1);
+    const double s2 = sigma * sigma;
+    for (int x = -r; x <= r; ++x) phi[x + r] = std::exp(-0.5 / s2 * (double)(x * x));
+    // numpy pairwise sum degenerates to a plain left-to-right loop for < 8 elements and an
+    // 8-accumulator form above; mirror both.
+    double tot;
+    const int m = 2 * r + 1;
+    if (m < 8) { tot = 0.0; for (int k = 0; k < m; ++k) tot += phi[k]; }
+    else {
+        double acc[8];
+        for (int k = 0; k < 8; ++k) acc[k] = phi[k];
+        int k = 8;
+        for (; k < m - (m % 8); k += 8) for (int t = 0; t < 8; ++t) acc[t] += phi[k + t];
+        tot = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+        for (; k < m; ++k) tot += phi[k];
+    }
+    for (int k = 0; k <= r; ++k) W.w[k] = phi[r + k] / tot;
+    hipLaunchKernelGGL(k_gauss_axis, qd_grid2d(c->geo), dim3(QD_BLOCK), 0, c->stream, c->geo, in, tmp, W, 0, mode_wrap);
+    hipLaunchKernelGGL(k_gauss_axis, qd_grid2d(c->geo), dim3(QD_BLOCK), 0, c->stream, c->geo, tmp, out, W, 1, mode_wrap);
+    return 0;
+}

@@ -1,0 +1,119 @@
+"""CPU: the oracle restatement against the golden vectors produced by the reference itself
+(oracle/gen_golden.py) and against the known-answer values of SURVEY.md Appendix A."""
+import glob
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+import qd_oracle as qo
+from qd_oracle import atmos as oat, numerics as onx, physics as oph
+from util import GOLD, STATE, DIAG, load_golden, relerr, surface, run_oracle_time_step, oracle_params
+
+TS_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "ts_*.npz")))
+OC_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "ocean_*.npz")))
+
+
+@pytest.mark.parametrize("shape", [(19, 36), (37, 72)])
+def test_operators_match_reference(shape):
+    meta, d = load_golden(f"ops_{shape[0]}x{shape[1]}")
+    nlat, nlon = shape
+    g = qo.Grid(nlat, nlon)
+    P = qo.defaults()
+    cosl = np.cos(np.deg2rad(g.lat_mesh))
+    c02, c05, c6 = np.maximum(cosl, 0.2), np.maximum(cosl, 0.5), np.maximum(1e-6, cosl)
+    Fh, T, u, v, k4, dt = d["F"], d["T"], d["u"], d["v"], d["k4"], meta["dt"]
+    dl, dn, a = g.dlat_rad, g.dlon_rad, P.a
+    got = dict(
+        lap_atm=oat.laplacian_sphere(Fh, dl, dn, c02, a), lap_ocn=oat.laplacian_sphere(Fh, dl, dn, c05, a),
+        hyper_atm=oat.hyperdiffuse(Fh, k4, dt, 1, dl, dn, c02, a),
+        hyper_atm_nsub2=oat.hyperdiffuse(Fh, 0.5 * k4, dt, 2, dl, dn, c02, a),
+        hyper_scalar=oat.hyperdiffuse(Fh, 1.0e14, dt, 1, dl, dn, c02, a),
+        shapiro2=onx.shapiro(Fh, 2), shapiro1=onx.shapiro(Fh, 1),
+        spectral=oat.spectral_zonal_filter(Fh, 0.75, 0.5, nlon),
+        div=g.divergence(u, v), vort=g.vorticity(u, v),
+        grad_lon=onx.gradient_axis1(Fh, dn), grad_lat=onx.gradient_axis0(Fh, dl),
+        gauss1=onx.gaussian_filter(Fh, 1.0), gauss02_wrap=onx.gaussian_filter(T, 0.2, "wrap"),
+    )
+    for k, val in got.items():          # every non-gather operator is bit-exact against the reference
+        assert np.array_equal(val, d["ref_" + k]), k
+    adv = dict(
+        advect_atm=oat.advect_semilag(T, u, v, dt, a, dl, dn, c6),
+        advect_ocn=oat.advect_semilag(T, 0.02 * u, 0.02 * v, dt, a, dl, dn, c05),
+        advect_storm=oat.advect_semilag(T, d["u_storm"], d["v_storm"], dt, a, dl, dn, c6),
+    )
+    for k, val in adv.items():          # bilinear gather: <= 1 ulp (folded pole rows)
+        assert relerr(val, d["ref_" + k]) < 4e-16, k
+
+
+@pytest.mark.parametrize("case", TS_CASES)
+def test_time_step_matches_reference(case):
+    meta, d = load_golden(case)
+    m = run_oracle_time_step(meta, d)
+    # the oracle differs from the reference by <= 1 ulp in the bilinear gather only; the pole rows
+    # travel 1e4-1e5 cells before the fold (cos floor 1e-6), which turns 1 ulp of wind into ~1e-11
+    # cells of departure point, hence the 1e-11 (not 1e-15) bound on gathered fields.
+    tol = 1e-11
+    for k in STATE + DIAG:
+        assert relerr(getattr(m, k), d["ref_" + k]) < tol, (case, k)
+    if meta["with_albedo"]:
+        assert relerr(m.cloud_eff_last, d["ref_cloud_eff_last"]) < tol
+
+
+@pytest.mark.parametrize("case", OC_CASES)
+def test_ocean_matches_reference(case):
+    meta, d = load_golden(case)
+    g, mask, _, _ = surface(meta["nlat"], meta["nlon"])
+    P = oracle_params(meta["over"])
+    oc = qo.OceanOracle(g, mask, P, init_Ts=d["init_Ts"])
+    oc.uo, oc.vo, oc.eta = d["init_uo"].copy(), d["init_vo"].copy(), d["init_eta"].copy()
+    nsub = []
+    for _ in range(meta["nsteps"]):
+        oc.step(meta["dt"], d["u_atm"], d["v_atm"], Q_net=d["Q_net"], ice_mask=d["ice_mask"].astype(bool))
+        nsub.append(oc.last_n_sub)
+    assert nsub == meta["n_sub"]
+    for k in ("uo", "vo", "eta", "Ts"):
+        assert relerr(getattr(oc, k), d["ref_" + k]) < 1e-14, (case, k)
+
+
+@pytest.mark.parametrize("shape", [(19, 36), (37, 72)])
+def test_physics_and_forcing_match_reference(shape):
+    meta, d = load_golden(f"physics_{shape[0]}x{shape[1]}")
+    g, mask, alb, _ = surface(*shape)
+    P = qo.defaults()
+    st = {k: d[k] for k in ("u", "v", "T_s", "cloud_cover", "h_ice")}
+    ice_frac = 1.0 - np.exp(-np.maximum(st["h_ice"], 0.0) / 0.5)
+    for tag, Pc in (("dry", np.zeros(shape)), ("wet", d["Pc_wet"])):
+        ns = SimpleNamespace(u=st["u"], v=st["v"], T_s=st["T_s"], cloud_cover=st["cloud_cover"], P_cond_flux_last=Pc)
+        assert np.array_equal(oph.diagnose_precipitation_hybrid(ns, g, P), d[f"ref_precip_{tag}"])
+    ns = SimpleNamespace(u=st["u"], v=st["v"], T_s=st["T_s"], cloud_cover=st["cloud_cover"], P_cond_flux_last=np.zeros(shape))
+    assert np.array_equal(oph.diagnose_precipitation(ns, g, -1e-7, 1e5), d["ref_precip_legacy"])
+    assert np.array_equal(oph.parameterize_cloud_cover(ns, g), d["ref_cloud_source"])
+    albedo = oph.calculate_dynamic_albedo(st["cloud_cover"], st["T_s"], alb, 0.6, 0.5, land_mask=mask, ice_frac=ice_frac)
+    assert np.array_equal(albedo, d["ref_albedo"])
+    f = qo.Forcing(g)
+    for j, t in enumerate(meta["times"]):
+        a_, b_ = f.insolation_components(t)
+        assert np.array_equal(a_, d[f"ref_isrA_{j}"]) and np.array_equal(b_, d[f"ref_isrB_{j}"])
+        assert np.array_equal(f.equilibrium_temp(t, albedo), d[f"ref_Teq_{j}"])
+
+
+def test_known_answers_appendix_a3():
+    """19x36, defaults, albedo passed, 12 steps of the benchmark loop."""
+    meta, d = load_golden("ts_19x36_default_alb")
+    m = run_oracle_time_step(meta, d)
+    ka = {"u": -15831.79371652359, "v": 0.07421922433790762, "h": 5436416.650300638,
+          "T_s": 197021.04348692857, "q": 3.7677353406505247}
+    for k, s in ka.items():
+        assert abs(float(np.sum(getattr(m, k))) - s) <= 1e-11 * max(1.0, abs(s)), k
+
+
+def test_known_answers_appendix_a4():
+    """19x36, QD_ENERGY_W=1 QD_MOM_SCHEME=primitive."""
+    meta, d = load_golden("ts_19x36_energy_primitive")
+    m = run_oracle_time_step(meta, d)
+    ka = {"u": 250.61478858575992, "v": 9.292487359073675, "h": 4687640.218455338,
+          "T_s": 197315.43946512075, "q": 3.8377409006693473}
+    for k, s in ka.items():
+        assert abs(float(np.sum(getattr(m, k))) - s) <= 1e-11 * max(1.0, abs(s)), k
