@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""
+bench.py -- headline benchmark: simulated planet-days per wall-second at 721x1440 f64.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the per-timestep grid update over the synthetic seed-42 planet:
+forcing (two-star insolation + Teq) -> SpectralModel.time_step(Teq, dt, albedo) with the explicit
+energy budget (QD_ENERGY_W=1, QD_CLOUD_COUPLE=1) -> ocean coupling (Q_net, WindDrivenSlabOcean.step,
+SST write-back), i.e. the loop of the reference's own harness scripts/benchmark_jax.py:124-158
+(--with-ocean) at BASELINE.json configs[2].  State is resident in HBM when the timed region starts.
+
+Prints ONE JSON line (rank 0).  No PyTorch anywhere: ranks rendezvous through the filesystem
+(single node) and synchronise / reduce through RCCL inside libqingdai_hip.so.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PLANET_DAY_S = 2 * np.pi / 8.726646259971648e-5      # 72 000 s (constants.py:34)
+HBM_PEAK_GBS = 8000.0                                # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+# algorithmic bytes per cell: the del^4 pair on u,v,h,q,cloud reads 5 + writes 5
+# fields in the first Laplacian pass (80 B) and reads L1 + F and writes F' in the second (120 B).
+BYTES_PER_CELL = {"k_laplacian": 80.0, "k_hyper_apply": 120.0, "k_dyn_hyper": 88.0, "k_ocn_hyper": 65.0}
+
+
+def build_case(nlat, nlon, with_ocean, device=0, band=None, rank=0, world=1):
+    import qingdai_amd as qa
+    from qingdai_amd.device import Device
+    from qingdai_amd.topography import create_land_sea_mask, generate_base_properties
+    grid = qa.SphericalGrid(nlat, nlon)
+    mask = create_land_sea_mask(grid)
+    base_albedo, friction = generate_base_properties(mask)
+    p = qa.QdParams(energy_w=1.0, cloud_couple=1)
+    Cs_ocean = 1000.0 * 4200.0 * 50.0
+    if band is not None:
+        Device(grid, p, device=device, row0=band[0], n_rows=band[1], halo=band[2], rank=rank, world=world)
+    m = qa.SpectralModel(grid, friction, H=8000, tau_rad=10 * 24 * 3600, greenhouse_factor=0.40,
+                         C_s_map=np.where(mask == 1, 3e6, Cs_ocean).astype(float), land_mask=mask,
+                         Cs_ocean=Cs_ocean, Cs_land=3e6, Cs_ice=5e6, params=p, device=device)
+    oc = None
+    if with_ocean:
+        oc = qa.WindDrivenSlabOcean(grid, mask, 50.0, init_Ts=np.full((nlat, nlon), 288.0))
+    m._dev.upload_now("BASE_ALBEDO", base_albedo)
+    forcing = qa.ThermalForcing(grid, qa.OrbitalSystem())
+    return grid, m, oc, forcing, mask, base_albedo, friction
+
+
+def cpu_baseline(nlat, nlon, with_ocean, budget_s=20.0):
+    """The oracle (NumPy restatement, proven equal to the reference in the authoring container)
+    timed on this box's host cores with the benchmark_jax.py loop: 1 warm-up step, then as many
+    steps as fit in ~budget_s (at least 2)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import qd_oracle as qo
+    from qd_oracle import column as col
+    from qingdai_amd.topography import create_land_sea_mask, generate_base_properties
+    g = qo.Grid(nlat, nlon)
+    mask = create_land_sea_mask(g)
+    alb, fric = generate_base_properties(mask)
+    P = qo.defaults(energy_w=1.0)
+    m = qo.AtmosOracle(g, fric, mask, P, C_s_map=np.where(mask == 1, 3e6, P.Cs_ocean).astype(float))
+    oc = qo.OceanOracle(g, mask, P, init_Ts=np.full((nlat, nlon), 288.0)) if with_ocean else None
+    f = qo.Forcing(g)
+    albedo = np.where(mask == 0, 0.08, alb)
+    dt = 300.0
+
+    def one(i):
+        t = i * dt
+        a_, b_ = f.insolation_components(t)
+        m.isr_A, m.isr_B, m.isr = a_, b_, a_ + b_
+        Teq = f.equilibrium_temp(t, albedo)
+        m.time_step(Teq, dt, albedo=albedo)
+        if oc is not None:
+            T_a = 288.0 + (9.81 / 1004.0) * m.h
+            _, SW_sfc, _ = col.shortwave(m.isr, albedo, m.cloud_eff_last, P)
+            ice_frac = 1.0 - np.exp(-np.maximum(m.h_ice, 0.0) / 0.5)
+            _, LW_sfc, _, _, _ = col.longwave_v2(m.T_s, T_a, m.cloud_eff_last, col.surface_emissivity_map(mask, ice_frac, P), P)
+            SH = col.sensible_heat(m.T_s, T_a, m.u, m.v, P)
+            ice = m.h_ice > 0.0
+            oc.step(dt, m.u, m.v, Q_net=SW_sfc - LW_sfc - SH - m.LH_last, ice_mask=ice)
+            m.T_s = np.where((mask == 0) & (~ice), oc.Ts, m.T_s)
+    one(0)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        one(n + 1)
+        n += 1
+        el = time.perf_counter() - t0
+        if n >= 2 and el >= budget_s or n >= 200:
+            break
+    per = el / n
+    return {"value": dt / per / PLANET_DAY_S, "unit": "planet-days/s", "cores": 1, "kind": "port",
+            "sample": f"{n} steps of the same {nlat}x{nlon} workload after 1 warm-up ({per * 1e3:.1f} ms/step); "
+                      f"NumPy is single-threaded, {os.cpu_count()} host cores available"}
+
+
+def file_rendezvous(rank, world, payload=None, tag="id"):
+    """Single-node rendezvous without a network service: rank 0 publishes bytes in a file keyed by
+    the launcher's MASTER_PORT / run id, the others poll for it."""
+    key = f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'x')}_{tag}"
+    path = os.path.join("/tmp", f"qd_rdzv_{key}")
+    if rank == 0:
+        with open(path + ".tmp", "wb") as fh:
+            fh.write(payload)
+        os.replace(path + ".tmp", path)
+        return payload
+    t0 = time.time()
+    while not os.path.exists(path):
+        if time.time() - t0 > 120:
+            raise RuntimeError("rendezvous timeout")
+        time.sleep(0.01)
+    with open(path, "rb") as fh:
+        return fh.read()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=240)
+    ap.add_argument("--warmup", type=int, default=24)
+    ap.add_argument("--nlat", type=int, default=721)
+    ap.add_argument("--nlon", type=int, default=1440)
+    ap.add_argument("--no-ocean", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--profile-kernel", default="k_hyper_apply")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world != 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world > 1:
+        raise SystemExit("multi-GPU latitude-band path is not wired into bench.py yet (see DESIGN.md)")
+
+    with_ocean = not args.no_ocean
+    dt = 300.0
+    grid, m, oc, forcing, mask, base_albedo, friction = build_case(args.nlat, args.nlon, with_ocean, device=local_rank)
+    dev = m._dev
+    K, W = args.steps, args.warmup
+    stars_w = forcing.star_table([i * dt for i in range(W)])
+    stars_k = forcing.star_table([(W + i) * dt for i in range(K)])
+
+    if W > 0:
+        dev.step_n(stars_w, dt, with_ocean=with_ocean, pass_albedo=True)
+    dev.sync()
+    dev.timing(select=args.profile_kernel)
+    t0 = time.perf_counter()
+    dev.step_n(stars_k, dt, with_ocean=with_ocean, pass_albedo=True)
+    dev.sync()
+    el = time.perf_counter() - t0
+    kern_ms, kern_n = dev.timing_get(args.profile_kernel)
+    dev.timing(on=False)
+
+    ms_per_step = el / K * 1e3
+    value = (K * dt / PLANET_DAY_S) / el
+    cells = args.nlat * args.nlon
+    bpc = BYTES_PER_CELL.get(args.profile_kernel, 0.0)
+    achieved = (bpc * cells / 1e9) / (kern_ms / 1e3) if kern_ms > 0 else 0.0
+    out = {
+        "metric": "simulated planet-days/sec at 721x1440 f64", "value": value, "unit": "planet-days/s",
+        "n_gpus": args.gpus, "steps": K, "warmup": W, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{args.nlat}x{args.nlon} seed-42 planet, dt=300 s: forcing + time_step(Teq, dt, albedo) "
+                               f"with QD_ENERGY_W=1 QD_CLOUD_COUPLE=1" + (" + slab-ocean coupling" if with_ocean else "") +
+                               " (benchmark_jax.py:124-158 loop; BASELINE configs[2] without the driver-side "
+                               "precipitation/cloud diagnostics)",
+                   "grid": [args.nlat, args.nlon], "dt_s": dt, "ocean_n_sub": dev.last_ocean_nsub() if with_ocean else 0,
+                   "parallelism": f"lat-bands x{args.gpus}"},
+        "roofline": {"bound": "hbm", "kernel": args.profile_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "bytes_per_cell": bpc, "cells": cells, "avg_kernel_ms": kern_ms, "launches": kern_n},
+    }
+    if not args.no_cpu_baseline and rank == 0 and args.gpus == 1:
+        out["cpu_baseline"] = cpu_baseline(args.nlat, args.nlon, with_ocean, args.cpu_budget)
+        out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

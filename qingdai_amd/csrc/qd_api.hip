@@ -2,6 +2,7 @@
 #include "qd_internal.h"
 #include <cstring>
 #include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 
 thread_local std::string g_qd_create_err;
@@ -77,6 +78,32 @@ static int build_tables(qd_ctx* c) {
         double s = (lat_deg - p.polar_sponge_lat) / std::max(1e-6, 90.0 - p.polar_sponge_lat);
         s = std::min(std::max(s, 0.0), 1.0);
         rx[i] = p.polar_sponge_gain * (s * s);
+    }
+    {
+        const double a = p.a, dphi = c->dlat, dlam = c->dlon;
+        const double f_min = 2.0 * p.omega * std::sin(5.0 * (M_PI / 180.0));
+        for (int k = 0; k < 2; ++k) {
+            const std::vector<double>& ck = k == 0 ? c02 : c05;
+            std::vector<double> A(nlat), P(nlat), Q(nlat);
+            for (int i = 0; i < nlat; ++i) {
+                A[i] = ck[i] / (2.0 * dphi);
+                P[i] = 1.0 / ((a * a) * ck[i] * (2.0 * dphi));
+                Q[i] = 1.0 / ((a * a) * (dlam * dlam) * (ck[i] * ck[i]));
+            }
+            c->tabs.lapA[k] = dev_table(c, A); c->tabs.lapP[k] = dev_table(c, P); c->tabs.lapQ[k] = dev_table(c, Q);
+        }
+        std::vector<double> cu(nlat), cv(nlat), px(nlat), igx(nlat);
+        for (int i = 0; i < nlat; ++i) {
+            const double f = fc[i];
+            const double sgn = f >= 0.0 ? 1.0 : -1.0;
+            const double f_safe = std::fabs(f) < f_min ? sgn * f_min : f;
+            cu[i] = -(p.g / (f_safe * a * c6[i]));
+            cv[i] = p.g / (f_safe * a);
+            px[i] = -(p.g / (a * c6[i]));
+            igx[i] = 1.0 / (a * c05[i]);
+        }
+        c->tabs.mom_cu = dev_table(c, cu); c->tabs.mom_cv = dev_table(c, cv); c->tabs.mom_px = dev_table(c, px);
+        c->tabs.ocn_igx = dev_table(c, igx);
     }
     std::vector<double> lr(nlon), sl(nlon), cl(nlon);
     for (int j = 0; j < nlon; ++j) { lr[j] = lon[j] * d2r; sl[j] = std::sin(lr[j]); cl[j] = std::cos(lr[j]); }
@@ -182,6 +209,7 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
     if (d->device < 0 || d->device >= ndev) return qd_fail(nullptr, "qd_create: bad device ordinal");
     qd_ctx* c = new qd_ctx();
     c->desc = *d; c->p = *params;
+    { const char* ef = std::getenv("QD_FUSED"); if (ef && ef[0] == '0') c->use_fused = 0; }
     c->geo = QdGeom{d->n_lat, d->n_lon, d->row0, d->n_rows, d->halo, full ? 1 : 0};
     auto bail = [&](const char* w, hipError_t e) { qd_fail(nullptr, w, e); qd_destroy(c); return -1; };
     hipError_t e;
@@ -311,7 +339,7 @@ extern "C" int qd_download(qd_handle c, int field, void* host, size_t bytes) {
 extern "C" int qd_set_params(qd_handle c, const qd_params* p, size_t sz) {
     if (!c || !p) return -1;
     if (sz != sizeof(qd_params)) return qd_fail(c, "qd_set_params: struct size mismatch (ABI drift)");
-    const bool tabs_stale = (p->omega != c->p.omega) || (p->polar_sponge_lat != c->p.polar_sponge_lat) ||
+    const bool tabs_stale = (p->omega != c->p.omega) || (p->g != c->p.g) || (p->a != c->p.a) || (p->polar_sponge_lat != c->p.polar_sponge_lat) ||
                             (p->polar_sponge_gain != c->p.polar_sponge_gain);
     c->p = *p;
     c->k4_atm_dt = -1; c->k4_ocn_dt = -1;

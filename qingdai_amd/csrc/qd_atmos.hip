@@ -14,6 +14,7 @@
 #include "qd_device.h"
 
 #include "qd_fluxes.h"
+#include "qd_fused.h"
 
 struct QdColPtrs {
     const double *u, *v, *Teq, *isr, *albedo, *csmap;
@@ -30,9 +31,10 @@ struct QdColPtrs {
 template <int PHASE, bool HAS_ALB>
 __global__ void __launch_bounds__(QD_BLOCK)
 k_column(QdGeom G, QdColP P, QdColPtrs A) {
-    const int j = blockIdx.x * QD_BLOCK + threadIdx.x;
+    const QdTile tl = qd_tile();
+    const int j = tl.seg * QD_BLOCK + threadIdx.x;
     if (j >= G.nlon) return;
-    const int i = G.row0 + blockIdx.y;
+    const int i = G.row0 + tl.row;
     const size_t o = (size_t)qd_lrow(G, i) * G.nlon + j;
 
     const double u = A.u[o], v = A.v[o], h = A.h[o], Ts = A.Ts[o];
@@ -147,9 +149,10 @@ struct QdMomP { double g, a, dt, dlat, dlon, f_min; int primitive; };
 __global__ void __launch_bounds__(QD_BLOCK)
 k_momentum(QdGeom G, QdTabs T, QdMomP P, const double* __restrict__ h, const double* __restrict__ fric,
            double* __restrict__ u, double* __restrict__ v) {
-    const int j = blockIdx.x * QD_BLOCK + threadIdx.x;
+    const QdTile tl = qd_tile();
+    const int j = tl.seg * QD_BLOCK + threadIdx.x;
     if (j >= G.nlon) return;
-    const int i = G.row0 + blockIdx.y;
+    const int i = G.row0 + tl.row;
     const int n = G.nlat, m = G.nlon;
     const size_t b = (size_t)qd_lrow(G, i) * m;
     const size_t o = b + j;
@@ -195,9 +198,10 @@ k_final(QdGeom G, const double* __restrict__ cosl, double dt, double a, double d
         double* __restrict__ u, double* __restrict__ v, double* __restrict__ h, double* __restrict__ Ts,
         double* __restrict__ q, const double* __restrict__ cloud_in, double* __restrict__ cloud_out,
         double decay, double dfac) {
-    const int j = blockIdx.x * QD_BLOCK + threadIdx.x;
+    const QdTile tl = qd_tile();
+    const int j = tl.seg * QD_BLOCK + threadIdx.x;
     if (j >= G.nlon) return;
-    const int i = G.row0 + blockIdx.y;
+    const int i = G.row0 + tl.row;
     const size_t o = (size_t)qd_lrow(G, i) * G.nlon + j;
     const double uu = u[o], vv = v[o];
     const QdBilin b = qd_departure(G, i, j, uu, vv, dt, a, cosl[i], dlat, dlon);
@@ -218,9 +222,10 @@ __global__ void __launch_bounds__(QD_BLOCK)
 k_forcing(QdGeom G, QdTabs T, QdStar A, QdStar B, double theta, double sigma, int with_teq,
           double* __restrict__ isrA, double* __restrict__ isrB, double* __restrict__ isr,
           const double* __restrict__ albedo, double* __restrict__ Teq) {
-    const int j = blockIdx.x * QD_BLOCK + threadIdx.x;
+    const QdTile tl = qd_tile();
+    const int j = tl.seg * QD_BLOCK + threadIdx.x;
     if (j >= G.nlon) return;
-    const int i = G.row0 + blockIdx.y;
+    const int i = G.row0 + tl.row;
     const size_t o = (size_t)qd_lrow(G, i) * G.nlon + j;
     const double sl = T.sin_raw[i], cl = T.cos_raw[i], lon = T.lon_rad[j];
     const double hA = theta + lon - A.alpha;
@@ -250,9 +255,10 @@ int qd_forcing_impl(qd_ctx* c, const double* sa, const double* sb, double theta,
 __global__ void __launch_bounds__(QD_BLOCK)
 k_simple_albedo(QdGeom G, const uint8_t* __restrict__ land, const double* __restrict__ base, double ocean_albedo,
                 double* __restrict__ albedo) {
-    const int j = blockIdx.x * QD_BLOCK + threadIdx.x;
+    const QdTile tl = qd_tile();
+    const int j = tl.seg * QD_BLOCK + threadIdx.x;
     if (j >= G.nlon) return;
-    const size_t o = (size_t)qd_lrow(G, G.row0 + blockIdx.y) * G.nlon + j;
+    const size_t o = (size_t)qd_lrow(G, G.row0 + tl.row) * G.nlon + j;
     albedo[o] = (land[o] == 0) ? ocean_albedo : base[o];
 }
 
@@ -342,34 +348,52 @@ int qd_atmos_step_impl(qd_ctx* c, double dt, int has_albedo) {
         qd_launch_advect(c, c->f[QD_F_U], c->f[QD_F_V], c->tabs.cos6, dt, c->f[QD_F_TS], oT, c->f[QD_F_Q], oq, 0.2, 1);
         qd_swap(c, QD_F_TS, 0); qd_swap(c, QD_F_Q, 1);
     }
-    // momentum (dynamics.py:482-530)
-    {
-        QdScope sc(c, "momentum");
-        QdMomP M;
-        M.g = p.g; M.a = p.a; M.dt = dt; M.dlat = c->dlat; M.dlon = c->dlon;
-        M.f_min = 2.0 * p.omega * std::sin(5.0 * (M_PI / 180.0));
-        M.primitive = p.mom_scheme == 1;
-        hipLaunchKernelGGL(k_momentum, grid, blk, 0, c->stream, G, c->tabs, M, c->f[QD_F_H], c->f[QD_F_FRICTION],
-                           c->f[QD_F_U], c->f[QD_F_V]);
-    }
-    // del^4 (dynamics.py:533-594)
+    // momentum (dynamics.py:482-530) + del^4 (dynamics.py:533-594)
     const int ft = p.filter_type;
-    if (p.diff_enable && (ft == 0 || ft == 1) && (sc_ % std::max(1, p.diff_every) == 0)) {
-        QdScope sc(c, "hyperdiffusion");
-        int rc = qd_build_k4_tables(c, dt, false, 0.0);
-        if (rc) return rc;
-        double* fl[5] = {c->f[QD_F_U], c->f[QD_F_V], c->f[QD_F_H], c->f[QD_F_Q], c->f[QD_F_CLOUD]};
-        const double ov[5] = {p.k4_u, p.k4_v, p.k4_h, p.k4_q, p.k4_cloud};
-        if (p.k4_nsub == 1) {
-            qd_hyperdiffuse_fields(c, fl, 5, c->k4_atm, c->k4_atm_skip, ov, dt, 1, c->tabs.cos02);
-        } else {
-            // u,v,h use QD_K4_NSUB sub-steps, q and cloud always one (dynamics.py:584-594)
-            int skip3[5] = {c->k4_atm_skip[0], c->k4_atm_skip[1], c->k4_atm_skip[2], 1, 1};
-            int skip2[5] = {1, 1, 1, c->k4_atm_skip[3], c->k4_atm_skip[4]};
-            qd_hyperdiffuse_fields(c, fl, 5, c->k4_atm, skip3, ov, dt, p.k4_nsub, c->tabs.cos02);
-            qd_hyperdiffuse_fields(c, fl, 5, c->k4_atm, skip2, ov, dt, 1, c->tabs.cos02);
+    const bool do_diff = p.diff_enable && (ft == 0 || ft == 1) && (sc_ % std::max(1, p.diff_every) == 0);
+    const double f_min = 2.0 * p.omega * std::sin(5.0 * (M_PI / 180.0));
+    if (do_diff) { int rc = qd_build_k4_tables(c, dt, false, 0.0); if (rc) return rc; }
+    const double ov[5] = {p.k4_u, p.k4_v, p.k4_h, p.k4_q, p.k4_cloud};
+    if (do_diff && c->use_fused && p.k4_nsub == 1) {
+        // one launch: u,v,h,friction,q,cloud in -> u,v,h,q,cloud out
+        QdDynArgs D;
+        D.u = c->f[QD_F_U]; D.v = c->f[QD_F_V]; D.h = c->f[QD_F_H]; D.fric = c->f[QD_F_FRICTION];
+        D.q = c->f[QD_F_Q]; D.cloud = c->f[QD_F_CLOUD];
+        D.uo = qd_scratch(c, 0); D.vo = qd_scratch(c, 1); D.ho = qd_scratch(c, 2); D.qo = qd_scratch(c, 3); D.co = qd_scratch(c, 4);
+        for (int f = 0; f < 5; ++f) {
+            const bool sc1 = qd_isset(ov[f]);
+            D.k4row[f] = sc1 ? nullptr : c->k4_atm + (size_t)f * G.nlat;
+            D.k4s[f] = sc1 ? ov[f] : 0.0;
+            D.skip[f] = c->k4_atm_skip[f];
         }
-        c->f[QD_F_U] = fl[0]; c->f[QD_F_V] = fl[1]; c->f[QD_F_H] = fl[2]; c->f[QD_F_Q] = fl[3]; c->f[QD_F_CLOUD] = fl[4];
+        D.g = p.g; D.a = p.a; D.dt = dt; D.dlat = c->dlat; D.dlon = c->dlon; D.f_min = f_min; D.primitive = p.mom_scheme == 1;
+        D.inv_dlon = 1.0 / c->dlon; D.inv_2dlon = 1.0 / (2.0 * c->dlon); D.inv_dlat = 1.0 / c->dlat; D.inv_2dlat = 1.0 / (2.0 * c->dlat);
+        D.pgf_y = -(p.g / p.a);
+        qd_launch_dyn_hyper(c, D);
+        qd_swap(c, QD_F_U, 0); qd_swap(c, QD_F_V, 1); qd_swap(c, QD_F_H, 2); qd_swap(c, QD_F_Q, 3); qd_swap(c, QD_F_CLOUD, 4);
+    } else {
+        {
+            QdScope sc(c, "momentum");
+            QdMomP M;
+            M.g = p.g; M.a = p.a; M.dt = dt; M.dlat = c->dlat; M.dlon = c->dlon; M.f_min = f_min;
+            M.primitive = p.mom_scheme == 1;
+            hipLaunchKernelGGL(k_momentum, grid, blk, 0, c->stream, G, c->tabs, M, c->f[QD_F_H], c->f[QD_F_FRICTION],
+                               c->f[QD_F_U], c->f[QD_F_V]);
+        }
+        if (do_diff) {
+            QdScope sc(c, "hyperdiffusion");
+            double* fl[5] = {c->f[QD_F_U], c->f[QD_F_V], c->f[QD_F_H], c->f[QD_F_Q], c->f[QD_F_CLOUD]};
+            if (p.k4_nsub == 1) {
+                qd_hyperdiffuse_fields(c, fl, 5, c->k4_atm, c->k4_atm_skip, ov, dt, 1, c->tabs.cos02);
+            } else {
+                // u,v,h use QD_K4_NSUB sub-steps, q and cloud always one (dynamics.py:584-594)
+                int skip3[5] = {c->k4_atm_skip[0], c->k4_atm_skip[1], c->k4_atm_skip[2], 1, 1};
+                int skip2[5] = {1, 1, 1, c->k4_atm_skip[3], c->k4_atm_skip[4]};
+                qd_hyperdiffuse_fields(c, fl, 5, c->k4_atm, skip3, ov, dt, p.k4_nsub, c->tabs.cos02);
+                qd_hyperdiffuse_fields(c, fl, 5, c->k4_atm, skip2, ov, dt, 1, c->tabs.cos02);
+            }
+            c->f[QD_F_U] = fl[0]; c->f[QD_F_V] = fl[1]; c->f[QD_F_H] = fl[2]; c->f[QD_F_Q] = fl[3]; c->f[QD_F_CLOUD] = fl[4];
+        }
     }
     // Shapiro (dynamics.py:610-626): combo, shapiro AND hyper4 all trigger it
     if ((ft == 0 || ft == 1 || ft == 2) && p.shapiro_every > 0 && (sc_ % p.shapiro_every == 0)) {

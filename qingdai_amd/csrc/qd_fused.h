@@ -1,0 +1,33 @@
+// qd_fused.h -- argument blocks of the fused momentum + del^4 kernels (qd_fused.hip).
+#pragma once
+#include "qd_internal.h"
+
+struct QdDynArgs {
+    const double *u, *v, *h, *fric, *q, *cloud;
+    double *uo, *vo, *ho, *qo, *co;
+    const double* k4row[5];     // u v h q cloud; nullptr -> scalar k4s
+    double k4s[5];
+    int skip[5];                // k4 <= 0 early-out of _hyperdiffuse: field passes through
+    double g, a, dt, dlat, dlon, f_min;
+    double inv_dlon, inv_2dlon, inv_dlat, inv_2dlat, pgf_y;
+    int primitive;
+    QdTileShape ts;
+};
+
+
+struct QdOcnArgs {
+    const double *uo, *vo, *eta, *taux, *tauy;
+    const uint8_t* land;
+    double *uo_out, *vo_out, *eta_out;
+    const double* k4row[3];
+    double k4s[3];
+    int skip[3];
+    double a, g, dlat, dlon, sub_dt, rhoH, r_bot;
+    double inv_2dlon, inv_2dlat, inv_a, inv_rhoH;
+    QdTileShape ts;
+};
+
+
+QdTileShape qd_pick_tile(const QdGeom& G);
+int qd_launch_dyn_hyper(qd_ctx* c, QdDynArgs& P);
+int qd_launch_ocn_hyper(qd_ctx* c, QdOcnArgs& P);

@@ -1,0 +1,475 @@
+// qd_fused.hip -- the fused momentum + del^4 kernels (gfx950), the hot stencil of the path.
+//
+//   k_dyn_hyper<TR>   atmosphere: np.gradient(h) -> geostrophic-relaxation | primitive momentum
+//                     (dynamics.py:482-530) -> del^4 hyperdiffusion of u, v, h, q, cloud
+//                     (dynamics.py:533-594, 144-212) in ONE launch.
+//   k_ocn_hyper<TR>   ocean sub-step: grad(eta) + Coriolis + wind stress + drag + land mask + polar
+//                     sponge (ocean.py:306-336) -> del^4 of uo, vo, eta (ocean.py:341-356).
+//
+// Algorithmic HBM traffic of k_dyn_hyper: read u,v,h,friction,q,cloud (48 B) + write u,v,h,q,cloud
+// (40 B) = 88 B/cell instead of the 22 field passes of the unfused sequence;
+// k_ocn_hyper: read uo,vo,eta,tau_x,tau_y (+mask) and write uo,vo,eta = 65 B/cell.
+//
+// Design (MI355X / CDNA4):
+//   * One 512-thread workgroup = 8 wavefronts owns a TR x 58 tile.  A wavefront IS a 64-column row
+//     segment: lane l always works on global column j0-3+l, in every plane and every phase, so every
+//     global access is one coalesced 512-byte row segment and every LDS access is conflict-free
+//     (64 consecutive 8-byte words).  Wave w handles plane rows w, w+8, w+16, ...
+//   * Each Laplacian is a 5-row x 3-column star (its latitude part gradient(cos*gradient(F)) only
+//     touches rows r-2, r, r+2), so del^4 needs F on (TR+8) x 62 and the momentum update that
+//     produces F needs h on (TR+10) x 64.  Halo cells are recomputed, never exchanged.
+//   * ALL global loads of a tile (the h plane and the thread's own u, v, friction, q, cloud cells)
+//     are issued back-to-back at kernel entry into registers: one exposed memory latency per tile.
+//     After that the kernel only touches LDS: three planes  A (h), B (field entering del^4),
+//     D (its Laplacian), re-used field after field (u', v', h, q, cloud).
+//   * Divisions by per-row / constant metrics are folded into host-computed reciprocal tables
+//     (lapA/lapP/lapQ, mom_cu/cv/px) for interior rows; the two rows next to each pole keep the
+//     reference's literal one-sided np.gradient expressions.
+//   * TR is a template parameter (fully unrolled cell loops, register-resident prefetch); the host
+//     picks the instantiation whose tile count fills 256 CUs x resident workgroups in the fewest
+//     rounds.  Tiles are dealt to the 8 XCDs in contiguous chunks so halo re-reads hit one L2.
+#include "qd_internal.h"
+#include "qd_device.h"
+#include "qd_fused.h"
+#include <cstdlib>
+#include <algorithm>
+
+#define QD_TC 58                 // owned columns per tile (lanes 3..60)
+#define QD_S 64                  // plane row stride (doubles) = one wavefront
+#define QD_FBLOCK 512             // threads per fused-kernel workgroup
+#define QD_NW (QD_FBLOCK / 64)   // wavefronts per workgroup
+
+// np.nan_to_num in 5 VALU ops instead of 12: clamp with max/min (which also map NaN to a bound), then
+// send NaN to 0 with one compare + select
+__device__ __forceinline__ double qd_nnf(double x) {
+    const double c = fmin(fmax(x, -DBL_MAX), DBL_MAX);
+    return (x == x) ? c : 0.0;
+}
+
+struct QdLapC {                  // scalars + reciprocal row tables of the spherical Laplacian
+    double dphi, dlam, a;
+    int n;                       // nlat
+    const double* cosf;          // global table (pole rows only)
+    const double *sA, *sP, *sQ;  // LDS copies of lapA/lapP/lapQ indexed by PLANE row rho
+};
+
+// the two rows next to each pole: literal reference expressions (one-sided np.gradient); kept out of
+// line so the unrolled interior path stays small
+__device__ __noinline__ double qd_lap_lds_pole(const double* __restrict__ p, int g, const QdLapC& C) {
+    const int n = C.n, S = QD_S;
+    const double cc = p[0];
+    auto dF = [&](int gr, int off) -> double {      // off: plane-row offset of global row gr from p
+        if (gr == 0) return (p[(off + 1) * S] - p[off * S]) / C.dphi;
+        if (gr == n - 1) return (p[off * S] - p[(off - 1) * S]) / C.dphi;
+        return (p[(off + 1) * S] - p[(off - 1) * S]) / (2.0 * C.dphi);
+    };
+    double Ga, Gb, den;
+    if (g == 0) { Ga = C.cosf[0] * dF(0, 0); Gb = C.cosf[1] * dF(1, 1); den = C.dphi; }
+    else if (g == n - 1) { Ga = C.cosf[n - 2] * dF(n - 2, -1); Gb = C.cosf[n - 1] * dF(n - 1, 0); den = C.dphi; }
+    else { Ga = C.cosf[g - 1] * dF(g - 1, -1); Gb = C.cosf[g + 1] * dF(g + 1, 1); den = 2.0 * C.dphi; }
+    const double ci = C.cosf[g];
+    const double term_phi = (1.0 / ci) * ((Gb - Ga) / den);
+    const double d2 = ((p[1] - 2.0 * cc) + p[-1]) / (C.dlam * C.dlam);
+    const double term_lam = d2 / (ci * ci);
+    return (term_phi + term_lam) / (C.a * C.a);
+}
+
+// Laplacian at plane position p (row stride QD_S) whose global row is g.  Plane values are already
+// nan_to_num'd.  Interior rows use the reciprocal form; rows 0,1,n-2,n-1 the literal reference form.
+__device__ __forceinline__ double qd_lap_lds(const double* __restrict__ p, int g, int rho, const QdLapC& C) {
+    const int n = C.n, S = QD_S;
+    const double cc = p[0];
+    if (g >= 2 && g <= n - 3) {
+        //   L = P_i (A_{i+1} (F_{i+2} - F_i) - A_{i-1} (F_i - F_{i-2})) + Q_i ((F_{j+1} - 2F) + F_{j-1})
+        const double Gb = C.sA[rho + 1] * (p[2 * S] - cc);
+        const double Ga = C.sA[rho - 1] * (cc - p[-2 * S]);
+        const double d2 = (p[1] - 2.0 * cc) + p[-1];
+        return C.sP[rho] * (Gb - Ga) + C.sQ[rho] * d2;
+    }
+    return qd_lap_lds_pole(p, g, C);
+}
+
+// Plane geometry shared by both kernels.  Common origin: plane row rho <-> global row i0-5+rho,
+// lane l <-> global column j0-3+l.   A: rho in [0,TR+10)   B: [1,TR+9)   D: [3,TR+7)   owned: [5,TR+5)
+template <int TR> struct QdPl {
+    static constexpr int RA = TR + 10;
+    static constexpr int K = (RA + QD_NW - 1) / QD_NW;     // cells per thread
+    static constexpr int NT = 10;                             // staged row tables
+    static constexpr size_t lds_bytes = sizeof(double) * (QD_S * (size_t)(3 * RA) + (size_t)NT * RA);
+};
+
+// del^4 of the field currently in plane B (valid rows [1,TR+9), lanes 1..62), written to `out`.
+// Caller has synchronised after filling B; this routine ends with a barrier so B/D may be reused.
+template <int TR>
+__device__ __forceinline__ void qd_del4_from_B(const double* __restrict__ B, double* __restrict__ D,
+                                               double* __restrict__ out, const QdGeom& G, int i0, int j0,
+                                               const QdLapC& C, const double* __restrict__ sK4, double dt) {
+    constexpr int K = QdPl<TR>::K;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: row math + table loads go scalar
+    const int gend = G.row0 + G.nrows;
+#pragma unroll 2
+    for (int k = 0; k < K; ++k) {
+        const int rho = wv + QD_NW * k;
+        const int g = i0 - 5 + rho;
+        if (rho >= 3 && rho < TR + 7 && lane >= 2 && lane <= 61)
+            D[rho * QD_S + lane] = (g >= 0 && g < C.n) ? qd_nnf(qd_lap_lds(B + rho * QD_S + lane, g, rho, C)) : 0.0;
+    }
+    __syncthreads();
+    const int j = j0 - 3 + lane;
+#pragma unroll 2
+    for (int k = 0; k < K; ++k) {
+        const int rho = wv + QD_NW * k;
+        const int g = i0 - 5 + rho;
+        if (rho >= 5 && rho < TR + 5 && g < gend && lane >= 3 && lane <= 60 && j < G.nlon) {
+            const double L2 = qd_lap_lds(D + rho * QD_S + lane, g, rho, C);
+            const double k4 = sK4[rho];
+            out[(size_t)qd_lrow(G, g) * G.nlon + j] = qd_nnf(B[rho * QD_S + lane] - (k4 * L2) * dt);
+        }
+    }
+    __syncthreads();
+}
+
+// store owned cells straight from per-thread register values (field skipped by the k4<=0 early-out)
+template <int TR>
+__device__ __forceinline__ void qd_store_owned(const double (&val)[QdPl<TR>::K], double* __restrict__ out,
+                                               const QdGeom& G, int i0, int j0) {
+    constexpr int K = QdPl<TR>::K;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: row math + table loads go scalar
+    const int j = j0 - 3 + lane, gend = G.row0 + G.nrows;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int rho = wv + QD_NW * k;
+        const int g = i0 - 5 + rho;
+        if (rho >= 5 && rho < TR + 5 && g < gend && lane >= 3 && lane <= 60 && j < G.nlon)
+            out[(size_t)qd_lrow(G, g) * G.nlon + j] = val[k];
+    }
+}
+
+__device__ __forceinline__ int qd_wrapj(int j, int n) {   // periodic column; narrow grids wrap more than once
+    j = j < 0 ? j + n : (j >= n ? j - n : j);
+    if (j < 0 || j >= n) { j %= n; if (j < 0) j += n; }
+    return j;
+}
+
+__device__ __forceinline__ void qd_tile_origin(int ntc, int tr, int row0, int& i0, int& j0) {
+    const unsigned nb = gridDim.x, L = blockIdx.x, per = nb >> 3, rem = nb & 7u, x = L & 7u;
+    const unsigned w = x * per + (x < rem ? x : rem) + (L >> 3);      // XCD-contiguous dealing
+    i0 = row0 + (int)(w / (unsigned)ntc) * tr;
+    j0 = (int)(w % (unsigned)ntc) * QD_TC;
+}
+
+// =========================================================================================
+// atmosphere
+// =========================================================================================
+// momentum update of one cell (dynamics.py:488-530); p points at the cell in the h plane.
+// t8/t9: staged row coefficients (geos: mom_cu, mom_cv; primitive: mom_px, f)
+__device__ __forceinline__ double qd_mom_cell(const double* __restrict__ p, int g, int j, const QdGeom& G,
+                                              const QdDynArgs& P, int comp, double u0, double v0, double fr,
+                                              double t8, double t9) {
+    const int n = G.nlat, m = G.nlon, S = QD_S;
+    if (P.primitive) {
+        const double f = t9;
+        if (comp == 0) {
+            const double dh_dlon = (j == 0) ? (p[1] - p[0]) * P.inv_dlon : (j == m - 1) ? (p[0] - p[-1]) * P.inv_dlon
+                                                                                      : (p[1] - p[-1]) * P.inv_2dlon;
+            return qd_clip(u0 + (t8 * dh_dlon + f * v0 - fr * u0) * P.dt, -200.0, 200.0);
+        }
+        const double dh_dlat = (g == 0) ? (p[S] - p[0]) * P.inv_dlat : (g == n - 1) ? (p[0] - p[-S]) * P.inv_dlat
+                                                                                    : (p[S] - p[-S]) * P.inv_2dlat;
+        return qd_clip(v0 + (P.pgf_y * dh_dlat - f * u0 - fr * v0) * P.dt, -200.0, 200.0);
+    }
+    if (comp == 0) {
+        const double dh_dlat = (g == 0) ? (p[S] - p[0]) * P.inv_dlat : (g == n - 1) ? (p[0] - p[-S]) * P.inv_dlat
+                                                                                    : (p[S] - p[-S]) * P.inv_2dlat;
+        const double u_g = qd_clip(t8 * dh_dlat, -200.0, 200.0);
+        const double un = u0 * 0.8 + u_g * 0.2;
+        return un + (-fr * un) * P.dt;
+    }
+    const double dh_dlon = (j == 0) ? (p[1] - p[0]) * P.inv_dlon : (j == m - 1) ? (p[0] - p[-1]) * P.inv_dlon
+                                                                              : (p[1] - p[-1]) * P.inv_2dlon;
+    const double v_g = qd_clip(t9 * dh_dlon, -200.0, 200.0);
+    const double vn = v0 * 0.8 + v_g * 0.2;
+    return vn + (-fr * vn) * P.dt;
+}
+
+template <int TR>
+__global__ void __launch_bounds__(QD_FBLOCK, 4)
+k_dyn_hyper(QdGeom G, QdTabs T, QdDynArgs P) {
+    extern __shared__ __align__(16) double lds[];
+    constexpr int RA = QdPl<TR>::RA, K = QdPl<TR>::K;
+    double* A = lds;
+    double* B = A + RA * QD_S;
+    double* D = B + RA * QD_S;
+    int i0, j0;
+    qd_tile_origin(P.ts.ntc, TR, G.row0, i0, j0);
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: row math + table loads go scalar
+    const int j = qd_wrapj(j0 - 3 + lane, G.nlon);
+    // row tables of this tile's plane rows, staged once in LDS (broadcast reads afterwards):
+    // 0 lapA  1 lapP  2 lapQ  3..7 k4[u,v,h,q,cloud]  8 mom_cu | mom_px  9 mom_cv | fcor
+    double* sT = D + RA * QD_S;
+    if (threadIdx.x < RA) {
+        const int rho = threadIdx.x, g = i0 - 5 + rho;
+        const bool ok = g >= 0 && g < G.nlat;
+        const int gg = ok ? g : 0;
+        sT[0 * RA + rho] = ok ? T.lapA[0][gg] : 0.0;
+        sT[1 * RA + rho] = ok ? T.lapP[0][gg] : 0.0;
+        sT[2 * RA + rho] = ok ? T.lapQ[0][gg] : 0.0;
+        for (int f = 0; f < 5; ++f) sT[(3 + f) * RA + rho] = P.k4row[f] ? (ok ? P.k4row[f][gg] : 0.0) : P.k4s[f];
+        sT[8 * RA + rho] = ok ? (P.primitive ? T.mom_px[gg] : T.mom_cu[gg]) : 0.0;
+        sT[9 * RA + rho] = ok ? (P.primitive ? T.fcor[gg] : T.mom_cv[gg]) : 0.0;
+    }
+    const QdLapC C{P.dlat, P.dlon, P.a, G.nlat, T.cos02, sT, sT + RA, sT + 2 * RA};
+
+    // ---- every global load of the tile, issued back to back (unconditional loads from clamped
+    //      offsets, masked afterwards: no branch and no wait sits between two loads)
+    double ah[K], ru[K], rv[K], rf[K], rq[K], rc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int rho = wv + QD_NW * k;
+        const int g = i0 - 5 + rho;
+        const bool ok = (rho < RA) && (g >= 0) && (g < G.nlat);
+        const unsigned o = ok ? (unsigned)qd_lrow(G, g) * (unsigned)G.nlon + (unsigned)j : (unsigned)j;
+        ah[k] = P.h[o]; ru[k] = P.u[o]; rv[k] = P.v[o]; rf[k] = P.fric[o]; rq[k] = P.q[o]; rc[k] = P.cloud[o];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int rho = wv + QD_NW * k;
+        const int g = i0 - 5 + rho;
+        const bool ok = (rho < RA) && (g >= 0) && (g < G.nlat);
+        const bool inB = ok && rho >= 1 && rho < TR + 9;
+        ah[k] = ok ? ah[k] : 0.0;
+        ru[k] = inB ? ru[k] : 0.0; rv[k] = inB ? rv[k] : 0.0; rf[k] = inB ? rf[k] : 0.0;
+        rq[k] = inB ? rq[k] : 0.0; rc[k] = inB ? rc[k] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) { const int rho = wv + QD_NW * k; if (rho < RA) A[rho * QD_S + lane] = ah[k]; }
+    __syncthreads();
+
+    // ---- u', v'
+#pragma unroll
+    for (int comp = 0; comp < 2; ++comp) {
+        double keep[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int rho = wv + QD_NW * k;
+            const int g = i0 - 5 + rho;
+            double val = 0.0;
+            if (rho >= 1 && rho < TR + 9 && lane >= 1 && lane <= 62 && g >= 0 && g < G.nlat)
+                val = qd_mom_cell(A + rho * QD_S + lane, g, j, G, P, comp, ru[k], rv[k], rf[k], sT[8 * RA + rho], sT[9 * RA + rho]);
+            keep[k] = val;
+            if (rho >= 1 && rho < TR + 9) B[rho * QD_S + lane] = qd_nnf(val);     // _hyperdiffuse starts from nan_to_num(F)
+        }
+        double* out = comp == 0 ? P.uo : P.vo;
+        if (P.skip[comp]) { qd_store_owned<TR>(keep, out, G, i0, j0); }
+        else {
+            __syncthreads();
+            qd_del4_from_B<TR>(B, D, out, G, i0, j0, C, sT + (3 + comp) * RA, P.dt);
+        }
+    }
+    // ---- h, q, cloud: B <- nan_to_num(register copy)
+#pragma unroll
+    for (int f = 2; f < 5; ++f) {
+        double* out = f == 2 ? P.ho : (f == 3 ? P.qo : P.co);
+        if (P.skip[f]) {
+            if (f == 2) qd_store_owned<TR>(ah, out, G, i0, j0);
+            else if (f == 3) qd_store_owned<TR>(rq, out, G, i0, j0);
+            else qd_store_owned<TR>(rc, out, G, i0, j0);
+            continue;
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int rho = wv + QD_NW * k;
+            if (rho >= 1 && rho < TR + 9) B[rho * QD_S + lane] = qd_nnf(f == 2 ? ah[k] : (f == 3 ? rq[k] : rc[k]));
+        }
+        __syncthreads();
+        qd_del4_from_B<TR>(B, D, out, G, i0, j0, C, sT + (3 + f) * RA, P.dt);
+    }
+}
+
+// =========================================================================================
+// ocean
+// =========================================================================================
+template <int TR>
+__global__ void __launch_bounds__(QD_FBLOCK, 4)
+k_ocn_hyper(QdGeom G, QdTabs T, QdOcnArgs P) {
+    extern __shared__ __align__(16) double lds[];
+    constexpr int RA = QdPl<TR>::RA, K = QdPl<TR>::K;
+    double* A = lds;
+    double* B = A + RA * QD_S;
+    double* D = B + RA * QD_S;
+    int i0, j0;
+    qd_tile_origin(P.ts.ntc, TR, G.row0, i0, j0);
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: row math + table loads go scalar
+    const int j = qd_wrapj(j0 - 3 + lane, G.nlon);
+    // staged row tables: 0 lapA 1 lapP 2 lapQ 3..5 k4[uo,vo,eta] 6 fcor 7 ocn_igx 8 r_extra
+    double* sT = D + RA * QD_S;
+    if (threadIdx.x < RA) {
+        const int rho = threadIdx.x, g = i0 - 5 + rho;
+        const bool ok = g >= 0 && g < G.nlat;
+        const int gg = ok ? g : 0;
+        sT[0 * RA + rho] = ok ? T.lapA[1][gg] : 0.0;
+        sT[1 * RA + rho] = ok ? T.lapP[1][gg] : 0.0;
+        sT[2 * RA + rho] = ok ? T.lapQ[1][gg] : 0.0;
+        for (int f = 0; f < 3; ++f) sT[(3 + f) * RA + rho] = P.k4row[f] ? (ok ? P.k4row[f][gg] : 0.0) : P.k4s[f];
+        sT[6 * RA + rho] = ok ? T.fcor[gg] : 0.0;
+        sT[7 * RA + rho] = ok ? T.ocn_igx[gg] : 0.0;
+        sT[8 * RA + rho] = ok ? T.r_extra[gg] : 0.0;
+    }
+    const QdLapC C{P.dlat, P.dlon, P.a, G.nlat, T.cos05, sT, sT + RA, sT + 2 * RA};
+
+    double ae[K], ru[K], rv[K], rtx[K], rty[K];
+    int rl[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int rho = wv + QD_NW * k;
+        const int g = i0 - 5 + rho;
+        // eta rows wrap across the poles (np.roll(axis=0), ocean.py:308); band mode reads the halo
+        int ge = g;
+        if (G.full) { if (ge < 0) ge += G.nlat; else if (ge >= G.nlat) ge -= G.nlat; }
+        const bool okA = rho < RA;
+        const bool inB = okA && rho >= 1 && rho < TR + 9 && g >= 0 && g < G.nlat;
+        const unsigned oe = okA ? (unsigned)qd_lrow(G, ge) * (unsigned)G.nlon + (unsigned)j : (unsigned)j;
+        const unsigned o = inB ? (unsigned)qd_lrow(G, g) * (unsigned)G.nlon + (unsigned)j : (unsigned)j;
+        ae[k] = P.eta[oe]; ru[k] = P.uo[o]; rv[k] = P.vo[o]; rtx[k] = P.taux[o]; rty[k] = P.tauy[o];
+        rl[k] = (int)P.land[o];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int rho = wv + QD_NW * k;
+        const int g = i0 - 5 + rho;
+        const bool okA = rho < RA;
+        const bool inB = okA && rho >= 1 && rho < TR + 9 && g >= 0 && g < G.nlat;
+        ae[k] = okA ? ae[k] : 0.0;
+        ru[k] = inB ? ru[k] : 0.0; rv[k] = inB ? rv[k] : 0.0; rtx[k] = inB ? rtx[k] : 0.0; rty[k] = inB ? rty[k] : 0.0;
+        rl[k] = inB ? rl[k] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) { const int rho = wv + QD_NW * k; if (rho < RA) A[rho * QD_S + lane] = ae[k]; }
+    __syncthreads();
+
+#pragma unroll
+    for (int comp = 0; comp < 2; ++comp) {
+        double keep[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int rho = wv + QD_NW * k;
+            const int g = i0 - 5 + rho;
+            double val = 0.0;
+            if (rho >= 1 && rho < TR + 9 && lane >= 1 && lane <= 62 && g >= 0 && g < G.nlat) {
+                // ocean.py:306-336 (both axes roll-periodic)
+                const double* p = A + rho * QD_S + lane;
+                const double f = sT[6 * RA + rho];
+                double xn;
+                if (comp == 0) {
+                    const double gx = ((p[1] - p[-1]) * P.inv_2dlon) * sT[7 * RA + rho];
+                    const double du = (f * rv[k] - P.g * gx + rtx[k] * P.inv_rhoH - P.r_bot * ru[k]);
+                    xn = ru[k] + P.sub_dt * du;
+                } else {
+                    const double gy = ((p[QD_S] - p[-QD_S]) * P.inv_2dlat) * P.inv_a;
+                    const double dv = (-f * ru[k] - P.g * gy + rty[k] * P.inv_rhoH - P.r_bot * rv[k]);
+                    xn = rv[k] + P.sub_dt * dv;
+                }
+                if (rl[k] == 1) xn = 0.0;
+                val = xn - P.sub_dt * sT[8 * RA + rho] * xn;
+            }
+            keep[k] = val;
+            if (rho >= 1 && rho < TR + 9) B[rho * QD_S + lane] = qd_nnf(val);
+        }
+        double* out = comp == 0 ? P.uo_out : P.vo_out;
+        if (P.skip[comp]) { qd_store_owned<TR>(keep, out, G, i0, j0); }
+        else {
+            __syncthreads();
+            qd_del4_from_B<TR>(B, D, out, G, i0, j0, C, sT + (3 + comp) * RA, P.sub_dt);
+        }
+    }
+    if (P.skip[2]) { qd_store_owned<TR>(ae, P.eta_out, G, i0, j0); return; }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int rho = wv + QD_NW * k;
+        const int g = i0 - 5 + rho;
+        if (rho >= 1 && rho < TR + 9) B[rho * QD_S + lane] = (g >= 0 && g < G.nlat) ? qd_nnf(ae[k]) : 0.0;
+    }
+    __syncthreads();
+    qd_del4_from_B<TR>(B, D, P.eta_out, G, i0, j0, C, sT + 5 * RA, P.sub_dt);
+}
+
+// =========================================================================================
+// host side
+// =========================================================================================
+static const int kTileRows[] = {6, 10, 14, 18, 22, 26, 30, 38};
+static const int kNTileRows = sizeof(kTileRows) / sizeof(int);
+
+static size_t qd_tile_lds_bytes(int tr) { return sizeof(double) * (QD_S * (size_t)(3 * (tr + 10)) + (size_t)10 * (tr + 10)); }
+
+// Pick the instantiation whose tile count fills (256 CUs x resident workgroups) in the fewest
+// rounds, each round weighted by the tile's work including the recomputed halo rows.
+QdTileShape qd_pick_tile(const QdGeom& G) {
+    const int ncu = 256;
+    const size_t lds_cu = 160 * 1024;
+    double best = 1e300;
+    QdTileShape bs{kTileRows[0], QD_TC, 1, 1};
+    const int ntc = (G.nlon + QD_TC - 1) / QD_TC;
+    for (int t = 0; t < kNTileRows; ++t) {
+        const int tr = kTileRows[t];
+        const int slots = (int)std::min<size_t>(lds_cu / qd_tile_lds_bytes(tr), 2);   // 2 x 8 waves: the 128-VGPR cap of __launch_bounds__(512, 4)
+        if (slots < 1) continue;
+        const int ntr = (G.nrows + tr - 1) / tr;
+        const long tiles = (long)ntr * ntc;
+        const long cap = (long)ncu * slots;
+        const long rounds = (tiles + cap - 1) / cap;
+        // co-resident workgroups share the CU: a round costs (tile work) x (workgroups per CU in it)
+        const double per_cu = std::max(1.0, std::ceil((double)tiles / (double)rounds / ncu));
+        const double work = (double)(tr + 10) + 0.5 * (double)(tr + 8);
+        const double cost = rounds * (per_cu * work + 12.0);
+        if (cost < best) { best = cost; bs = QdTileShape{tr, QD_TC, ntr, ntc}; }
+    }
+    return bs;
+}
+
+static void qd_tile_init(qd_ctx* c) {
+    if (c->tile.tr != 0) return;
+    c->tile = qd_pick_tile(c->geo);
+    const char* etr = std::getenv("QD_TILE_TR");              // tuning override
+    if (etr) {
+        const int tr = std::atoi(etr);
+        for (int t = 0; t < kNTileRows; ++t)
+            if (kTileRows[t] == tr)
+                c->tile = QdTileShape{tr, QD_TC, (c->geo.nrows + tr - 1) / tr, (c->geo.nlon + QD_TC - 1) / QD_TC};
+    }
+}
+
+template <int TR> static void launch_dyn(qd_ctx* c, const QdDynArgs& P) {
+    static bool once = false;
+    if (!once) { hipFuncSetAttribute((const void*)k_dyn_hyper<TR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)QdPl<TR>::lds_bytes); once = true; }
+    hipLaunchKernelGGL(k_dyn_hyper<TR>, dim3(P.ts.ntr * P.ts.ntc), dim3(QD_FBLOCK), QdPl<TR>::lds_bytes, c->stream, c->geo, c->tabs, P);
+}
+template <int TR> static void launch_ocn(qd_ctx* c, const QdOcnArgs& P) {
+    static bool once = false;
+    if (!once) { hipFuncSetAttribute((const void*)k_ocn_hyper<TR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)QdPl<TR>::lds_bytes); once = true; }
+    hipLaunchKernelGGL(k_ocn_hyper<TR>, dim3(P.ts.ntr * P.ts.ntc), dim3(QD_FBLOCK), QdPl<TR>::lds_bytes, c->stream, c->geo, c->tabs, P);
+}
+
+#define QD_DISPATCH_TR(tr, CALL)                                                                              \
+    switch (tr) {                                                                                             \
+        case 6: CALL(6); break; case 10: CALL(10); break; case 14: CALL(14); break; case 18: CALL(18); break; \
+        case 22: CALL(22); break; case 26: CALL(26); break; case 30: CALL(30); break; case 38: CALL(38); break; \
+        default: return qd_fail(c, "fused kernel: no instantiation for this tile height");                    \
+    }
+
+int qd_launch_dyn_hyper(qd_ctx* c, QdDynArgs& P) {
+    qd_tile_init(c);
+    P.ts = c->tile;
+    QdScope sc(c, "k_dyn_hyper");
+#define QD_CALL_DYN(N) launch_dyn<N>(c, P)
+    QD_DISPATCH_TR(P.ts.tr, QD_CALL_DYN)
+    return 0;
+}
+
+int qd_launch_ocn_hyper(qd_ctx* c, QdOcnArgs& P) {
+    qd_tile_init(c);
+    P.ts = c->tile;
+    QdScope sc(c, "k_ocn_hyper");
+#define QD_CALL_OCN(N) launch_ocn<N>(c, P)
+    QD_DISPATCH_TR(P.ts.tr, QD_CALL_OCN)
+    return 0;
+}

@@ -41,6 +41,15 @@ struct QdTabs {
     const double* fcor;      // 2 Omega sin(lat) grid.py:90-96
     const double* warea;     // max(cos,0)       energy.py:520, ocean.py:372
     const double* r_extra;   // polar sponge gain * s^2   ocean.py:332-334
+    // reciprocal-form coefficients of the fused (fast) kernels, per cos-floor kind k = 0 (0.2), 1 (0.5):
+    //   lapA[k][r] = cos_k[r]/(2 dphi)   lapP[k][i] = 1/(a^2 cos_k[i] 2 dphi)   lapQ[k][i] = 1/(a^2 dlam^2 cos_k[i]^2)
+    const double* lapA[2];
+    const double* lapP[2];
+    const double* lapQ[2];
+    const double* mom_cu;    // -(g / (f_safe a cos6))   geostrophic u_g coefficient
+    const double* mom_cv;    //   g / (f_safe a)         geostrophic v_g coefficient
+    const double* mom_px;    // -(g / (a cos6))          primitive PGF_x coefficient
+    const double* ocn_igx;   // 1 / (a cos05)
     const double* lon_rad;   // deg2rad(lon) [n_lon]
     const double* sin_lon;   // [n_lon]
     const double* cos_lon;   // [n_lon]
@@ -86,8 +95,29 @@ __device__ __forceinline__ int qd_wrapc(int j, int n) {        // periodic colum
     return j < 0 ? j + n : (j >= n ? j - n : j);
 }
 
+// XCD-aware work mapping.  Workgroups are dealt round-robin over the 8 XCDs (block b and b+8
+// share an L2); a row-segment stencil wants the rows it re-reads (i-2..i+2) in the SAME L2, so
+// the linear block id is remapped such that every XCD walks one contiguous chunk of
+// (field, row, segment) work items.  Pure performance: any placement gives the same result.
+struct QdTile { int seg, row, fld; };
+__device__ __forceinline__ QdTile qd_tile() {
+    const unsigned gx = gridDim.x, gy = gridDim.y;
+    const unsigned nb = gx * gy * gridDim.z;
+    const unsigned L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned per = nb >> 3, rem = nb & 7u;
+    const unsigned x = L & 7u, s = L >> 3;
+    const unsigned w = x * per + (x < rem ? x : rem) + s;
+    QdTile t;
+    t.seg = (int)(w % gx);
+    const unsigned r = w / gx;
+    t.row = (int)(r % gy);
+    t.fld = (int)(r / gy);
+    return t;
+}
+
 // ---------------------------------------------------------------- host context
 struct QdTimer { double total_ms = 0; int64_t n = 0; };
+struct QdTileShape { int tr, tc, ntr, ntc; };
 
 struct qd_ctx {
     qd_grid_desc desc;
@@ -116,6 +146,8 @@ struct qd_ctx {
     double* hpin = nullptr;        // pinned host scalars
     double wsum_ocean = 0, wsum_all = 0;
     int64_t atm_counter = 0, ocn_counter = 0;
+    QdTileShape tile{0, 0, 0, 0};   // fused-kernel tile (qd_pick_tile)
+    int use_fused = 1;              // QD_FUSED=0 selects the unfused reference-order kernels
     int cloud_eff_valid = 0;
     int last_nsub = 0;
     // host staging

@@ -15,6 +15,7 @@
 #include "qd_device.h"
 
 #include "qd_fluxes.h"
+#include "qd_fused.h"
 
 QdColP qd_make_colp(const qd_ctx* c, double dt);   // qd_atmos.hip
 
@@ -25,9 +26,10 @@ k_qnet(QdGeom G, QdColP P, const double* __restrict__ isr, const double* __restr
        const double* __restrict__ u, const double* __restrict__ v, const uint8_t* __restrict__ land,
        const double* __restrict__ hice, const double* __restrict__ LH, double* __restrict__ qnet,
        uint8_t* __restrict__ icemask) {
-    const int j = blockIdx.x * QD_BLOCK + threadIdx.x;
+    const QdTile tl = qd_tile();
+    const int j = tl.seg * QD_BLOCK + threadIdx.x;
     if (j >= G.nlon) return;
-    const size_t o = (size_t)qd_lrow(G, G.row0 + blockIdx.y) * G.nlon + j;
+    const size_t o = (size_t)qd_lrow(G, G.row0 + tl.row) * G.nlon + j;
     const double hh = h[o];
     const double T_a = 288.0 + P.ga * hh;
     const double hi = hice[o];
@@ -96,9 +98,10 @@ __global__ void __launch_bounds__(QD_BLOCK)
 k_ocean_momentum(QdGeom G, QdTabs T, QdOcnP P, const double* __restrict__ eta, const double* __restrict__ taux,
                  const double* __restrict__ tauy, const uint8_t* __restrict__ land,
                  double* __restrict__ uo, double* __restrict__ vo) {
-    const int j = blockIdx.x * QD_BLOCK + threadIdx.x;
+    const QdTile tl = qd_tile();
+    const int j = tl.seg * QD_BLOCK + threadIdx.x;
     if (j >= G.nlon) return;
-    const int i = G.row0 + blockIdx.y;
+    const int i = G.row0 + tl.row;
     const size_t b = (size_t)qd_lrow(G, i) * G.nlon;
     const size_t o = b + j;
     const int jp = qd_wrapc(j + 1, G.nlon), jm = qd_wrapc(j - 1, G.nlon);
@@ -177,9 +180,10 @@ k_sst_advect(QdGeom G, const double* __restrict__ cos05, double sub_dt, double a
              const double* __restrict__ uo, const double* __restrict__ vo, const double* __restrict__ Ts,
              double* __restrict__ Ts_out, double alpha, double* __restrict__ eta, const double* __restrict__ eta_mean,
              int has_ocean) {
-    const int j = blockIdx.x * QD_BLOCK + threadIdx.x;
+    const QdTile tl = qd_tile();
+    const int j = tl.seg * QD_BLOCK + threadIdx.x;
     if (j >= G.nlon) return;
-    const int i = G.row0 + blockIdx.y;
+    const int i = G.row0 + tl.row;
     const size_t o = (size_t)qd_lrow(G, i) * G.nlon + j;
     if (has_ocean) eta[o] = eta[o] - *eta_mean;
     const QdBilin b = qd_departure(G, i, j, uo[o], vo[o], sub_dt, a, cos05[i], dlat, dlon);
@@ -194,9 +198,10 @@ __global__ void __launch_bounds__(QD_BLOCK)
 k_sst_diffuse_heat(QdGeom G, const double* __restrict__ cos05, double dlat, double dlon, double a, QdHeatP P,
                    const double* __restrict__ Ts1, double* __restrict__ Ts_out, const double* __restrict__ qnet,
                    const uint8_t* __restrict__ land, const uint8_t* __restrict__ ice) {
-    const int j = blockIdx.x * QD_BLOCK + threadIdx.x;
+    const QdTile tl = qd_tile();
+    const int j = tl.seg * QD_BLOCK + threadIdx.x;
     if (j >= G.nlon) return;
-    const int i = G.row0 + blockIdx.y;
+    const int i = G.row0 + tl.row;
     const size_t o = (size_t)qd_lrow(G, i) * G.nlon + j;
     double T = Ts1[o];
     if (P.K_h > 0.0) T = T + P.sub_dt * P.K_h * qd_lap_point<true>(Ts1, G, cos05, i, j, dlat, dlon, a);
@@ -216,9 +221,10 @@ k_sst_diffuse_heat(QdGeom G, const double* __restrict__ cos05, double dlat, doub
 __global__ void __launch_bounds__(QD_BLOCK)
 k_outlier(QdGeom G, const double* __restrict__ uo, const double* __restrict__ vo, double* __restrict__ uo_out,
           double* __restrict__ vo_out, double* __restrict__ eta, double cap, double eta_cap, int mean4) {
-    const int j = blockIdx.x * QD_BLOCK + threadIdx.x;
+    const QdTile tl = qd_tile();
+    const int j = tl.seg * QD_BLOCK + threadIdx.x;
     if (j >= G.nlon) return;
-    const int i = G.row0 + blockIdx.y;
+    const int i = G.row0 + tl.row;
     const size_t b = (size_t)qd_lrow(G, i) * G.nlon;
     const size_t o = b + j;
     double u = qd_nn(uo[o]), v = qd_nn(vo[o]);
@@ -294,9 +300,10 @@ __global__ void __launch_bounds__(QD_BLOCK)
 k_sst_clamp_inject(QdGeom G, double* __restrict__ sst, double tmin, double tmax, int inject,
                    const uint8_t* __restrict__ land, const uint8_t* __restrict__ ice, int has_ice,
                    double* __restrict__ Ts_atm) {
-    const int j = blockIdx.x * QD_BLOCK + threadIdx.x;
+    const QdTile tl = qd_tile();
+    const int j = tl.seg * QD_BLOCK + threadIdx.x;
     if (j >= G.nlon) return;
-    const size_t o = (size_t)qd_lrow(G, G.row0 + blockIdx.y) * G.nlon + j;
+    const size_t o = (size_t)qd_lrow(G, G.row0 + tl.row) * G.nlon + j;
     const double t = qd_clip(sst[o], tmin, tmax);
     sst[o] = t;
     // gcm.T_s = where(ocean & ~ice, ocean.Ts, gcm.T_s)    run_simulation.py:2252-2253
@@ -354,18 +361,34 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
     const double ov[3] = {p.ocean_k4_u, p.ocean_k4_v, p.ocean_k4_eta};
 
     for (int s = 0; s < n_sub; ++s) {
-        {
-            QdScope sc(c, "ocean_momentum");
-            hipLaunchKernelGGL(k_ocean_momentum, grid, blk, 0, c->stream, G, c->tabs, OP, c->f[QD_F_ETA], taux, tauy,
-                               c->land, c->f[QD_F_UO], c->f[QD_F_VO]);
-        }
-        if (do_diff) {
-            QdScope sc(c, "ocean_hyperdiffusion");
-            double* fl[3] = {c->f[QD_F_UO], c->f[QD_F_VO], c->f[QD_F_ETA]};
-            c->lap_tag = "ocean_k_laplacian"; c->hyp_tag = "ocean_k_hyper_apply";
-            qd_hyperdiffuse_fields(c, fl, 3, c->k4_ocn, c->k4_ocn_skip, ov, sub_dt, p.ocean_k4_nsub, c->tabs.cos05);
-            c->lap_tag = "k_laplacian"; c->hyp_tag = "k_hyper_apply";
-            c->f[QD_F_UO] = fl[0]; c->f[QD_F_VO] = fl[1]; c->f[QD_F_ETA] = fl[2];
+        if (do_diff && c->use_fused && p.ocean_k4_nsub == 1) {
+            QdOcnArgs O;
+            O.uo = c->f[QD_F_UO]; O.vo = c->f[QD_F_VO]; O.eta = c->f[QD_F_ETA]; O.taux = taux; O.tauy = tauy; O.land = c->land;
+            O.uo_out = qd_scratch(c, 0); O.vo_out = qd_scratch(c, 1); O.eta_out = qd_scratch(c, 2);
+            for (int f = 0; f < 3; ++f) {
+                const bool sc1 = !(ov[f] != ov[f]);
+                O.k4row[f] = sc1 ? nullptr : c->k4_ocn + (size_t)f * G.nlat;
+                O.k4s[f] = sc1 ? ov[f] : 0.0;
+                O.skip[f] = c->k4_ocn_skip[f];
+            }
+            O.a = p.a; O.g = p.g_ocean; O.dlat = c->dlat; O.dlon = c->dlon; O.sub_dt = sub_dt; O.rhoH = p.rho_w * H; O.r_bot = p.r_bot;
+            O.inv_2dlon = 1.0 / (2.0 * c->dlon); O.inv_2dlat = 1.0 / (2.0 * c->dlat); O.inv_a = 1.0 / p.a; O.inv_rhoH = 1.0 / (p.rho_w * H);
+            qd_launch_ocn_hyper(c, O);
+            qd_swap(c, QD_F_UO, 0); qd_swap(c, QD_F_VO, 1); qd_swap(c, QD_F_ETA, 2);
+        } else {
+            {
+                QdScope sc(c, "ocean_momentum");
+                hipLaunchKernelGGL(k_ocean_momentum, grid, blk, 0, c->stream, G, c->tabs, OP, c->f[QD_F_ETA], taux, tauy,
+                                   c->land, c->f[QD_F_UO], c->f[QD_F_VO]);
+            }
+            if (do_diff) {
+                QdScope sc(c, "ocean_hyperdiffusion");
+                double* fl[3] = {c->f[QD_F_UO], c->f[QD_F_VO], c->f[QD_F_ETA]};
+                c->lap_tag = "ocean_k_laplacian"; c->hyp_tag = "ocean_k_hyper_apply";
+                qd_hyperdiffuse_fields(c, fl, 3, c->k4_ocn, c->k4_ocn_skip, ov, sub_dt, p.ocean_k4_nsub, c->tabs.cos05);
+                c->lap_tag = "k_laplacian"; c->hyp_tag = "k_hyper_apply";
+                c->f[QD_F_UO] = fl[0]; c->f[QD_F_VO] = fl[1]; c->f[QD_F_ETA] = fl[2];
+            }
         }
         if (do_shap) {
             double* fl[3] = {c->f[QD_F_UO], c->f[QD_F_VO], c->f[QD_F_ETA]};

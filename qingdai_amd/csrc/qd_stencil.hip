@@ -16,10 +16,11 @@
 // ------------------------------------------------------------------ Laplacian (device)
 __global__ void __launch_bounds__(QD_BLOCK)
 k_laplacian(QdGeom G, QdFieldList fl, const double* __restrict__ cosf, double dphi, double dlam, double a) {
-    const int j = blockIdx.x * QD_BLOCK + threadIdx.x;
+    const QdTile tl = qd_tile();
+    const int j = tl.seg * QD_BLOCK + threadIdx.x;
     if (j >= G.nlon) return;
-    const int i = G.row0 + blockIdx.y;
-    const int f = blockIdx.z;
+    const int i = G.row0 + tl.row;
+    const int f = tl.fld;
     const size_t o = (size_t)qd_lrow(G, i) * G.nlon + j;
     fl.out[f][o] = qd_lap_point<true>(fl.in[f], G, cosf, i, j, dphi, dlam, a);
 }
@@ -28,10 +29,11 @@ k_laplacian(QdGeom G, QdFieldList fl, const double* __restrict__ cosf, double dp
 __global__ void __launch_bounds__(QD_BLOCK)
 k_hyper_apply(QdGeom G, QdFieldList fl, const double* __restrict__ cosf, double dphi, double dlam, double a,
               double sub_dt) {
-    const int j = blockIdx.x * QD_BLOCK + threadIdx.x;
+    const QdTile tl = qd_tile();
+    const int j = tl.seg * QD_BLOCK + threadIdx.x;
     if (j >= G.nlon) return;
-    const int i = G.row0 + blockIdx.y;
-    const int f = blockIdx.z;
+    const int i = G.row0 + tl.row;
+    const int f = tl.fld;
     const size_t o = (size_t)qd_lrow(G, i) * G.nlon + j;
     const double L2 = qd_lap_point<true>(fl.in[f], G, cosf, i, j, dphi, dlam, a);
     const double k4 = fl.k4row[f] ? fl.k4row[f][i] : fl.k4s[f];
@@ -96,10 +98,11 @@ int qd_hyperdiffuse_fields(qd_ctx* c, double** fields, int n, const double* k4ta
 // ------------------------------------------------------------------ Shapiro
 __global__ void __launch_bounds__(QD_BLOCK)
 k_shapiro_pass(QdGeom G, QdFieldList fl, int scrub) {
-    const int j = blockIdx.x * QD_BLOCK + threadIdx.x;
+    const QdTile tl = qd_tile();
+    const int j = tl.seg * QD_BLOCK + threadIdx.x;
     if (j >= G.nlon) return;
-    const int i = G.row0 + blockIdx.y;
-    const int f = blockIdx.z;
+    const int i = G.row0 + tl.row;
+    const int f = tl.fld;
     const double* __restrict__ F = fl.in[f];
     const int jm = qd_wrapc(j - 1, G.nlon), jp = qd_wrapc(j + 1, G.nlon);
     const int rm = i > 0 ? i - 1 : 0, rp = i < G.nlat - 1 ? i + 1 : G.nlat - 1;   // mode='nearest'
@@ -138,9 +141,10 @@ k_advect(QdGeom G, const double* __restrict__ u, const double* __restrict__ v, c
          double dt, double a, double dlat, double dlon,
          const double* __restrict__ f0, double* __restrict__ o0,
          const double* __restrict__ f1, double* __restrict__ o1, double alpha, int clipq) {
-    const int j = blockIdx.x * QD_BLOCK + threadIdx.x;
+    const QdTile tl = qd_tile();
+    const int j = tl.seg * QD_BLOCK + threadIdx.x;
     if (j >= G.nlon) return;
-    const int i = G.row0 + blockIdx.y;
+    const int i = G.row0 + tl.row;
     const size_t o = (size_t)qd_lrow(G, i) * G.nlon + j;
     const QdBilin b = qd_departure(G, i, j, u[o], v[o], dt, a, cosl[i], dlat, dlon);
     const bool blend = (alpha != 1.0);
@@ -169,9 +173,10 @@ void qd_launch_advect(qd_ctx* c, const double* u, const double* v, const double*
 __global__ void __launch_bounds__(QD_BLOCK)
 k_divvort(QdGeom G, QdTabs T, const double* __restrict__ u, const double* __restrict__ v, double* __restrict__ out,
           double a, double dlat, double dlon, int vort) {
-    const int j = blockIdx.x * QD_BLOCK + threadIdx.x;
+    const QdTile tl = qd_tile();
+    const int j = tl.seg * QD_BLOCK + threadIdx.x;
     if (j >= G.nlon) return;
-    const int i = G.row0 + blockIdx.y;
+    const int i = G.row0 + tl.row;
     out[(size_t)qd_lrow(G, i) * G.nlon + j] =
         vort ? qd_divvort_point(G, T, v, u, i, j, a, dlat, dlon, 1) : qd_divvort_point(G, T, u, v, i, j, a, dlat, dlon, 0);
 }
@@ -196,9 +201,10 @@ __device__ __forceinline__ int qd_ext(int i, int n, int mode_wrap) {
 // scipy correlate1d symmetric branch: tmp = x0*w0; for k = r..1: tmp += (x[-k] + x[+k]) * w[k]
 __global__ void __launch_bounds__(QD_BLOCK)
 k_gauss_axis(QdGeom G, const double* __restrict__ in, double* __restrict__ out, QdGaussW W, int axis, int mode_wrap) {
-    const int j = blockIdx.x * QD_BLOCK + threadIdx.x;
+    const QdTile tl = qd_tile();
+    const int j = tl.seg * QD_BLOCK + threadIdx.x;
     if (j >= G.nlon) return;
-    const int i = G.row0 + blockIdx.y;
+    const int i = G.row0 + tl.row;
     const size_t o = (size_t)qd_lrow(G, i) * G.nlon + j;
     double tmp = in[o] * W.w[0];
     if (axis == 0) {
