@@ -366,6 +366,78 @@ def case_physics(nlat, nlon, seed):
          Pc_wet=Pc_wet, base_albedo=alb, **{"ref_" + k: v for k, v in out.items()})
 
 
+def case_driver_physics(nlat, nlon, seed, nsteps=3):
+    """run_simulation.py:1766-1934 + 2063-2146 composed from the REFERENCE's functions
+    (physics.*, scripts.run_simulation._advect_scalar_periodic, scipy gaussian_filter), interleaved
+    with the reference time_step(Teq, dt) the way the driver calls it (no albedo argument)."""
+    from scipy.ndimage import gaussian_filter
+    from pygcm import physics as rph
+    from pygcm.forcing import ThermalForcing
+    from pygcm.orbital import OrbitalSystem
+    cwd = os.getcwd()
+    os.chdir("/tmp")
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            from scripts.run_simulation import _advect_scalar_periodic
+    finally:
+        os.chdir(cwd)
+    from qd_oracle.driver import driver_physics_step
+    g, mask, alb, fric = surface(nlat, nlon)
+    st = perturbed_state((nlat, nlon), seed, cloudy=True, icy=True)
+    dt = 300.0
+    snaps = {}
+    with ref_env({}):
+        forcing = ThermalForcing(g, OrbitalSystem())
+        m = build_ref_model(g, mask, fric, st)
+        for i in range(nsteps):
+            t = i * dt
+            precip = rph.diagnose_precipitation_hybrid(m, g, D_crit=-1e-7, k_precip=1e5, orog_factor=None,
+                                                       smooth_sigma=1.0, beta_div=0.4, renorm=True)
+            if np.any(precip > 0):
+                P_pos = precip[precip > 0]
+                P_ref = float(np.median(P_pos)) if P_pos.size > 0 else 1e-6
+            else:
+                P_ref = 1e-6
+            C_from_P = rph.cloud_from_precip(precip, C_max=0.95, P_ref=P_ref, smooth_sigma=1.0)
+            src = rph.parameterize_cloud_cover(m, g, mask)
+            tendency = src * (dt / (6 * 3600))
+            W_MEM, W_P, W_SRC = 0.4, 0.4, 0.2
+            W_sum = W_MEM + W_P + W_SRC
+            W_MEM /= W_sum; W_P /= W_sum; W_SRC /= W_sum
+            m.cloud_cover = (W_MEM * m.cloud_cover + W_P * C_from_P + W_SRC * np.clip(m.cloud_cover + tendency, 0.0, 1.0))
+            m.cloud_cover = np.maximum(m.cloud_cover, np.clip(0.8 * C_from_P, 0.0, 1.0))
+            m.cloud_cover = np.clip(m.cloud_cover, 0.0, 1.0)
+            cloud_adv = _advect_scalar_periodic(m.cloud_cover, m.u, m.v, dt, g)
+            cloud_adv = gaussian_filter(cloud_adv, sigma=0.2, mode="wrap")
+            m.cloud_cover = np.clip((1.0 - 0.7) * m.cloud_cover + 0.7 * cloud_adv, 0.0, 1.0)
+            insA, insB = forcing.calculate_insolation_components(t)
+            m.isr_A, m.isr_B = insA, insB
+            m.isr = insA + insB
+            ice_frac = 1.0 - np.exp(-np.maximum(m.h_ice, 0.0) / 0.5)
+            cloud_for_rad = getattr(m, "cloud_eff_last", m.cloud_cover)
+            albedo = rph.calculate_dynamic_albedo(cloud_for_rad, m.T_s, alb.copy(), 0.6, 0.5, land_mask=mask, ice_frac=ice_frac)
+            Teq = forcing.calculate_equilibrium_temp(t, albedo)
+            m.time_step(Teq, dt)
+            if i == 0:
+                snaps.update(s1_precip=precip.copy(), s1_albedo=albedo.copy(), s1_C_from_P=C_from_P.copy(), s1_src=src.copy())
+    P = qo.defaults()
+    og, om = build_oracle_model(g, mask, fric, P, st)
+    of = qo.Forcing(og)
+    for i in range(nsteps):
+        t = i * dt
+        precip_o, albedo_o = driver_physics_step(om, og, P, alb, mask, dt)
+        a_, b_ = of.insolation_components(t)
+        om.isr_A, om.isr_B, om.isr = a_, b_, a_ + b_
+        om.time_step(of.equilibrium_temp(t, albedo_o), dt)
+    for k in STATE:
+        print(f"    {k:18s} oracle-vs-ref maxrel {maxrel(getattr(om, k), getattr(m, k)):.2e}")
+    print(f"    precip(last)       oracle-vs-ref maxrel {maxrel(precip_o, precip):.2e}")
+    print(f"    albedo(last)       oracle-vs-ref maxrel {maxrel(albedo_o, albedo):.2e}")
+    save(f"driverphys_{nlat}x{nlon}", dict(kind="driver_physics", nlat=nlat, nlon=nlon, seed=seed, nsteps=nsteps, dt=dt),
+         **{"init_" + k: st[k] for k in STATE}, **{"ref_" + k: getattr(m, k) for k in STATE},
+         ref_precip_last=precip, ref_albedo_last=albedo, **snaps)
+
+
 def main():
     only = sys.argv[1:]
 
@@ -401,6 +473,10 @@ def main():
         if want(c[0]):
             print(f"[{c[0]}]")
             case_ocean(*c)
+    if want("driverphys"):
+        for (a, b, sd) in ((19, 36, 41), (37, 72, 42)):
+            print(f"[driver physics {a}x{b}]")
+            case_driver_physics(a, b, sd)
     if want("physics"):
         for (a, b, s) in ((19, 36, 31), (37, 72, 32)):
             print(f"[physics {a}x{b}]")

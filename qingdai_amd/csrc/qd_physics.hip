@@ -1,8 +1,249 @@
-// qd_physics.hip -- driver-side per-step diagnostics (pygcm/physics.py, run_simulation.py:1766-2146).
+// qd_physics.hip -- driver-side per-step diagnostics on gfx950
+// (pygcm/physics.py:12-354 as sequenced by scripts/run_simulation.py:1766-1934, 2063-2146):
+//
+//   k_precip_raw      divergence -> pos = max(0, -(div - D_crit)); F_div = clip(pos/median(pos>0), 0, 5);
+//                     P_raw = max(0, P_cond) (1 + beta F_div); weighted sums for the renormalisation
+//   k_gauss_axis x2   sigma = 1 blur of s * P_raw                       (physics.py:318-330)
+//   k_pdyn + blur     legacy convergence precipitation for the fallback blend (physics.py:344-352)
+//   k_precip_blend    (1 - a) P + a P_dyn when <P_cond> < PQ_MIN, clip >= 0
+//   radix select      P_ref = median(precip > 0)                        (run_simulation.py:1866-1874)
+//   k_cloud_from_p    C_max tanh(P / (P_ref + 1e-12)) -> blur -> clip   (physics.py:48-70)
+//   k_cloud_source    tanh terms from T_s, relative vorticity, |T advection| -> blur -> clip (physics.py:72-114)
+//   k_cloud_blend     memory / precipitation / source blend + event floor (run_simulation.py:1890-1913)
+//   k_advect + blur   cloud tracer advection, cos floor 0.5, sigma = 0.2 wrap (run_simulation.py:1916-1934)
+//   k_cloud_albedo    alpha-blend + ice fraction + dynamic albedo       (physics.py:164-250)
 #include "qd_internal.h"
 #include "qd_device.h"
 
+__device__ __forceinline__ double qd_wsum(double x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+    return x;
+}
+
+// one workgroup per row: P_raw and the two weighted row sums (num = sum Pq w, den = sum P_raw w)
+__global__ void __launch_bounds__(QD_BLOCK)
+k_precip_raw(QdGeom G, QdTabs T, const double* __restrict__ u, const double* __restrict__ v,
+             const double* __restrict__ pcond, double a, double dlat, double dlon, double D_crit, double beta,
+             const double* __restrict__ scale_p, const unsigned long long* __restrict__ sel_state,
+             double* __restrict__ praw, double* __restrict__ pos_out, double* __restrict__ partial) {
+    __shared__ double sm[2][QD_BLOCK / 64];
+    const int i = G.row0 + blockIdx.y;
+    const size_t b = (size_t)qd_lrow(G, i) * G.nlon;
+    const double w = T.warea[i];
+    const bool anypos = sel_state[0] > 0;                    // np.any(pos > 0)
+    const double scale = qd_max(*scale_p, 1e-12);
+    double s_num = 0.0, s_den = 0.0;
+    for (int j = threadIdx.x; j < G.nlon; j += QD_BLOCK) {
+        const double div = qd_divvort_point(G, T, u, v, i, j, a, dlat, dlon, 0);
+        const double pos = qd_max(0.0, -(div - D_crit));
+        const double F_div = anypos ? qd_clip(pos / scale, 0.0, 5.0) : 0.0;
+        const double Pq = qd_max(0.0, pcond[b + j]);
+        const double F = (1.0 + beta * F_div) * 1.0;          // F_orog = 1.0 (QD_OROG off)
+        const double pr = Pq * F;
+        praw[b + j] = pr;
+        pos_out[b + j] = pos;
+        s_num += Pq * w;
+        s_den += pr * w;
+    }
+    s_num = qd_wsum(s_num); s_den = qd_wsum(s_den);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { sm[0][wv] = s_num; sm[1][wv] = s_den; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < QD_BLOCK / 64; ++k) { s_num += sm[0][k]; s_den += sm[1][k]; }
+        partial[blockIdx.y] = s_num;
+        partial[gridDim.y + blockIdx.y] = s_den;
+    }
+}
+
+// s = num/den (renorm), Pq_mean = num / wsum; out[0] = s, out[1] = blend weight of the legacy field
+__global__ void __launch_bounds__(QD_BLOCK)
+k_precip_scalars(const double* __restrict__ partial, int n, double wsum, double pq_min, double p_blend, int use_fb,
+                 double* __restrict__ out) {
+    __shared__ double sm[2][QD_BLOCK / 64];
+    double a = 0.0, b = 0.0;
+    for (int k = threadIdx.x; k < n; k += QD_BLOCK) { a += partial[k]; b += partial[n + k]; }
+    a = qd_wsum(a); b = qd_wsum(b);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { sm[0][wv] = a; sm[1][wv] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < QD_BLOCK / 64; ++k) { a += sm[0][k]; b += sm[1][k]; }
+        const double den = b + 1e-20;
+        out[0] = den > 0 ? a / den : 1.0;
+        const double pq_mean = a / (wsum + 1e-15);
+        out[1] = (use_fb && pq_mean < pq_min) ? p_blend : 0.0;
+    }
+}
+
+__global__ void __launch_bounds__(QD_BLOCK)
+k_scale_field(QdGeom G, const double* __restrict__ in, const double* __restrict__ s, double k, double* __restrict__ out) {
+    const QdTile tl = qd_tile();
+    const int j = tl.seg * QD_BLOCK + threadIdx.x;
+    if (j >= G.nlon) return;
+    const size_t o = (size_t)qd_lrow(G, G.row0 + tl.row) * G.nlon + j;
+    out[o] = s ? in[o] * (*s) : k * in[o];
+}
+
+__global__ void __launch_bounds__(QD_BLOCK)
+k_precip_blend(QdGeom G, const double* __restrict__ P, const double* __restrict__ Pdyn, const double* __restrict__ sc,
+               double* __restrict__ out) {
+    const QdTile tl = qd_tile();
+    const int j = tl.seg * QD_BLOCK + threadIdx.x;
+    if (j >= G.nlon) return;
+    const size_t o = (size_t)qd_lrow(G, G.row0 + tl.row) * G.nlon + j;
+    const double al = sc[1];
+    double p = P[o];
+    if (al != 0.0) p = (1.0 - al) * p + al * Pdyn[o];
+    out[o] = qd_max(p, 0.0);                                  // np.clip(P, 0, None)
+}
+
+__global__ void __launch_bounds__(QD_BLOCK)
+k_cloud_from_p(QdGeom G, const double* __restrict__ precip, const double* __restrict__ pref, double cmax,
+               double* __restrict__ out) {
+    const QdTile tl = qd_tile();
+    const int j = tl.seg * QD_BLOCK + threadIdx.x;
+    if (j >= G.nlon) return;
+    const size_t o = (size_t)qd_lrow(G, G.row0 + tl.row) * G.nlon + j;
+    out[o] = cmax * tanh(precip[o] / (*pref + 1e-12));
+}
+
+__global__ void __launch_bounds__(QD_BLOCK)
+k_clip01(QdGeom G, double* __restrict__ x) {
+    const QdTile tl = qd_tile();
+    const int j = tl.seg * QD_BLOCK + threadIdx.x;
+    if (j >= G.nlon) return;
+    const size_t o = (size_t)qd_lrow(G, G.row0 + tl.row) * G.nlon + j;
+    x[o] = qd_clip(x[o], 0.0, 1.0);
+}
+
+// physics.py:72-109 before the blur
+__global__ void __launch_bounds__(QD_BLOCK)
+k_cloud_source(QdGeom G, QdTabs T, const double* __restrict__ u, const double* __restrict__ v,
+               const double* __restrict__ Ts, double a, double dlat, double dlon, double* __restrict__ out) {
+    const QdTile tl = qd_tile();
+    const int j = tl.seg * QD_BLOCK + threadIdx.x;
+    if (j >= G.nlon) return;
+    const int i = G.row0 + tl.row;
+    const size_t b = (size_t)qd_lrow(G, i) * G.nlon;
+    const size_t o = b + j;
+    const double T0 = Ts[o];
+    double src = 0.0;
+    src = src + 0.5 * qd_clip(tanh((T0 - 285.0) / 12.0), 0.0, 1.0);
+    const double vort = qd_divvort_point(G, T, v, u, i, j, a, dlat, dlon, 1);
+    const double rel = vort / (T.fcor[i] + 1e-12);
+    src = src + 0.4 * qd_clip(tanh((rel - 0.5) / 2.0), 0.0, 1.0);
+    const double dx = dlon * a * T.cos6[i];
+    const double dy = dlat * a;
+    const int jp = qd_wrapc(j + 1, G.nlon), jm = qd_wrapc(j - 1, G.nlon);
+    const double gx = (Ts[b + jp] - Ts[b + jm]) / (2 * dx);
+    const double gy = (Ts[(size_t)qd_lrow(G, i + 1) * G.nlon + j] - Ts[(size_t)qd_lrow(G, i - 1) * G.nlon + j]) / (2 * dy);
+    const double tadv = -(u[o] * gx + v[o] * gy);
+    src = src + 0.3 * qd_clip(tanh(fabs(tadv) / 2e-5), 0.0, 1.0);
+    out[o] = src;
+}
+
+struct QdBlendP { double w_mem, w_p, w_src, tend, c_floor; };
+
+__global__ void __launch_bounds__(QD_BLOCK)
+k_cloud_blend(QdGeom G, QdBlendP P, const double* __restrict__ cfp, const double* __restrict__ src,
+              double* __restrict__ cloud) {
+    const QdTile tl = qd_tile();
+    const int j = tl.seg * QD_BLOCK + threadIdx.x;
+    if (j >= G.nlon) return;
+    const size_t o = (size_t)qd_lrow(G, G.row0 + tl.row) * G.nlon + j;
+    const double c0 = cloud[o], cp = cfp[o];
+    const double tendency = src[o] * P.tend;
+    double c = (P.w_mem * c0 + P.w_p * cp + P.w_src * qd_clip(c0 + tendency, 0.0, 1.0));
+    if (P.c_floor > 0.0) c = qd_max(c, qd_clip(P.c_floor * cp, 0.0, 1.0));
+    cloud[o] = qd_clip(c, 0.0, 1.0);
+}
+
+struct QdAlbP { double alpha, hice_ref_safe, alpha_ice, alpha_cloud, alpha_water; int do_adv, use_topo; };
+
+// cloud <- clip((1-a) cloud + a adv, 0, 1)  and  the dynamic albedo (physics.py:164-250)
+__global__ void __launch_bounds__(QD_BLOCK)
+k_cloud_albedo(QdGeom G, QdAlbP P, const double* __restrict__ adv, double* __restrict__ cloud,
+               const double* __restrict__ cloud_eff, const double* __restrict__ hice,
+               const double* __restrict__ base, const uint8_t* __restrict__ land, double* __restrict__ albedo) {
+    const QdTile tl = qd_tile();
+    const int j = tl.seg * QD_BLOCK + threadIdx.x;
+    if (j >= G.nlon) return;
+    const size_t o = (size_t)qd_lrow(G, G.row0 + tl.row) * G.nlon + j;
+    double c = cloud[o];
+    if (P.do_adv) { c = qd_clip((1.0 - P.alpha) * c + P.alpha * adv[o], 0.0, 1.0); cloud[o] = c; }
+    const double crad = cloud_eff ? cloud_eff[o] : c;
+    const double C = qd_clip(crad, 0.0, 1.0);
+    const double ice_frac = 1.0 - exp(-qd_max(hice[o], 0.0) / P.hice_ref_safe);
+    double fi = qd_clip(ice_frac, 0.0, 1.0);
+    fi = fi * ((land[o] == 0) ? 1.0 : 0.0);
+    const double b0 = P.use_topo ? base[o] : P.alpha_water;
+    const double surf = b0 * (1.0 - fi) + P.alpha_ice * fi;
+    albedo[o] = qd_clip(surf * (1.0 - C) + P.alpha_cloud * C, 0.0, 1.0);
+}
+
 int qd_driver_physics_impl(qd_ctx* c, double dt) {
-    (void)dt;
-    return qd_fail(c, "qd_driver_physics: not built yet");
+    const qd_params& p = c->p;
+    const QdGeom& G = c->geo;
+    const dim3 grid = qd_grid2d(G), blk(QD_BLOCK), rows(1, G.nrows);
+    auto isset = [](double x) { return !(x != x); };
+    double* praw = qd_scratch(c, 4);
+    double* pos = qd_scratch(c, 5);
+    double* tmp = qd_scratch(c, 6);
+    double* pdyn = qd_scratch(c, 7);
+    double* cfp = c->f[QD_F_CLOUD_FROM_P];
+    double* src = c->f[QD_F_CLOUD_SRC];
+    double* precip = c->f[QD_F_PRECIP];
+    {
+        QdScope sc(c, "phys_precip");
+        // median of pos = max(0, -(div - D_crit)) over pos > 0, straight from the divergence field
+        qd_launch_divvort(c, c->f[QD_F_U], c->f[QD_F_V], tmp, 0);
+        qd_median_positive_dev(c, tmp, 1e-12, QD_S_PSCALE, 1, p.D_crit);
+        hipLaunchKernelGGL(k_precip_raw, rows, blk, 0, c->stream, G, c->tabs, c->f[QD_F_U], c->f[QD_F_V], c->f[QD_F_PCOND],
+                           p.a, c->dlat, c->dlon, p.D_crit, p.p_betadiv, c->dscal + QD_S_PSCALE, c->sel_state, praw, pos,
+                           c->red_partial);
+        hipLaunchKernelGGL(k_precip_scalars, dim3(1), blk, 0, c->stream, c->red_partial, G.nrows, c->wsum_all, p.pq_min,
+                           p.p_blend, p.p_hybrid_fallback, c->dscal + QD_S_RENORM);
+        // P = gaussian(P_raw * s); P_dyn = gaussian(k_precip * pos)
+        hipLaunchKernelGGL(k_scale_field, grid, blk, 0, c->stream, G, praw, c->dscal + QD_S_RENORM, 0.0, praw);
+        if (qd_gaussian(c, praw, praw, tmp, 1.0, 0)) return -1;
+        hipLaunchKernelGGL(k_scale_field, grid, blk, 0, c->stream, G, pos, (const double*)nullptr, p.k_precip, pdyn);
+        if (qd_gaussian(c, pdyn, pdyn, tmp, 1.0, 0)) return -1;
+        hipLaunchKernelGGL(k_precip_blend, grid, blk, 0, c->stream, G, praw, pdyn, c->dscal + QD_S_RENORM, precip);
+    }
+    {
+        QdScope sc(c, "phys_cloud");
+        if (isset(p.pref) && p.pref != 0.0) {
+            hipMemcpyAsync(c->dscal + QD_S_MED_OUT, &p.pref, sizeof(double), hipMemcpyHostToDevice, c->stream);
+        } else {
+            qd_median_positive_dev(c, precip, 1e-6, QD_S_MED_OUT, 0, 0.0);
+        }
+        hipLaunchKernelGGL(k_cloud_from_p, grid, blk, 0, c->stream, G, precip, c->dscal + QD_S_MED_OUT, p.cmax, cfp);
+        if (qd_gaussian(c, cfp, cfp, tmp, 1.0, 0)) return -1;
+        hipLaunchKernelGGL(k_clip01, grid, blk, 0, c->stream, G, cfp);
+        hipLaunchKernelGGL(k_cloud_source, grid, blk, 0, c->stream, G, c->tabs, c->f[QD_F_U], c->f[QD_F_V], c->f[QD_F_TS],
+                           p.a, c->dlat, c->dlon, src);
+        if (qd_gaussian(c, src, src, tmp, 1.0, 0)) return -1;
+        hipLaunchKernelGGL(k_clip01, grid, blk, 0, c->stream, G, src);
+        double wm = p.w_mem, wp = p.w_p, ws = p.w_src, wsum = wm + wp + ws;
+        if (wsum <= 0) { wm = 0.5; wp = 0.4; ws = 0.1; wsum = 1.0; }
+        wm /= wsum; wp /= wsum; ws /= wsum;
+        QdBlendP B{wm, wp, ws, dt / (6 * 3600), p.cloud_from_p_floor};
+        hipLaunchKernelGGL(k_cloud_blend, grid, blk, 0, c->stream, G, B, cfp, src, c->f[QD_F_CLOUD]);
+    }
+    {
+        QdScope sc(c, "phys_albedo");
+        double* adv = qd_scratch(c, 7);
+        if (p.cloud_advect) {
+            qd_launch_advect(c, c->f[QD_F_U], c->f[QD_F_V], c->tabs.cos05, dt, c->f[QD_F_CLOUD], adv, nullptr, nullptr, 1.0, 0);
+            if (p.cloud_smooth_sigma > 0.0) { if (qd_gaussian(c, adv, adv, tmp, p.cloud_smooth_sigma, 1)) return -1; }
+        }
+        QdAlbP A{p.cloud_adv_alpha, std::max(1e-6, p.hice_ref), p.alpha_ice, p.alpha_cloud, p.alpha_water,
+                 p.cloud_advect ? 1 : 0, p.use_topo_albedo ? 1 : 0};
+        hipLaunchKernelGGL(k_cloud_albedo, grid, blk, 0, c->stream, G, A, adv, c->f[QD_F_CLOUD],
+                           c->cloud_eff_valid ? c->f[QD_F_CLOUD_EFF] : (const double*)nullptr, c->f[QD_F_HICE],
+                           c->f[QD_F_BASE_ALBEDO], c->land, c->f[QD_F_ALBEDO]);
+    }
+    return 0;
 }

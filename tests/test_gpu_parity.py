@@ -124,3 +124,39 @@ def test_forcing_vs_reference(gpu):
         assert relerr(a_, d[f"ref_isrA_{j}"]) < 1e-12 and relerr(b_, d[f"ref_isrB_{j}"]) < 1e-12
         Teq = f.calculate_equilibrium_temp(t, d["ref_albedo"])
         assert relerr(Teq, d[f"ref_Teq_{j}"]) < 1e-12
+
+
+@pytest.mark.parametrize("shape", [(19, 36), (37, 72)])
+def test_driver_physics_vs_reference(gpu, shape):
+    """run_simulation.py:1766-1934 + 2063-2146 (hybrid precipitation, cloud diagnostics, cloud tracer
+    advection, dynamic albedo) interleaved with time_step(Teq, dt) the way the driver calls it."""
+    import qingdai_amd as qa
+    meta, d = load_golden(f"driverphys_{shape[0]}x{shape[1]}")
+    nlat, nlon = shape
+    _, mask, alb, fric = surface(nlat, nlon)
+    grid = qa.SphericalGrid(nlat, nlon)
+    Cs_ocean = 1000.0 * 4200.0 * 50.0
+    m = qa.SpectralModel(grid, fric, H=8000, tau_rad=10 * 24 * 3600, greenhouse_factor=0.40,
+                         C_s_map=np.where(mask == 1, 3e6, Cs_ocean).astype(float), land_mask=mask,
+                         Cs_ocean=Cs_ocean, Cs_land=3e6, Cs_ice=5e6, params=qa.QdParams())
+    for k in STATE:
+        setattr(m, k, d["init_" + k].copy())
+    m._dev.upload_now("BASE_ALBEDO", alb)
+    forcing = qa.ThermalForcing(grid, qa.OrbitalSystem())
+    dt = meta["dt"]
+    for i in range(meta["nsteps"]):
+        m._dev.driver_physics(dt)
+        if i == 0:
+            e0 = {k: relerr(m._dev.get(f), d["s1_" + k]) for k, f in (("precip", "PRECIP"), ("albedo", "ALBEDO"),
+                                                                       ("C_from_P", "CLOUD_FROM_P"), ("src", "CLOUD_SRC"))}
+            print("step-1 diagnostics", e0)
+            for k, e in e0.items():
+                assert e < 1e-11, (k, e)
+        forcing.update_device(i * dt, with_teq=True)
+        m.time_step(None, dt)
+    errs = {k: relerr(getattr(m, k), d["ref_" + k]) for k in STATE}
+    errs["precip"] = relerr(m._dev.get("PRECIP"), d["ref_precip_last"])
+    errs["albedo"] = relerr(m._dev.get("ALBEDO"), d["ref_albedo_last"])
+    print(errs)
+    for k, e in errs.items():
+        assert e < STEP_TOL, (k, e)
