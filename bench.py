@@ -130,6 +130,7 @@ def main():
     ap.add_argument("--nlat", type=int, default=721)
     ap.add_argument("--nlon", type=int, default=1440)
     ap.add_argument("--no-ocean", action="store_true")
+    ap.add_argument("--no-driver-physics", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--profile-kernel", default="k_hyper_apply")
@@ -144,6 +145,7 @@ def main():
         raise SystemExit("multi-GPU latitude-band path is not wired into bench.py yet (see DESIGN.md)")
 
     with_ocean = not args.no_ocean
+    with_phys = not args.no_driver_physics
     dt = 300.0
     grid, m, oc, forcing, mask, base_albedo, friction = build_case(args.nlat, args.nlon, with_ocean, device=local_rank)
     dev = m._dev
@@ -152,11 +154,11 @@ def main():
     stars_k = forcing.star_table([(W + i) * dt for i in range(K)])
 
     if W > 0:
-        dev.step_n(stars_w, dt, with_ocean=with_ocean, pass_albedo=True)
+        dev.step_n(stars_w, dt, with_ocean=with_ocean, with_physics=with_phys, pass_albedo=True)
     dev.sync()
     dev.timing(select=args.profile_kernel)
     t0 = time.perf_counter()
-    dev.step_n(stars_k, dt, with_ocean=with_ocean, pass_albedo=True)
+    dev.step_n(stars_k, dt, with_ocean=with_ocean, with_physics=with_phys, pass_albedo=True)
     dev.sync()
     el = time.perf_counter() - t0
     kern_ms, kern_n = dev.timing_get(args.profile_kernel)
@@ -173,8 +175,8 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{args.nlat}x{args.nlon} seed-42 planet, dt=300 s: forcing + time_step(Teq, dt, albedo) "
                                f"with QD_ENERGY_W=1 QD_CLOUD_COUPLE=1" + (" + slab-ocean coupling" if with_ocean else "") +
-                               " (benchmark_jax.py:124-158 loop; BASELINE configs[2] without the driver-side "
-                               "precipitation/cloud diagnostics)",
+                               (" + driver-side precipitation/cloud/albedo diagnostics (run_simulation.py:1766-1934,2063-2146)" if with_phys else "") +
+                               " (BASELINE configs[2]; loop order of benchmark_jax.py:124-158)",
                    "grid": [args.nlat, args.nlon], "dt_s": dt, "ocean_n_sub": dev.last_ocean_nsub() if with_ocean else 0,
                    "parallelism": f"lat-bands x{args.gpus}"},
         "roofline": {"bound": "hbm", "kernel": args.profile_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,

@@ -238,6 +238,8 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
     if ((e = hipMalloc(&c->sel_state, 8 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
     hipMemsetAsync(c->dscal, 0, QD_S_COUNT * sizeof(double), c->stream);
     hipMemsetAsync(c->dcount, 0, 8 * sizeof(unsigned long long), c->stream);
+    hipMemsetAsync(c->hist, 0, 2 * QD_HIST_BINS * sizeof(unsigned int), c->stream);
+    hipMemsetAsync(c->sel_state, 0, 8 * sizeof(unsigned long long), c->stream);
     if ((e = hipHostMalloc((void**)&c->hpin, 64 * sizeof(double))) != hipSuccess) return bail("hipHostMalloc", e);
     // reference initial state
     const double q0 = std::min(std::max(q_init_rh, 0.0), 1.0) * host_qsat(288.0, params->p0);

@@ -62,11 +62,7 @@ k_column(QdGeom G, QdColP P, QdColPtrs A) {
         LHrel = P.L_v * Pc;
         q = qd_clip(qd_nn(q_next), 0.0, 0.5);
         A.q[o] = q; A.E[o] = E; A.Pcond[o] = Pc; A.LH[o] = LH; A.LHrel[o] = LHrel;
-        if (PHASE == 1) {
-            const unsigned long long m = __ballot(Pc > 0.0);
-            if ((threadIdx.x & 63) == 0 && m) atomicAdd(A.npos, (unsigned long long)__popcll(m));
-            return;
-        }
+        if (PHASE == 1) return;
     } else {
         q = A.q[o]; E = A.E[o]; Pc = A.Pcond[o]; LH = A.LH[o]; LHrel = A.LHrel[o];
     }

@@ -40,6 +40,20 @@ __device__ __forceinline__ double qd_lap_point(const double* __restrict__ F, con
 }
 
 
+// Reciprocal-table form of the same Laplacian for interior rows (2 <= i <= n-3); the two rows next to
+// each pole fall back to the literal form above.  k: cos-floor kind (0: 0.2, 1: 0.5).
+template <bool SCRUB>
+__device__ __forceinline__ double qd_lap_point_fast(const double* __restrict__ F, const QdGeom& G, const QdTabs& T,
+                                                    int k, int i, int j, double dphi, double dlam, double a) {
+    if (i < 2 || i > G.nlat - 3) return qd_lap_point<SCRUB>(F, G, k ? T.cos05 : T.cos02, i, j, dphi, dlam, a);
+    const int jp = qd_wrapc(j + 1, G.nlon), jm = qd_wrapc(j - 1, G.nlon);
+    const double cc = qd_ld<SCRUB>(F, G, i, j);
+    const double Gb = T.lapA[k][i + 1] * (qd_ld<SCRUB>(F, G, i + 2, j) - cc);
+    const double Ga = T.lapA[k][i - 1] * (cc - qd_ld<SCRUB>(F, G, i - 2, j));
+    const double d2 = (qd_ld<SCRUB>(F, G, i, jp) - 2.0 * cc) + qd_ld<SCRUB>(F, G, i, jm);
+    return T.lapP[k][i] * (Gb - Ga) + T.lapQ[k][i] * d2;
+}
+
 // ------------------------------------------------------------------ semi-Lagrangian gather (O5)
 __device__ __forceinline__ double qd_fold(double x, int n) {
     // scipy.ndimage map_coordinates(mode='wrap'): period n-1

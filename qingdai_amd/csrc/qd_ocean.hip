@@ -247,6 +247,52 @@ k_outlier(QdGeom G, const double* __restrict__ uo, const double* __restrict__ vo
     eta[o] = qd_clip(qd_nn(eta[o]), -eta_cap, eta_cap);
 }
 
+// ------------------------------------------------------------------ fused: SST diffusion + heating + outliers + caps
+// (ocean.py:385-444 in one pass; the fast Laplacian uses the reciprocal row tables)
+__global__ void __launch_bounds__(QD_BLOCK)
+k_sst_outlier_fused(QdGeom G, QdTabs T, double dlat, double dlon, double a, QdHeatP P,
+                    const double* __restrict__ Ts1, double* __restrict__ Ts_out, const double* __restrict__ qnet,
+                    const uint8_t* __restrict__ land, const uint8_t* __restrict__ ice,
+                    const double* __restrict__ uo, const double* __restrict__ vo, double* __restrict__ uo_out,
+                    double* __restrict__ vo_out, double* __restrict__ eta, double cap, double eta_cap, int mean4) {
+    const QdTile tl = qd_tile();
+    const int j = tl.seg * QD_BLOCK + threadIdx.x;
+    if (j >= G.nlon) return;
+    const int i = G.row0 + tl.row;
+    const size_t b = (size_t)qd_lrow(G, i) * G.nlon;
+    const size_t o = b + j;
+    double Tv = Ts1[o];
+    if (P.K_h > 0.0) Tv = Tv + P.sub_dt * P.K_h * qd_lap_point_fast<true>(Ts1, G, T, 1, i, j, dlat, dlon, a);
+    if (P.use_q) {
+        const double heat = qnet[o] / P.rcH;
+        const bool ocean = land[o] == 0;
+        if (P.has_ice) {
+            const bool ic = ice[o] != 0;
+            if (ocean && !ic) Tv = Tv + P.sub_dt * heat;
+            if (P.ice_qfac > 0.0 && ocean && ic) Tv = Tv + P.sub_dt * P.ice_qfac * heat;
+        } else if (ocean) Tv = Tv + P.sub_dt * heat;
+    }
+    Ts_out[o] = qd_nn(Tv);
+    double u = qd_nn(uo[o]), v = qd_nn(vo[o]);
+    const double speed = sqrt(u * u + v * v);
+    if (mean4) {
+        if (speed > cap) {
+            const size_t bn = (size_t)qd_lrow(G, i + 1) * G.nlon, bs = (size_t)qd_lrow(G, i - 1) * G.nlon;
+            const int je = qd_wrapc(j + 1, G.nlon), jw = qd_wrapc(j - 1, G.nlon);
+            u = 0.25 * (qd_nn(uo[bn + j]) + qd_nn(uo[bs + j]) + qd_nn(uo[b + je]) + qd_nn(uo[b + jw]));
+            v = 0.25 * (qd_nn(vo[bn + j]) + qd_nn(vo[bs + j]) + qd_nn(vo[b + je]) + qd_nn(vo[b + jw]));
+        }
+        const double sp2 = sqrt(u * u + v * v);
+        const double sc2 = (sp2 > cap) ? cap / (sp2 + 1e-12) : 1.0;
+        u = u * sc2; v = v * sc2;
+    } else {
+        const double sc = (speed > cap) ? cap / (speed + 1e-12) : 1.0;
+        u = u * sc; v = v * sc;
+    }
+    uo_out[o] = u; vo_out[o] = v;
+    eta[o] = qd_clip(qd_nn(eta[o]), -eta_cap, eta_cap);
+}
+
 // ------------------------------------------------------------------ polar ring fills: ocean.py:197-262
 // one workgroup per pole row; fixed-order tree sums (deterministic)
 __device__ __forceinline__ double qd_block_sum_ocn(double x, double* sm) {
@@ -409,11 +455,19 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
                                c->f[QD_F_UO], c->f[QD_F_VO], c->f[QD_F_SST], T1, p.ocean_adv_alpha, c->f[QD_F_ETA],
                                c->dscal + QD_S_ETA_MEAN, c->wsum_ocean > 0.0 ? 1 : 0);
             double* T2 = qd_scratch(c, 1);
-            hipLaunchKernelGGL(k_sst_diffuse_heat, grid, blk, 0, c->stream, G, c->tabs.cos05, c->dlat, c->dlon, p.a, HP,
-                               T1, T2, c->f[QD_F_QNET], c->land, c->icemask);
-            qd_swap(c, QD_F_SST, 1);
+            if (c->use_fused) {
+                double* u2 = qd_scratch(c, 2); double* v2 = qd_scratch(c, 3);
+                hipLaunchKernelGGL(k_sst_outlier_fused, grid, blk, 0, c->stream, G, c->tabs, c->dlat, c->dlon, p.a, HP, T1, T2,
+                                   c->f[QD_F_QNET], c->land, c->icemask, c->f[QD_F_UO], c->f[QD_F_VO], u2, v2,
+                                   c->f[QD_F_ETA], p.ocean_max_u, p.eta_cap, p.ocean_outlier == 0 ? 1 : 0);
+                qd_swap(c, QD_F_SST, 1); qd_swap(c, QD_F_UO, 2); qd_swap(c, QD_F_VO, 3);
+            } else {
+                hipLaunchKernelGGL(k_sst_diffuse_heat, grid, blk, 0, c->stream, G, c->tabs.cos05, c->dlat, c->dlon, p.a, HP,
+                                   T1, T2, c->f[QD_F_QNET], c->land, c->icemask);
+                qd_swap(c, QD_F_SST, 1);
+            }
         }
-        {
+        if (!c->use_fused) {
             QdScope sc(c, "ocean_outlier");
             double* u2 = qd_scratch(c, 2); double* v2 = qd_scratch(c, 3);
             hipLaunchKernelGGL(k_outlier, grid, blk, 0, c->stream, G, c->f[QD_F_UO], c->f[QD_F_VO], u2, v2,

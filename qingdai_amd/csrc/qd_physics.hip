@@ -201,7 +201,7 @@ int qd_driver_physics_impl(qd_ctx* c, double dt) {
         qd_launch_divvort(c, c->f[QD_F_U], c->f[QD_F_V], tmp, 0);
         qd_median_positive_dev(c, tmp, 1e-12, QD_S_PSCALE, 1, p.D_crit);
         hipLaunchKernelGGL(k_precip_raw, rows, blk, 0, c->stream, G, c->tabs, c->f[QD_F_U], c->f[QD_F_V], c->f[QD_F_PCOND],
-                           p.a, c->dlat, c->dlon, p.D_crit, p.p_betadiv, c->dscal + QD_S_PSCALE, c->sel_state, praw, pos,
+                           p.a, c->dlat, c->dlon, p.D_crit, p.p_betadiv, c->dscal + QD_S_PSCALE, c->dcount, praw, pos,
                            c->red_partial);
         hipLaunchKernelGGL(k_precip_scalars, dim3(1), blk, 0, c->stream, c->red_partial, G.nrows, c->wsum_all, p.pq_min,
                            p.p_blend, p.p_hybrid_fallback, c->dscal + QD_S_RENORM);

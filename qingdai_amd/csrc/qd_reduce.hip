@@ -98,55 +98,61 @@ __device__ __forceinline__ double qd_med_value(double x, int transform, double t
     return x;
 }
 
+// One pass = histogram of the next digit over the still-matching positive entries + (last workgroup
+// to finish, found with a ticket) the scan that extends the two prefixes.  Histogram counts reach
+// global memory through device-scope atomics; the last workgroup reads them back with agent-scope
+// atomic loads behind a fence, so no stale L1/L2 line can be observed (MI355X: per-XCD L2s are not
+// coherent for plain loads).  State and histogram are left zeroed for the next pass / next call.
+// sel_state: [0] count of positives, [1] prefix_lo, [2] rank_lo, [3] prefix_hi, [4] rank_hi, [6] ticket
 __global__ void __launch_bounds__(QD_BLOCK)
-k_sel_init(unsigned long long* st, unsigned int* hist) {
-    for (int k = threadIdx.x; k < 2 * QD_HIST_BINS; k += QD_BLOCK) hist[k] = 0u;
-    if (threadIdx.x < 8) st[threadIdx.x] = 0ull;
-}
-
-// pass: histogram the next 11-bit digit of every positive element whose resolved prefix
-// matches prefix_lo (hist 0) / prefix_hi (hist 1).  First pass also counts positives.
-__global__ void __launch_bounds__(QD_BLOCK)
-k_sel_hist(QdGeom G, const double* __restrict__ x, int transform, double tparam,
-           const unsigned long long* __restrict__ st, unsigned int* __restrict__ hist, int shift, int width,
-           int first) {
-    __shared__ unsigned int sh[2 * QD_HIST_BINS];
-    for (int k = threadIdx.x; k < 2 * QD_HIST_BINS; k += QD_BLOCK) sh[k] = 0u;
-    __syncthreads();
-    const unsigned long long plo = st[1], phi = st[3];
-    const int i = G.row0 + blockIdx.y;
-    const size_t b = (size_t)qd_lrow(G, i) * G.nlon;
-    for (int j = blockIdx.x * QD_BLOCK + threadIdx.x; j < G.nlon; j += gridDim.x * QD_BLOCK) {
-        const double v = qd_med_value(x[b + j], transform, tparam);
-        if (!(v > 0.0)) continue;
-        const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
-        const int up = shift + width;                    // bits above the current digit
-        const unsigned long long hi_bits = up >= 64 ? 0ull : (bits >> up);
-        const unsigned int digit = (unsigned int)((bits >> shift) & ((1u << width) - 1u));
-        if (first || hi_bits == (up >= 64 ? 0ull : (plo >> up))) atomicAdd(&sh[digit], 1u);
-        if (!first && plo != phi && hi_bits == (phi >> up)) atomicAdd(&sh[QD_HIST_BINS + digit], 1u);
-    }
-    __syncthreads();
-    for (int k = threadIdx.x; k < 2 * QD_HIST_BINS; k += QD_BLOCK) if (sh[k]) atomicAdd(&hist[k], sh[k]);
-}
-
-// single workgroup: locate the digit holding each target rank, extend the prefixes, clear hist.
-// Threads own 8 consecutive bins each; lane 0 / lane 1 walk the 256 chunk sums held in LDS for
-// the lower / upper middle rank.
-__global__ void __launch_bounds__(QD_BLOCK)
-k_sel_scan(unsigned long long* st, unsigned int* hist, int shift, int first) {
+k_sel_pass(QdGeom G, const double* __restrict__ x, int transform, double tparam, unsigned long long* st,
+           unsigned int* hist, int shift, int width, int first) {
     __shared__ unsigned int sh[2 * QD_HIST_BINS];
     __shared__ unsigned int csum[2][QD_BLOCK];
     __shared__ unsigned long long s_st[8];
+    __shared__ int s_last;
     const int t = threadIdx.x;
+    const unsigned long long n0 = __hip_atomic_load(&st[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!first && n0 == 0ull) return;                        // no positive entry: nothing to refine
+    for (int k = t; k < 2 * QD_HIST_BINS; k += QD_BLOCK) sh[k] = 0u;
+    const unsigned long long plo = __hip_atomic_load(&st[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long phi = __hip_atomic_load(&st[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int i = G.row0 + blockIdx.y;
+    const size_t b = (size_t)qd_lrow(G, i) * G.nlon;
+    const int up = shift + width;                            // bits above the current digit
+    for (int j = blockIdx.x * QD_BLOCK + t; j < G.nlon; j += gridDim.x * QD_BLOCK) {
+        const double v = qd_med_value(x[b + j], transform, tparam);
+        if (!(v > 0.0)) continue;
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+        const unsigned long long hi_bits = up >= 64 ? 0ull : (bits >> up);
+        const unsigned int digit = (unsigned int)((bits >> shift) & ((1u << width) - 1u));
+        if (first || hi_bits == (plo >> up)) atomicAdd(&sh[digit], 1u);
+        if (!first && plo != phi && hi_bits == (phi >> up)) atomicAdd(&sh[QD_HIST_BINS + digit], 1u);
+    }
+    __syncthreads();
+    // returning atomics: the wave cannot pass its s_waitcnt until every add has been performed at the
+    // memory side, so the ticket below is ordered after this workgroup's counts without a cache flush
+    unsigned int sink = 0u;
+    for (int k = t; k < 2 * QD_HIST_BINS; k += QD_BLOCK) if (sh[k]) sink += atomicAdd(&hist[k], sh[k]);
+    asm volatile("s_waitcnt vmcnt(0)" ::"v"(sink) : "memory");
+    __syncthreads();
+    if (t == 0) {
+        const unsigned long long ticket = atomicAdd(&st[6], 1ull);
+        s_last = (ticket == (unsigned long long)(gridDim.x * gridDim.y) - 1ull) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // ---- last workgroup: scan
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     const int per = QD_HIST_BINS / QD_BLOCK;
-    for (int k = t; k < 2 * QD_HIST_BINS; k += QD_BLOCK) sh[k] = hist[k];
-    if (t < 8) s_st[t] = st[t];
+    for (int k = t; k < 2 * QD_HIST_BINS; k += QD_BLOCK) sh[k] = __hip_atomic_load(&hist[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t < 8) s_st[t] = __hip_atomic_load(&st[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     for (int hsel = 0; hsel < 2; ++hsel) {
-        unsigned int s = 0;
-        for (int k = 0; k < per; ++k) s += sh[hsel * QD_HIST_BINS + t * per + k];
-        csum[hsel][t] = s;
+        unsigned int sacc = 0;
+        for (int k = 0; k < per; ++k) sacc += sh[hsel * QD_HIST_BINS + t * per + k];
+        csum[hsel][t] = sacc;
     }
     __syncthreads();
     if (t == 0 && first) {
@@ -168,39 +174,42 @@ k_sel_scan(unsigned long long* st, unsigned int* hist, int shift, int first) {
         int d = ch * per;
         for (; d < ch * per + per; ++d) { const unsigned int hv = sh[hsel * QD_HIST_BINS + d]; if (cum + hv > r) break; cum += hv; }
         if (d >= ch * per + per) d = ch * per + per - 1;
-        st[t == 0 ? 2 : 4] = r - cum;
-        st[t == 0 ? 1 : 3] = s_st[t == 0 ? 1 : 3] | ((unsigned long long)d << shift);
-        if (t == 0 && first) st[0] = s_st[0];
+        __hip_atomic_store(&st[t == 0 ? 2 : 4], r - cum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&st[t == 0 ? 1 : 3], s_st[t == 0 ? 1 : 3] | ((unsigned long long)d << shift), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (t == 0 && first && s_st[0] == 0) st[0] = 0;
-    __syncthreads();
-    for (int k = t; k < 2 * QD_HIST_BINS; k += QD_BLOCK) hist[k] = 0u;
+    if (t == 0) {
+        if (first) __hip_atomic_store(&st[0], s_st[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&st[6], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (int k = t; k < 2 * QD_HIST_BINS; k += QD_BLOCK) __hip_atomic_store(&hist[k], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ void k_sel_finish(const unsigned long long* st, double dflt, double* out) {
+// result + reset of the select state for the next call; `count_out` (optional) keeps the count
+__global__ void k_sel_finish(unsigned long long* st, double dflt, double* out, unsigned long long* count_out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        if (st[0] == 0) { *out = dflt; return; }
-        const double lo = __longlong_as_double((long long)st[1]);
-        const double hi = __longlong_as_double((long long)st[3]);
-        *out = (st[0] & 1ull) ? lo : (lo + hi) / 2.0;     // np.median: mean of the two middles
+        const unsigned long long n = st[0];
+        if (n == 0) *out = dflt;
+        else {
+            const double lo = __longlong_as_double((long long)st[1]);
+            const double hi = __longlong_as_double((long long)st[3]);
+            *out = (n & 1ull) ? lo : (lo + hi) / 2.0;     // np.median: mean of the two middles
+        }
+        if (count_out) *count_out = n;
+        for (int k = 0; k < 8; ++k) st[k] = 0ull;
     }
 }
 
 // median of the positive entries of x (after `transform`) -> device scalar slot; `dflt` if none
 int qd_median_positive_dev(qd_ctx* c, const double* x, double dflt, int slot, int transform, double tparam) {
     const QdGeom& G = c->geo;
-    hipLaunchKernelGGL(k_sel_init, dim3(1), dim3(QD_BLOCK), 0, c->stream, c->sel_state, c->hist);
     // digits from the top: bits 63..53, 52..42, 41..31, 30..20 (11 wide), 19..10, 9..0 (10 wide)
     const int shifts[6] = {53, 42, 31, 20, 10, 0};
     const int widths[6] = {11, 11, 11, 11, 10, 10};
     dim3 grid(1, G.nrows);
-    for (int p = 0; p < 6; ++p) {
-        const int shift = shifts[p];
-        hipLaunchKernelGGL(k_sel_hist, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam,
-                           c->sel_state, c->hist, shift, widths[p], p == 0 ? 1 : 0);
-        hipLaunchKernelGGL(k_sel_scan, dim3(1), dim3(QD_BLOCK), 0, c->stream, c->sel_state, c->hist, shift,
-                           p == 0 ? 1 : 0);
-    }
-    hipLaunchKernelGGL(k_sel_finish, dim3(1), dim3(64), 0, c->stream, c->sel_state, dflt, c->dscal + slot);
+    for (int p = 0; p < 6; ++p)
+        hipLaunchKernelGGL(k_sel_pass, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, c->sel_state, c->hist,
+                           shifts[p], widths[p], p == 0 ? 1 : 0);
+    hipLaunchKernelGGL(k_sel_finish, dim3(1), dim3(64), 0, c->stream, c->sel_state, dflt, c->dscal + slot, c->dcount);
     return 0;
 }
