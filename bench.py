@@ -103,25 +103,6 @@ def cpu_baseline(nlat, nlon, with_ocean, budget_s=20.0):
                       f"NumPy is single-threaded, {os.cpu_count()} host cores available"}
 
 
-def file_rendezvous(rank, world, payload=None, tag="id"):
-    """Single-node rendezvous without a network service: rank 0 publishes bytes in a file keyed by
-    the launcher's MASTER_PORT / run id, the others poll for it."""
-    key = f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'x')}_{tag}"
-    path = os.path.join("/tmp", f"qd_rdzv_{key}")
-    if rank == 0:
-        with open(path + ".tmp", "wb") as fh:
-            fh.write(payload)
-        os.replace(path + ".tmp", path)
-        return payload
-    t0 = time.time()
-    while not os.path.exists(path):
-        if time.time() - t0 > 120:
-            raise RuntimeError("rendezvous timeout")
-        time.sleep(0.01)
-    with open(path, "rb") as fh:
-        return fh.read()
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -139,34 +120,54 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world != 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if world > 1:
-        raise SystemExit("multi-GPU latitude-band path is not wired into bench.py yet (see DESIGN.md)")
+    if os.environ.get("QD_BENCH_ONE_DEVICE") == "1":     # rehearsal of the multi-rank flow on a 1-GPU box
+        local_rank = 0
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run / torchrun "
+                         f"(--nproc-per-node {args.gpus}); only the launcher's env vars are used, not torch")
 
     with_ocean = not args.no_ocean
     with_phys = not args.no_driver_physics
     dt = 300.0
-    grid, m, oc, forcing, mask, base_albedo, friction = build_case(args.nlat, args.nlon, with_ocean, device=local_rank)
+    band = None
+    if world > 1:
+        from qingdai_amd.bands import band_ranges, required_halo
+        r0, n = band_ranges(args.nlat, world)[rank]
+        band = (r0, n, required_halo(args.nlat, dt))
+    grid, m, oc, forcing, mask, base_albedo, friction = build_case(args.nlat, args.nlon, with_ocean, device=local_rank,
+                                                                   band=band, rank=rank, world=world)
     dev = m._dev
+    if world > 1:
+        from qingdai_amd.bands import init_rccl
+        init_rccl(dev, rank, world)
     K, W = args.steps, args.warmup
     stars_w = forcing.star_table([i * dt for i in range(W)])
     stars_k = forcing.star_table([(W + i) * dt for i in range(K)])
 
+    def barrier():
+        dev.sync()
+        if world > 1:
+            dev._chk(dev.lib.qd_comm_barrier(dev.h), "qd_comm_barrier")
+
     if W > 0:
         dev.step_n(stars_w, dt, with_ocean=with_ocean, with_physics=with_phys, pass_albedo=True)
-    dev.sync()
+    barrier()
     dev.timing(select=args.profile_kernel)
     t0 = time.perf_counter()
     dev.step_n(stars_k, dt, with_ocean=with_ocean, with_physics=with_phys, pass_albedo=True)
-    dev.sync()
+    barrier()
     el = time.perf_counter() - t0
+    if world > 1:                                  # MAX over ranks
+        import ctypes
+        v = (ctypes.c_double * 1)(el)
+        dev._chk(dev.lib.qd_comm_allreduce_max(dev.h, v, 1), "qd_comm_allreduce_max")
+        el = v[0]
     kern_ms, kern_n = dev.timing_get(args.profile_kernel)
     dev.timing(on=False)
 
     ms_per_step = el / K * 1e3
     value = (K * dt / PLANET_DAY_S) / el
-    cells = args.nlat * args.nlon
+    cells = (band[1] if band else args.nlat) * args.nlon     # cells one launch of this rank's kernel covers
     bpc = BYTES_PER_CELL.get(args.profile_kernel, 0.0)
     achieved = (bpc * cells / 1e9) / (kern_ms / 1e3) if kern_ms > 0 else 0.0
     out = {

@@ -159,6 +159,10 @@ int qd_reduce(qd_handle h, int field, int op, double* out);
 /* ---- multi-GPU: latitude bands, RCCL halo exchange ------------------ */
 int qd_comm_unique_id(void* id128, size_t bytes);                 /* rank 0: ncclGetUniqueId */
 int qd_comm_init(qd_handle h, const void* id128, size_t bytes);   /* all ranks: ncclCommInitRank */
+/* in-process group of band handles on ONE device, one host thread per handle: exercises the band
+ * logic (margins, ring halos, reductions) without RCCL; handles[] ordered by rank */
+int qd_comm_init_local(qd_handle* handles, int n);
+int qd_comm_stats(qd_handle h, int* halo_exchanges);
 int qd_comm_barrier(qd_handle h);
 int qd_comm_allreduce_max(qd_handle h, double* inout, int n);     /* bench timing: max over ranks */
 

@@ -210,7 +210,8 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
     qd_ctx* c = new qd_ctx();
     c->desc = *d; c->p = *params;
     { const char* ef = std::getenv("QD_FUSED"); if (ef && ef[0] == '0') c->use_fused = 0; }
-    c->geo = QdGeom{d->n_lat, d->n_lon, d->row0, d->n_rows, d->halo, full ? 1 : 0};
+    c->geo = QdGeom{d->n_lat, d->n_lon, d->row0, d->n_rows, d->halo, full ? 1 : 0, d->row0 - d->halo, d->n_rows + 2 * d->halo};
+    c->own_row0 = d->row0; c->own_nrows = d->n_rows;
     auto bail = [&](const char* w, hipError_t e) { qd_fail(nullptr, w, e); qd_destroy(c); return -1; };
     hipError_t e;
     if ((e = hipSetDevice(d->device)) != hipSuccess) return bail("hipSetDevice", e);
@@ -246,6 +247,11 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
     hipLaunchKernelGGL(k_init_state, dim3((d->n_lon + QD_BLOCK - 1) / QD_BLOCK, c->geo.lrows()), dim3(QD_BLOCK), 0,
                        c->stream, c->geo, c->tabs, params->H, q0, c->f[QD_F_H], c->f[QD_F_TS], c->f[QD_F_Q], c->f[QD_F_SST]);
     if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail("init", e);
+    if (!full) {
+        // a fresh handle is consistent everywhere: every field slab (and the masks) is valid on its whole halo
+        for (int f = 0; f < QD_F_COUNT_F64; ++f) c->vm[c->f[f]] = d->halo;
+        c->vm[c->land] = d->halo; c->vm[c->icemask] = d->halo;
+    }
     *out = c;
     return 0;
 }
@@ -296,10 +302,12 @@ extern "C" int qd_upload(qd_handle c, int field, const void* host, size_t bytes)
         if (bytes != n) return qd_fail(c, "qd_upload: mask size mismatch");
         uint8_t* dst = field == QD_F_LAND_MASK ? c->land : c->icemask;
         if (band_copy_in(c, dst, host, 1)) return qd_fail(c, "qd_upload: copy failed");
+        qd_mark(c, {dst}, c->geo.halo);
     } else {
         if (field < 0 || field >= QD_F_COUNT_F64) return qd_fail(c, "qd_upload: unknown field");
         if (bytes != n * sizeof(double)) return qd_fail(c, "qd_upload: size mismatch (expect n_lat*n_lon float64)");
         if (band_copy_in(c, c->f[field], host, sizeof(double))) return qd_fail(c, "qd_upload: copy failed");
+        qd_mark(c, {c->f[field]}, c->geo.halo);
         if (field == QD_F_CLOUD_EFF) c->cloud_eff_valid = 1;
     }
     QD_HIP(c, hipStreamSynchronize(c->stream));    // host buffer is only borrowed for the call
@@ -448,7 +456,7 @@ extern "C" int qd_op_laplacian(qd_handle c, const double* F, int cos_kind, doubl
     double* in = c->scratch[10];
     if (seam_in(c, in, F)) return -1;
     QdFieldList fl; fl.n = 1; fl.in[0] = in; fl.out[0] = c->scratch[11]; fl.aux[0] = nullptr; fl.k4row[0] = nullptr; fl.k4s[0] = 0;
-    qd_launch_laplacian(c, fl, cos_kind ? c->tabs.cos05 : c->tabs.cos02);
+    qd_launch_laplacian(c, fl, cos_kind ? c->tabs.cos05 : c->tabs.cos02, 0);
     return seam_out(c, c->scratch[11], out);
 }
 
@@ -470,7 +478,7 @@ extern "C" int qd_op_hyperdiffuse(qd_handle c, const double* F, const double* k4
     } else { ov = k4_scalar; skip = (k4_scalar > 0.0) ? 0 : 1; }
     double* fl[1] = {in};
     double* save10 = c->scratch[10];
-    qd_hyperdiffuse_fields(c, fl, 1, tab, &skip, &ov, dt, n_substeps, cos_kind ? c->tabs.cos05 : c->tabs.cos02);
+    qd_hyperdiffuse_fields(c, fl, 1, tab, &skip, &ov, dt, n_substeps, cos_kind ? c->tabs.cos05 : c->tabs.cos02, 0);
     int rc = seam_out(c, fl[0], out);
     // restore scratch bookkeeping: slot 10 must keep owning a distinct slab
     if (fl[0] != save10) { for (int s = 0; s < QD_NSCRATCH; ++s) if (c->scratch[s] == save10 && s != 10) { c->scratch[s] = fl[0]; break; } c->scratch[10] = save10; }
@@ -483,7 +491,7 @@ extern "C" int qd_op_advect(qd_handle c, const double* field, const double* u, c
     hipSetDevice(c->desc.device);
     if (seam_in(c, c->scratch[10], field) || seam_in(c, c->scratch[11], u) || seam_in(c, c->scratch[12], v)) return -1;
     qd_launch_advect(c, c->scratch[11], c->scratch[12], cos_kind ? c->tabs.cos05 : c->tabs.cos6, dt,
-                     c->scratch[10], c->scratch[13], nullptr, nullptr, 1.0, 0);
+                     c->scratch[10], c->scratch[13], nullptr, nullptr, 1.0, 0, 0);
     return seam_out(c, c->scratch[13], out);
 }
 
@@ -493,7 +501,7 @@ extern "C" int qd_op_shapiro(qd_handle c, const double* F, int n, double* out) {
     if (seam_in(c, c->scratch[10], F)) return -1;
     double* fl[1] = {c->scratch[10]};
     double* save10 = c->scratch[10];
-    qd_shapiro_fields(c, fl, 1, n);
+    qd_shapiro_fields(c, fl, 1, n, 0);
     int rc = seam_out(c, fl[0], out);
     if (fl[0] != save10) { for (int s = 0; s < QD_NSCRATCH; ++s) if (c->scratch[s] == save10 && s != 10) { c->scratch[s] = fl[0]; break; } c->scratch[10] = save10; }
     return rc;
@@ -503,7 +511,7 @@ static int seam_divvort(qd_ctx* c, const double* u, const double* v, double* out
     if (!c || !u || !v || !out) return -1;
     hipSetDevice(c->desc.device);
     if (seam_in(c, c->scratch[10], u) || seam_in(c, c->scratch[11], v)) return -1;
-    qd_launch_divvort(c, c->scratch[10], c->scratch[11], c->scratch[12], vort);
+    qd_launch_divvort(c, c->scratch[10], c->scratch[11], c->scratch[12], vort, 0);
     return seam_out(c, c->scratch[12], out);
 }
 extern "C" int qd_op_divergence(qd_handle c, const double* u, const double* v, double* out) { return seam_divvort(c, u, v, out, 0); }
@@ -513,7 +521,7 @@ extern "C" int qd_op_gaussian(qd_handle c, const double* F, double sigma, int mo
     if (!c || !F || !out) return -1;
     hipSetDevice(c->desc.device);
     if (seam_in(c, c->scratch[10], F)) return -1;
-    if (qd_gaussian(c, c->scratch[10], c->scratch[11], c->scratch[12], sigma, mode_wrap)) return -1;
+    if (qd_gaussian(c, c->scratch[10], c->scratch[11], c->scratch[12], sigma, mode_wrap, 0)) return -1;
     return seam_out(c, c->scratch[11], out);
 }
 

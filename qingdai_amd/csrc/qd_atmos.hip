@@ -242,9 +242,13 @@ int qd_forcing_impl(qd_ctx* c, const double* sa, const double* sb, double theta,
     QdScope sc(c, "forcing");
     QdStar A{sa[0], std::sin(sa[1]), std::cos(sa[1]), sa[2]};
     QdStar B{sb[0], std::sin(sb[1]), std::cos(sb[1]), sb[2]};
-    hipLaunchKernelGGL(k_forcing, qd_grid2d(c->geo), dim3(QD_BLOCK), 0, c->stream, c->geo, c->tabs, A, B, theta,
-                       5.670374e-8, with_teq, c->f[QD_F_ISR_A], c->f[QD_F_ISR_B], c->f[QD_F_ISR],
-                       c->f[QD_F_ALBEDO], c->f[QD_F_TEQ]);
+    const int m = with_teq ? qd_plan(c, {QD_IN(c->f[QD_F_ALBEDO], 0)}) : c->geo.halo;
+    if (m < 0) return -1;
+    QD_ROWS(c, m, G, hipLaunchKernelGGL(k_forcing, qd_grid2d(G), dim3(QD_BLOCK), 0, c->stream, G, c->tabs, A, B, theta,
+                                        5.670374e-8, with_teq, c->f[QD_F_ISR_A], c->f[QD_F_ISR_B], c->f[QD_F_ISR],
+                                        c->f[QD_F_ALBEDO], c->f[QD_F_TEQ]));
+    qd_mark(c, {c->f[QD_F_ISR_A], c->f[QD_F_ISR_B], c->f[QD_F_ISR]}, m);
+    if (with_teq) qd_mark(c, {c->f[QD_F_TEQ]}, m);
     return 0;
 }
 
@@ -259,8 +263,10 @@ k_simple_albedo(QdGeom G, const uint8_t* __restrict__ land, const double* __rest
 }
 
 int qd_simple_albedo_impl(qd_ctx* c, double ocean_albedo) {
-    hipLaunchKernelGGL(k_simple_albedo, qd_grid2d(c->geo), dim3(QD_BLOCK), 0, c->stream, c->geo, c->land,
-                       c->f[QD_F_BASE_ALBEDO], ocean_albedo, c->f[QD_F_ALBEDO]);
+    const int m = c->geo.full ? 0 : c->geo.halo;              // static inputs: valid on the whole slab
+    QD_ROWS(c, m, G, hipLaunchKernelGGL(k_simple_albedo, qd_grid2d(G), dim3(QD_BLOCK), 0, c->stream, G, c->land,
+                                        c->f[QD_F_BASE_ALBEDO], ocean_albedo, c->f[QD_F_ALBEDO]));
+    qd_mark(c, {c->f[QD_F_ALBEDO]}, m);
     return 0;
 }
 
@@ -306,33 +312,44 @@ __global__ void k_zero_count(unsigned long long* p) { if (threadIdx.x == 0 && bl
 
 int qd_atmos_step_impl(qd_ctx* c, double dt, int has_albedo) {
     const qd_params& p = c->p;
-    const QdGeom& G = c->geo;
-    const dim3 grid = qd_grid2d(G), blk(QD_BLOCK);
+    const QdGeom& G0 = c->geo;
+    const dim3 blk(QD_BLOCK);
+    double** F = c->f;
     if (p.spec_every > 0 && (p.filter_type == 0 || p.filter_type == 3))
         return qd_fail(c, "zonal-FFT filter (QD_SPEC_EVERY>0) is not available on the device path yet");
     QdColP P = qd_make_colp(c, dt);
-    QdColPtrs A;
-    A.u = c->f[QD_F_U]; A.v = c->f[QD_F_V]; A.Teq = c->f[QD_F_TEQ]; A.isr = c->f[QD_F_ISR];
-    A.albedo = c->f[QD_F_ALBEDO]; A.csmap = c->f[QD_F_CSMAP];
-    A.h = c->f[QD_F_H]; A.Ts = c->f[QD_F_TS]; A.q = c->f[QD_F_Q]; A.cloud = c->f[QD_F_CLOUD]; A.hice = c->f[QD_F_HICE];
-    A.E = c->f[QD_F_EFLUX]; A.Pcond = c->f[QD_F_PCOND]; A.LH = c->f[QD_F_LH]; A.LHrel = c->f[QD_F_LHREL];
-    A.olr = c->f[QD_F_OLR]; A.cloud_eff = c->f[QD_F_CLOUD_EFF];
-    A.land = c->land; A.pref = c->dscal + QD_S_PREF; A.npos = c->dcount;
+    const int R = qd_adv_reach(c, dt, 250.0);      // lat reach of the gather for |v| <= 250 m/s
 
     {
         QdScope sc(c, "column");
+        // pointwise: every input at radius 0
+        int m = has_albedo
+            ? qd_plan(c, {QD_IN(F[QD_F_U], 0), QD_IN(F[QD_F_V], 0), QD_IN(F[QD_F_H], 0), QD_IN(F[QD_F_TS], 0), QD_IN(F[QD_F_Q], 0),
+                          QD_IN(F[QD_F_CLOUD], 0), QD_IN(F[QD_F_HICE], 0), QD_IN(F[QD_F_TEQ], 0), QD_IN(F[QD_F_ISR], 0),
+                          QD_IN(F[QD_F_ALBEDO], 0)})
+            : qd_plan(c, {QD_IN(F[QD_F_U], 0), QD_IN(F[QD_F_V], 0), QD_IN(F[QD_F_H], 0), QD_IN(F[QD_F_TS], 0), QD_IN(F[QD_F_Q], 0),
+                          QD_IN(F[QD_F_HICE], 0), QD_IN(F[QD_F_TEQ], 0)});
+        if (m < 0) return -1;
+        QdColPtrs A;
+        A.u = F[QD_F_U]; A.v = F[QD_F_V]; A.Teq = F[QD_F_TEQ]; A.isr = F[QD_F_ISR];
+        A.albedo = F[QD_F_ALBEDO]; A.csmap = F[QD_F_CSMAP];
+        A.h = F[QD_F_H]; A.Ts = F[QD_F_TS]; A.q = F[QD_F_Q]; A.cloud = F[QD_F_CLOUD]; A.hice = F[QD_F_HICE];
+        A.E = F[QD_F_EFLUX]; A.Pcond = F[QD_F_PCOND]; A.LH = F[QD_F_LH]; A.LHrel = F[QD_F_LHREL];
+        A.olr = F[QD_F_OLR]; A.cloud_eff = F[QD_F_CLOUD_EFF];
+        A.land = c->land; A.pref = c->dscal + QD_S_PREF; A.npos = c->dcount;
         if (!has_albedo) {
-            hipLaunchKernelGGL((k_column<0, false>), grid, blk, 0, c->stream, G, P, A);
+            QD_ROWS(c, m, G, hipLaunchKernelGGL((k_column<0, false>), qd_grid2d(G), blk, 0, c->stream, G, P, A));
         } else if (!p.cloud_couple || qd_isset(p.pcond_ref)) {
             hipLaunchKernelGGL(k_set_scalar, dim3(1), dim3(1), 0, c->stream, c->dscal + QD_S_PREF,
                                qd_isset(p.pcond_ref) ? p.pcond_ref : 1e-6);
-            hipLaunchKernelGGL((k_column<0, true>), grid, blk, 0, c->stream, G, P, A);
+            QD_ROWS(c, m, G, hipLaunchKernelGGL((k_column<0, true>), qd_grid2d(G), blk, 0, c->stream, G, P, A));
         } else {
-            hipLaunchKernelGGL((k_column<1, true>), grid, blk, 0, c->stream, G, P, A);
-            qd_median_positive_dev(c, c->f[QD_F_PCOND], 1e-6, QD_S_PREF, 0, 0.0);
-            hipLaunchKernelGGL((k_column<2, true>), grid, blk, 0, c->stream, G, P, A);
+            QD_ROWS(c, m, G, hipLaunchKernelGGL((k_column<1, true>), qd_grid2d(G), blk, 0, c->stream, G, P, A));
+            if (qd_median_positive_dev(c, F[QD_F_PCOND], 1e-6, QD_S_PREF, 0, 0.0)) return -1;
+            QD_ROWS(c, m, G, hipLaunchKernelGGL((k_column<2, true>), qd_grid2d(G), blk, 0, c->stream, G, P, A));
         }
-        if (has_albedo) c->cloud_eff_valid = 1;
+        qd_mark(c, {F[QD_F_H], F[QD_F_TS], F[QD_F_Q], F[QD_F_EFLUX], F[QD_F_PCOND], F[QD_F_LH], F[QD_F_LHREL], F[QD_F_OLR]}, m);
+        if (has_albedo) { qd_mark(c, {F[QD_F_HICE], F[QD_F_CLOUD_EFF]}, m); c->cloud_eff_valid = 1; }
     }
     c->atm_counter += 1;
     const int64_t sc_ = c->atm_counter;
@@ -340,8 +357,10 @@ int qd_atmos_step_impl(qd_ctx* c, double dt, int has_albedo) {
     // T_s, q gather with the OLD winds (dynamics.py:454-461)
     {
         QdScope sc(c, "advect_tsq");
+        const int m = qd_plan(c, {QD_IN(F[QD_F_TS], R), QD_IN(F[QD_F_Q], R), QD_IN(F[QD_F_U], 0), QD_IN(F[QD_F_V], 0)});
+        if (m < 0) return -1;
         double* oT = qd_scratch(c, 0); double* oq = qd_scratch(c, 1);
-        qd_launch_advect(c, c->f[QD_F_U], c->f[QD_F_V], c->tabs.cos6, dt, c->f[QD_F_TS], oT, c->f[QD_F_Q], oq, 0.2, 1);
+        qd_launch_advect(c, F[QD_F_U], F[QD_F_V], c->tabs.cos6, dt, F[QD_F_TS], oT, F[QD_F_Q], oq, 0.2, 1, m);
         qd_swap(c, QD_F_TS, 0); qd_swap(c, QD_F_Q, 1);
     }
     // momentum (dynamics.py:482-530) + del^4 (dynamics.py:533-594)
@@ -352,63 +371,83 @@ int qd_atmos_step_impl(qd_ctx* c, double dt, int has_albedo) {
     const double ov[5] = {p.k4_u, p.k4_v, p.k4_h, p.k4_q, p.k4_cloud};
     if (do_diff && c->use_fused && p.k4_nsub == 1) {
         // one launch: u,v,h,friction,q,cloud in -> u,v,h,q,cloud out
+        const int m = qd_plan(c, {QD_IN(F[QD_F_H], 5), QD_IN(F[QD_F_U], 4), QD_IN(F[QD_F_V], 4), QD_IN(F[QD_F_FRICTION], 4),
+                                  QD_IN(F[QD_F_Q], 4), QD_IN(F[QD_F_CLOUD], 4)});
+        if (m < 0) return -1;
         QdDynArgs D;
-        D.u = c->f[QD_F_U]; D.v = c->f[QD_F_V]; D.h = c->f[QD_F_H]; D.fric = c->f[QD_F_FRICTION];
-        D.q = c->f[QD_F_Q]; D.cloud = c->f[QD_F_CLOUD];
+        D.u = F[QD_F_U]; D.v = F[QD_F_V]; D.h = F[QD_F_H]; D.fric = F[QD_F_FRICTION];
+        D.q = F[QD_F_Q]; D.cloud = F[QD_F_CLOUD];
         D.uo = qd_scratch(c, 0); D.vo = qd_scratch(c, 1); D.ho = qd_scratch(c, 2); D.qo = qd_scratch(c, 3); D.co = qd_scratch(c, 4);
         for (int f = 0; f < 5; ++f) {
             const bool sc1 = qd_isset(ov[f]);
-            D.k4row[f] = sc1 ? nullptr : c->k4_atm + (size_t)f * G.nlat;
+            D.k4row[f] = sc1 ? nullptr : c->k4_atm + (size_t)f * G0.nlat;
             D.k4s[f] = sc1 ? ov[f] : 0.0;
             D.skip[f] = c->k4_atm_skip[f];
         }
         D.g = p.g; D.a = p.a; D.dt = dt; D.dlat = c->dlat; D.dlon = c->dlon; D.f_min = f_min; D.primitive = p.mom_scheme == 1;
         D.inv_dlon = 1.0 / c->dlon; D.inv_2dlon = 1.0 / (2.0 * c->dlon); D.inv_dlat = 1.0 / c->dlat; D.inv_2dlat = 1.0 / (2.0 * c->dlat);
         D.pgf_y = -(p.g / p.a);
-        qd_launch_dyn_hyper(c, D);
+        if (qd_launch_dyn_hyper(c, D, m)) return -1;
+        qd_mark(c, {D.uo, D.vo, D.ho, D.qo, D.co}, m);
         qd_swap(c, QD_F_U, 0); qd_swap(c, QD_F_V, 1); qd_swap(c, QD_F_H, 2); qd_swap(c, QD_F_Q, 3); qd_swap(c, QD_F_CLOUD, 4);
     } else {
         {
             QdScope sc(c, "momentum");
+            const int m = qd_plan(c, {QD_IN(F[QD_F_H], 1), QD_IN(F[QD_F_U], 0), QD_IN(F[QD_F_V], 0), QD_IN(F[QD_F_FRICTION], 0)});
+            if (m < 0) return -1;
             QdMomP M;
             M.g = p.g; M.a = p.a; M.dt = dt; M.dlat = c->dlat; M.dlon = c->dlon; M.f_min = f_min;
             M.primitive = p.mom_scheme == 1;
-            hipLaunchKernelGGL(k_momentum, grid, blk, 0, c->stream, G, c->tabs, M, c->f[QD_F_H], c->f[QD_F_FRICTION],
-                               c->f[QD_F_U], c->f[QD_F_V]);
+            QD_ROWS(c, m, G, hipLaunchKernelGGL(k_momentum, qd_grid2d(G), blk, 0, c->stream, G, c->tabs, M, F[QD_F_H],
+                                                F[QD_F_FRICTION], F[QD_F_U], F[QD_F_V]));
+            qd_mark(c, {F[QD_F_U], F[QD_F_V]}, m);
         }
         if (do_diff) {
             QdScope sc(c, "hyperdiffusion");
-            double* fl[5] = {c->f[QD_F_U], c->f[QD_F_V], c->f[QD_F_H], c->f[QD_F_Q], c->f[QD_F_CLOUD]};
-            if (p.k4_nsub == 1) {
-                qd_hyperdiffuse_fields(c, fl, 5, c->k4_atm, c->k4_atm_skip, ov, dt, 1, c->tabs.cos02);
-            } else {
-                // u,v,h use QD_K4_NSUB sub-steps, q and cloud always one (dynamics.py:584-594)
-                int skip3[5] = {c->k4_atm_skip[0], c->k4_atm_skip[1], c->k4_atm_skip[2], 1, 1};
-                int skip2[5] = {1, 1, 1, c->k4_atm_skip[3], c->k4_atm_skip[4]};
-                qd_hyperdiffuse_fields(c, fl, 5, c->k4_atm, skip3, ov, dt, p.k4_nsub, c->tabs.cos02);
-                qd_hyperdiffuse_fields(c, fl, 5, c->k4_atm, skip2, ov, dt, 1, c->tabs.cos02);
-            }
-            c->f[QD_F_U] = fl[0]; c->f[QD_F_V] = fl[1]; c->f[QD_F_H] = fl[2]; c->f[QD_F_Q] = fl[3]; c->f[QD_F_CLOUD] = fl[4];
+            const int ns = std::max(1, p.k4_nsub);
+            const int m3 = qd_plan(c, {QD_IN(F[QD_F_U], 4 * ns), QD_IN(F[QD_F_V], 4 * ns), QD_IN(F[QD_F_H], 4 * ns)});
+            const int m2 = qd_plan(c, {QD_IN(F[QD_F_Q], 4), QD_IN(F[QD_F_CLOUD], 4)});
+            if (m3 < 0 || m2 < 0) return -1;
+            double* fl[5] = {F[QD_F_U], F[QD_F_V], F[QD_F_H], F[QD_F_Q], F[QD_F_CLOUD]};
+            // u,v,h use QD_K4_NSUB sub-steps, q and cloud always one (dynamics.py:584-594)
+            int skip3[5] = {c->k4_atm_skip[0], c->k4_atm_skip[1], c->k4_atm_skip[2], 1, 1};
+            int skip2[5] = {1, 1, 1, c->k4_atm_skip[3], c->k4_atm_skip[4]};
+            qd_hyperdiffuse_fields(c, fl, 5, c->k4_atm, skip3, ov, dt, ns, c->tabs.cos02, m3);
+            qd_hyperdiffuse_fields(c, fl, 5, c->k4_atm, skip2, ov, dt, 1, c->tabs.cos02, m2);
+            F[QD_F_U] = fl[0]; F[QD_F_V] = fl[1]; F[QD_F_H] = fl[2]; F[QD_F_Q] = fl[3]; F[QD_F_CLOUD] = fl[4];
         }
     }
     // Shapiro (dynamics.py:610-626): combo, shapiro AND hyper4 all trigger it
     if ((ft == 0 || ft == 1 || ft == 2) && p.shapiro_every > 0 && (sc_ % p.shapiro_every == 0)) {
         QdScope sc(c, "shapiro");
-        double* fl[3] = {c->f[QD_F_U], c->f[QD_F_V], c->f[QD_F_H]};
-        qd_shapiro_fields(c, fl, 3, p.shapiro_n);
-        c->f[QD_F_U] = fl[0]; c->f[QD_F_V] = fl[1]; c->f[QD_F_H] = fl[2];
+        const int np_ = std::max(1, p.shapiro_n);
+        const int m = qd_plan(c, {QD_IN(F[QD_F_U], np_), QD_IN(F[QD_F_V], np_), QD_IN(F[QD_F_H], np_)});
+        if (m < 0) return -1;
+        double* fl[3] = {F[QD_F_U], F[QD_F_V], F[QD_F_H]};
+        qd_shapiro_fields(c, fl, 3, np_, m);
+        F[QD_F_U] = fl[0]; F[QD_F_V] = fl[1]; F[QD_F_H] = fl[2];
         const int n1 = std::max(1, p.shapiro_n - 1);
-        if (p.diff_q) { double* g1[1] = {c->f[QD_F_Q]}; qd_shapiro_fields(c, g1, 1, n1); c->f[QD_F_Q] = g1[0]; }
-        if (p.diff_cloud) { double* g1[1] = {c->f[QD_F_CLOUD]}; qd_shapiro_fields(c, g1, 1, n1); c->f[QD_F_CLOUD] = g1[0]; }
+        if (p.diff_q) {
+            const int mq = qd_plan(c, {QD_IN(F[QD_F_Q], n1)}); if (mq < 0) return -1;
+            double* g1[1] = {F[QD_F_Q]}; qd_shapiro_fields(c, g1, 1, n1, mq); F[QD_F_Q] = g1[0];
+        }
+        if (p.diff_cloud) {
+            const int mc = qd_plan(c, {QD_IN(F[QD_F_CLOUD], n1)}); if (mc < 0) return -1;
+            double* g1[1] = {F[QD_F_CLOUD]}; qd_shapiro_fields(c, g1, 1, n1, mc); F[QD_F_CLOUD] = g1[0];
+        }
     }
     // cloud gather + decay + damp + scrub (dynamics.py:642-667)
     {
         QdScope sc(c, "final");
+        const int m = qd_plan(c, {QD_IN(F[QD_F_CLOUD], R), QD_IN(F[QD_F_U], 0), QD_IN(F[QD_F_V], 0), QD_IN(F[QD_F_H], 0),
+                                  QD_IN(F[QD_F_TS], 0), QD_IN(F[QD_F_Q], 0)});
+        if (m < 0) return -1;
         double* oc = qd_scratch(c, 0);
         const double decay = 1 - dt / (2.0 * 24 * 3600);
-        hipLaunchKernelGGL(k_final, grid, blk, 0, c->stream, G, c->tabs.cos6, dt, p.a, c->dlat, c->dlon,
-                           c->f[QD_F_U], c->f[QD_F_V], c->f[QD_F_H], c->f[QD_F_TS], c->f[QD_F_Q],
-                           c->f[QD_F_CLOUD], oc, decay, p.diff_factor);
+        QD_ROWS(c, m, G, hipLaunchKernelGGL(k_final, qd_grid2d(G), blk, 0, c->stream, G, c->tabs.cos6, dt, p.a, c->dlat, c->dlon,
+                                            F[QD_F_U], F[QD_F_V], F[QD_F_H], F[QD_F_TS], F[QD_F_Q], F[QD_F_CLOUD], oc, decay,
+                                            p.diff_factor));
+        qd_mark(c, {F[QD_F_U], F[QD_F_V], F[QD_F_H], F[QD_F_TS], F[QD_F_Q], oc}, m);
         qd_swap(c, QD_F_CLOUD, 0);
     }
     return 0;

@@ -1,0 +1,235 @@
+// qd_band.hip -- latitude-band decomposition: validity margins, launch segments,
+// halo exchange and small all-reduces.
+//
+// A band handle owns global rows [row0, row0+n) and keeps `halo` extra rows on each side.  Halos
+// form a RING in latitude: the south halo of band 0 holds the last rows of the last band (period
+// n_lat), which is exactly what the reference's np.roll(axis=0) stencils and the period-(n-1)
+// map_coordinates fold read at the poles.  Every slab carries a validity margin vm = number of rows
+// beyond the owned band that hold current data.  A stencil of reach r run on inputs with margin m
+// produces outputs with margin m - r ("deep halo": halo rows are recomputed redundantly instead of
+// being exchanged after every kernel); when an input's margin is too small the planner exchanges
+// that slab's halos (margin back to `halo`).  Whole-globe handles skip all of this.
+//
+// Transports: RCCL (one process per GPU, grouped ncclSend/ncclRecv on the handle's stream) or an
+// in-process group of handles on one device (device-to-device copies + a pthread barrier), used to
+// test the band logic on a single GPU.
+#include "qd_internal.h"
+#include <rccl/rccl.h>
+#include <pthread.h>
+#include <cstring>
+#include <algorithm>
+
+struct QdLocalGroup {
+    std::vector<qd_ctx*> peers;
+    pthread_barrier_t bar;
+    std::vector<double> stage_d;        // [world][64]
+    std::vector<unsigned int> stage_u;  // [world][4096]
+};
+
+int qd_vm_get(qd_ctx* c, const void* slab) {
+    if (c->geo.full) return INT_MAX / 2;
+    auto it = c->vm.find(slab);
+    return it == c->vm.end() ? 0 : it->second;
+}
+
+void qd_mark(qd_ctx* c, std::initializer_list<const void*> out, int margin) {
+    if (c->geo.full) return;
+    for (const void* s : out) if (s) c->vm[s] = margin;
+}
+
+QdSegs qd_segments(qd_ctx* c, int margin) {
+    QdSegs S; S.n = 0;
+    const QdGeom& G0 = c->geo;
+    if (G0.full) { S.g[0] = G0; S.n = 1; return S; }
+    const int n = G0.nlat;
+    int vr = c->own_row0 - margin, cnt = c->own_nrows + 2 * margin;
+    while (cnt > 0) {
+        int g0, len;
+        if (vr < 0) { g0 = vr + n; len = std::min(cnt, -vr); }
+        else if (vr >= n) { g0 = vr - n; len = cnt; }
+        else { g0 = vr; len = std::min(cnt, n - vr); }
+        QdGeom g = G0; g.row0 = g0; g.nrows = len;
+        S.g[S.n++] = g;
+        vr += len; cnt -= len;
+        if (S.n == 3) break;
+    }
+    return S;
+}
+
+int qd_plan(qd_ctx* c, std::initializer_list<QdUse> in, int want) {
+    if (c->geo.full) return 0;
+    const int H = c->geo.halo;
+    bool need = false;
+    for (const QdUse& u : in) {
+        if (!*u.slot) continue;
+        if (u.radius > H) return qd_fail(c, "band halo narrower than a stencil reach (create the handle with a larger halo)") , -1;
+        if (qd_vm_get(c, *u.slot) < u.radius) need = true;
+    }
+    if (need) {
+        // refresh every listed slab that is not already at full margin in the same grouped exchange
+        std::vector<QdUse> ex;
+        for (const QdUse& u : in) if (*u.slot && qd_vm_get(c, *u.slot) < H) ex.push_back(u);
+        if (qd_exchange(c, ex.data(), (int)ex.size())) return -1;
+    }
+    int out = INT_MAX;
+    for (const QdUse& u : in) if (*u.slot) out = std::min(out, qd_vm_get(c, *u.slot) - u.radius);
+    if (out == INT_MAX) out = H;
+    out = std::min(out, want);
+    return out < 0 ? 0 : out;
+}
+
+int qd_exchange(qd_ctx* c, const QdUse* slots, int n) {
+    if (c->geo.full || n == 0) return 0;
+    const QdGeom& G = c->geo;
+    const int H = G.halo, nown = c->own_nrows, world = c->desc.world, rank = c->desc.rank;
+    if (nown < H) return qd_fail(c, "latitude band thinner than its halo");
+    const int up = (rank + 1) % world, dn = (rank - 1 + world) % world;
+    c->exchanges += 1;
+    if (c->comm) {
+        ncclComm_t comm = (ncclComm_t)c->comm;
+        ncclGroupStart();
+        for (int k = 0; k < n; ++k) {
+            const size_t esz = slots[k].u8 ? 1 : sizeof(double);
+            const size_t cnt = (size_t)H * G.nlon;
+            char* base = (char*)*slots[k].slot;
+            const ncclDataType_t ty = slots[k].u8 ? ncclUint8 : ncclDouble;
+            ncclSend(base + (size_t)(H + nown - H) * G.nlon * esz, cnt, ty, up, comm, c->stream);   // my top rows -> up's south halo
+            ncclRecv(base, cnt, ty, dn, comm, c->stream);                                            // my south halo <- dn's top rows
+            ncclSend(base + (size_t)H * G.nlon * esz, cnt, ty, dn, comm, c->stream);                 // my bottom rows -> dn's north halo
+            ncclRecv(base + (size_t)(H + nown) * G.nlon * esz, cnt, ty, up, comm, c->stream);        // my north halo <- up's bottom rows
+        }
+        ncclResult_t r = ncclGroupEnd();
+        if (r != ncclSuccess) { c->err = std::string("halo exchange: ") + ncclGetErrorString(r); return -1; }
+    } else if (c->lgroup) {
+        QdLocalGroup* g = c->lgroup;
+        QD_HIP(c, hipStreamSynchronize(c->stream));
+        pthread_barrier_wait(&g->bar);
+        qd_ctx* pu = g->peers[up];
+        qd_ctx* pd = g->peers[dn];
+        for (int k = 0; k < n; ++k) {
+            const size_t esz = slots[k].u8 ? 1 : sizeof(double);
+            const size_t bytes = (size_t)H * G.nlon * esz;
+            const size_t off = (char*)slots[k].slot - (char*)c;               // same logical slot in the peer context
+            char* mine = (char*)*slots[k].slot;
+            const char* dnb = (const char*)*(void**)((char*)pd + off);
+            const char* upb = (const char*)*(void**)((char*)pu + off);
+            QD_HIP(c, hipMemcpyAsync(mine, dnb + (size_t)pd->own_nrows * G.nlon * esz, bytes, hipMemcpyDeviceToDevice, c->stream));
+            QD_HIP(c, hipMemcpyAsync(mine + (size_t)(H + nown) * G.nlon * esz, upb + (size_t)H * G.nlon * esz, bytes,
+                                     hipMemcpyDeviceToDevice, c->stream));
+        }
+        QD_HIP(c, hipStreamSynchronize(c->stream));
+        pthread_barrier_wait(&g->bar);
+    } else {
+        return qd_fail(c, "band handle without a communicator (qd_comm_init / qd_comm_init_local)");
+    }
+    for (int k = 0; k < n; ++k) c->vm[*slots[k].slot] = H;
+    return 0;
+}
+
+int qd_allreduce_f64(qd_ctx* c, double* dptr, int n, int op) {
+    if (c->geo.full) return 0;
+    if (c->comm) {
+        ncclResult_t r = ncclAllReduce(dptr, dptr, n, ncclDouble, op ? ncclMax : ncclSum, (ncclComm_t)c->comm, c->stream);
+        if (r != ncclSuccess) { c->err = std::string("allreduce: ") + ncclGetErrorString(r); return -1; }
+        return 0;
+    }
+    if (c->lgroup) {
+        QdLocalGroup* g = c->lgroup;
+        const int world = c->desc.world, rank = c->desc.rank;
+        if (n > 64) return qd_fail(c, "qd_allreduce_f64: n > 64");
+        QD_HIP(c, hipMemcpyAsync(&g->stage_d[(size_t)rank * 64], dptr, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        QD_HIP(c, hipStreamSynchronize(c->stream));
+        pthread_barrier_wait(&g->bar);
+        double acc[64];
+        for (int k = 0; k < n; ++k) {
+            double a = g->stage_d[k];
+            for (int r = 1; r < world; ++r) { const double b = g->stage_d[(size_t)r * 64 + k]; a = op ? (b > a ? b : a) : a + b; }
+            acc[k] = a;
+        }
+        pthread_barrier_wait(&g->bar);
+        QD_HIP(c, hipMemcpyAsync(dptr, acc, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        QD_HIP(c, hipStreamSynchronize(c->stream));
+        return 0;
+    }
+    return qd_fail(c, "band handle without a communicator");
+}
+
+int qd_allreduce_u32(qd_ctx* c, unsigned int* dptr, int n) {
+    if (c->geo.full) return 0;
+    if (c->comm) {
+        ncclResult_t r = ncclAllReduce(dptr, dptr, n, ncclUint32, ncclSum, (ncclComm_t)c->comm, c->stream);
+        if (r != ncclSuccess) { c->err = std::string("allreduce: ") + ncclGetErrorString(r); return -1; }
+        return 0;
+    }
+    if (c->lgroup) {
+        QdLocalGroup* g = c->lgroup;
+        const int world = c->desc.world, rank = c->desc.rank;
+        if (n > 4096) return qd_fail(c, "qd_allreduce_u32: n > 4096");
+        QD_HIP(c, hipMemcpyAsync(&g->stage_u[(size_t)rank * 4096], dptr, n * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        QD_HIP(c, hipStreamSynchronize(c->stream));
+        pthread_barrier_wait(&g->bar);
+        std::vector<unsigned int> acc(n);
+        for (int k = 0; k < n; ++k) { unsigned a = 0; for (int r = 0; r < world; ++r) a += g->stage_u[(size_t)r * 4096 + k]; acc[k] = a; }
+        pthread_barrier_wait(&g->bar);
+        QD_HIP(c, hipMemcpyAsync(dptr, acc.data(), n * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
+        QD_HIP(c, hipStreamSynchronize(c->stream));
+        return 0;
+    }
+    return qd_fail(c, "band handle without a communicator");
+}
+
+// ---- C-ABI ---------------------------------------------------------------------------------
+extern "C" int qd_comm_unique_id(void* id128, size_t bytes) {
+    if (!id128 || bytes < sizeof(ncclUniqueId)) return -1;
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return -1;
+    std::memcpy(id128, &id, sizeof(id));
+    return 0;
+}
+
+extern "C" int qd_comm_init(qd_handle c, const void* id128, size_t bytes) {
+    if (!c || !id128 || bytes < sizeof(ncclUniqueId)) return -1;
+    hipSetDevice(c->desc.device);
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    ncclComm_t comm;
+    ncclResult_t r = ncclCommInitRank(&comm, c->desc.world, id, c->desc.rank);
+    if (r != ncclSuccess) { c->err = std::string("ncclCommInitRank: ") + ncclGetErrorString(r); return -1; }
+    c->comm = (void*)comm;
+    return 0;
+}
+
+// handles[] ordered by rank, all on one device, each driven by its own host thread
+extern "C" int qd_comm_init_local(qd_handle* handles, int n) {
+    if (!handles || n < 2) return -1;
+    QdLocalGroup* g = new QdLocalGroup();
+    g->peers.assign(handles, handles + n);
+    pthread_barrier_init(&g->bar, nullptr, (unsigned)n);
+    g->stage_d.assign((size_t)n * 64, 0.0);
+    g->stage_u.assign((size_t)n * 4096, 0u);
+    for (int k = 0; k < n; ++k) {
+        if (!handles[k] || handles[k]->desc.rank != k || handles[k]->desc.world != n) { delete g; return -1; }
+        handles[k]->lgroup = g;
+    }
+    return 0;
+}
+
+extern "C" int qd_comm_allreduce_max(qd_handle c, double* inout, int n) {
+    if (!c || !inout || n < 1 || n > 8) return -1;
+    if (c->geo.full || (!c->comm && !c->lgroup)) return 0;     // single process: identity
+    hipSetDevice(c->desc.device);
+    double* d = c->dscal + QD_S_TMP0 + 2;
+    QD_HIP(c, hipMemcpyAsync(d, inout, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (qd_allreduce_f64(c, d, n, 1)) return -1;
+    QD_HIP(c, hipMemcpyAsync(inout, d, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    QD_HIP(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int qd_comm_barrier(qd_handle c) {
+    if (!c) return -1;
+    double z = 0.0;
+    return qd_comm_allreduce_max(c, &z, 1);
+}
+
+extern "C" int qd_comm_stats(qd_handle c, int* exchanges) { if (!c || !exchanges) return -1; *exchanges = c->exchanges; return 0; }

@@ -29,5 +29,5 @@ struct QdOcnArgs {
 
 
 QdTileShape qd_pick_tile(const QdGeom& G);
-int qd_launch_dyn_hyper(qd_ctx* c, QdDynArgs& P);
-int qd_launch_ocn_hyper(qd_ctx* c, QdOcnArgs& P);
+int qd_launch_dyn_hyper(qd_ctx* c, QdDynArgs& P, int margin);
+int qd_launch_ocn_hyper(qd_ctx* c, QdOcnArgs& P, int margin);

@@ -227,7 +227,8 @@ k_dyn_hyper(QdGeom G, QdTabs T, QdDynArgs P) {
     for (int k = 0; k < K; ++k) {
         const int rho = wv + QD_NW * k;
         const int g = i0 - 5 + rho;
-        const bool ok = (rho < RA) && (g >= 0) && (g < G.nlat);
+        // rows of the last tile that fall off the slab (band handles) are masked like rows beyond a pole
+        const bool ok = (rho < RA) && (g >= 0) && (g < G.nlat) && (qd_lrow(G, g) < G.lrows());
         const unsigned o = ok ? (unsigned)qd_lrow(G, g) * (unsigned)G.nlon + (unsigned)j : (unsigned)j;
         ah[k] = P.h[o]; ru[k] = P.u[o]; rv[k] = P.v[o]; rf[k] = P.fric[o]; rq[k] = P.q[o]; rc[k] = P.cloud[o];
     }
@@ -235,7 +236,7 @@ k_dyn_hyper(QdGeom G, QdTabs T, QdDynArgs P) {
     for (int k = 0; k < K; ++k) {
         const int rho = wv + QD_NW * k;
         const int g = i0 - 5 + rho;
-        const bool ok = (rho < RA) && (g >= 0) && (g < G.nlat);
+        const bool ok = (rho < RA) && (g >= 0) && (g < G.nlat) && (qd_lrow(G, g) < G.lrows());
         const bool inB = ok && rho >= 1 && rho < TR + 9;
         ah[k] = ok ? ah[k] : 0.0;
         ru[k] = inB ? ru[k] : 0.0; rv[k] = inB ? rv[k] : 0.0; rf[k] = inB ? rf[k] : 0.0;
@@ -325,8 +326,8 @@ k_ocn_hyper(QdGeom G, QdTabs T, QdOcnArgs P) {
         const int g = i0 - 5 + rho;
         // eta rows wrap across the poles (np.roll(axis=0), ocean.py:308); band mode reads the halo
         int ge = g;
-        if (G.full) { if (ge < 0) ge += G.nlat; else if (ge >= G.nlat) ge -= G.nlat; }
-        const bool okA = rho < RA;
+        if (ge < 0) ge += G.nlat; else if (ge >= G.nlat) ge -= G.nlat;
+        const bool okA = rho < RA && qd_lrow(G, ge) < G.lrows();      // off-slab rows of a band's last tile: masked
         const bool inB = okA && rho >= 1 && rho < TR + 9 && g >= 0 && g < G.nlat;
         const unsigned oe = okA ? (unsigned)qd_lrow(G, ge) * (unsigned)G.nlon + (unsigned)j : (unsigned)j;
         const unsigned o = inB ? (unsigned)qd_lrow(G, g) * (unsigned)G.nlon + (unsigned)j : (unsigned)j;
@@ -337,7 +338,9 @@ k_ocn_hyper(QdGeom G, QdTabs T, QdOcnArgs P) {
     for (int k = 0; k < K; ++k) {
         const int rho = wv + QD_NW * k;
         const int g = i0 - 5 + rho;
-        const bool okA = rho < RA;
+        int ge = g;
+        if (ge < 0) ge += G.nlat; else if (ge >= G.nlat) ge -= G.nlat;
+        const bool okA = rho < RA && qd_lrow(G, ge) < G.lrows();
         const bool inB = okA && rho >= 1 && rho < TR + 9 && g >= 0 && g < G.nlat;
         ae[k] = okA ? ae[k] : 0.0;
         ru[k] = inB ? ru[k] : 0.0; rv[k] = inB ? rv[k] : 0.0; rtx[k] = inB ? rtx[k] : 0.0; rty[k] = inB ? rty[k] : 0.0;
@@ -438,15 +441,18 @@ static void qd_tile_init(qd_ctx* c) {
     }
 }
 
-template <int TR> static void launch_dyn(qd_ctx* c, const QdDynArgs& P) {
+// one launch per row segment (a whole-globe handle has one; a polar band computing its wrap rows has two)
+template <int TR> static void launch_dyn(qd_ctx* c, const QdDynArgs& P, int margin) {
     static bool once = false;
     if (!once) { hipFuncSetAttribute((const void*)k_dyn_hyper<TR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)QdPl<TR>::lds_bytes); once = true; }
-    hipLaunchKernelGGL(k_dyn_hyper<TR>, dim3(P.ts.ntr * P.ts.ntc), dim3(QD_FBLOCK), QdPl<TR>::lds_bytes, c->stream, c->geo, c->tabs, P);
+    QD_ROWS(c, margin, G, hipLaunchKernelGGL(k_dyn_hyper<TR>, dim3(((G.nrows + TR - 1) / TR) * P.ts.ntc), dim3(QD_FBLOCK),
+                                             QdPl<TR>::lds_bytes, c->stream, G, c->tabs, P));
 }
-template <int TR> static void launch_ocn(qd_ctx* c, const QdOcnArgs& P) {
+template <int TR> static void launch_ocn(qd_ctx* c, const QdOcnArgs& P, int margin) {
     static bool once = false;
     if (!once) { hipFuncSetAttribute((const void*)k_ocn_hyper<TR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)QdPl<TR>::lds_bytes); once = true; }
-    hipLaunchKernelGGL(k_ocn_hyper<TR>, dim3(P.ts.ntr * P.ts.ntc), dim3(QD_FBLOCK), QdPl<TR>::lds_bytes, c->stream, c->geo, c->tabs, P);
+    QD_ROWS(c, margin, G, hipLaunchKernelGGL(k_ocn_hyper<TR>, dim3(((G.nrows + TR - 1) / TR) * P.ts.ntc), dim3(QD_FBLOCK),
+                                             QdPl<TR>::lds_bytes, c->stream, G, c->tabs, P));
 }
 
 #define QD_DISPATCH_TR(tr, CALL)                                                                              \
@@ -456,20 +462,20 @@ template <int TR> static void launch_ocn(qd_ctx* c, const QdOcnArgs& P) {
         default: return qd_fail(c, "fused kernel: no instantiation for this tile height");                    \
     }
 
-int qd_launch_dyn_hyper(qd_ctx* c, QdDynArgs& P) {
+int qd_launch_dyn_hyper(qd_ctx* c, QdDynArgs& P, int margin) {
     qd_tile_init(c);
     P.ts = c->tile;
     QdScope sc(c, "k_dyn_hyper");
-#define QD_CALL_DYN(N) launch_dyn<N>(c, P)
+#define QD_CALL_DYN(N) launch_dyn<N>(c, P, margin)
     QD_DISPATCH_TR(P.ts.tr, QD_CALL_DYN)
     return 0;
 }
 
-int qd_launch_ocn_hyper(qd_ctx* c, QdOcnArgs& P) {
+int qd_launch_ocn_hyper(qd_ctx* c, QdOcnArgs& P, int margin) {
     qd_tile_init(c);
     P.ts = c->tile;
     QdScope sc(c, "k_ocn_hyper");
-#define QD_CALL_OCN(N) launch_ocn<N>(c, P)
+#define QD_CALL_OCN(N) launch_ocn<N>(c, P, margin)
     QD_DISPATCH_TR(P.ts.tr, QD_CALL_OCN)
     return 0;
 }

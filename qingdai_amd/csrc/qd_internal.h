@@ -12,6 +12,9 @@
 #include <string>
 #include <vector>
 #include <map>
+#include <unordered_map>
+#include <initializer_list>
+#include <climits>
 #include <cfloat>
 #include <cmath>
 
@@ -24,9 +27,11 @@
 
 struct QdGeom {
     int nlat, nlon;          // global grid
-    int row0, nrows, halo;   // band
+    int row0, nrows, halo;   // rows [row0, row0+nrows) are the rows a launch computes (a band or a segment of it)
     int full;                // 1: band == whole globe (row wrap/fold resolved by index arithmetic)
-    __host__ __device__ inline int lrows() const { return nrows + 2 * halo; }
+    int lbase;               // global row held by local row 0 (= owned row0 - halo; may be negative: wraps)
+    int lrows_;              // local rows of the slab (owned + 2*halo)
+    __host__ __device__ inline int lrows() const { return lrows_; }
     __host__ __device__ inline size_t cells() const { return (size_t)lrows() * (size_t)nlon; }
 };
 
@@ -76,19 +81,16 @@ __device__ __forceinline__ double qd_pow4(double x) { double x2 = x * x; return 
 // local row of global row g; in `full` mode rows outside [0,nlat) wrap with period nlat
 // (np.roll(axis=0) semantics); in band mode they address the halo.
 __device__ __forceinline__ int qd_lrow(const QdGeom& G, int g) {
-    if (G.full) {
-        if (g < 0) g += G.nlat; else if (g >= G.nlat) g -= G.nlat;
-        return g;
-    }
-    return g - G.row0 + G.halo;
+    int l = g - G.lbase;                       // full mode: lbase = 0
+    if (l < 0) l += G.nlat; else if (l >= G.nlat) l -= G.nlat;
+    return l;
 }
 // local row of a global row that is already inside [0, nlat) (advection departure rows):
 // band mode lets the polar bands reach the opposite pole through their period-nlat halo.
 __device__ __forceinline__ int qd_lrow_far(const QdGeom& G, int g) {
-    if (G.full) return g;
-    int l = g - G.row0 + G.halo;
-    if (l < 0) l += G.nlat; else if (l >= G.lrows()) l -= G.nlat;
-    if (l < 0) l = 0; if (l >= G.lrows()) l = G.lrows() - 1;   // never fault; flagged by host checks
+    int l = g - G.lbase;
+    if (l < 0) l += G.nlat; else if (l >= G.nlat) l -= G.nlat;
+    if (l >= G.lrows()) l = G.lrows() - 1;     // outside the halo: never fault (band runs size the halo for the reach)
     return l;
 }
 __device__ __forceinline__ int qd_wrapc(int j, int n) {        // periodic column
@@ -152,8 +154,13 @@ struct qd_ctx {
     int last_nsub = 0;
     // host staging
     void* stage = nullptr; size_t stage_bytes = 0;
+    // latitude bands: validity margin (rows beyond the owned band that hold current data) per slab
+    std::unordered_map<const void*, int> vm;
+    int own_row0 = 0, own_nrows = 0;
     // comm
-    void* comm = nullptr;
+    void* comm = nullptr;          // RCCL communicator (one process per GPU)
+    struct QdLocalGroup* lgroup = nullptr;   // in-process peers on one device (tests of the band logic)
+    int exchanges = 0;             // statistics
     // timing
     const char* lap_tag = "k_laplacian";       // timing-group names of the two del^4 kernels
     const char* hyp_tag = "k_hyper_apply";     // (the ocean switches them to ocean_* around its calls)
@@ -181,6 +188,22 @@ struct QdScope {               // optional per-kernel-group timing with hipEvent
     ~QdScope();
 };
 
+// ---- latitude-band planning (qd_band.hip) ----------------------------------------------------
+struct QdUse { void** slot; int radius; int u8; };
+#define QD_IN(ptr, r) QdUse{(void**)&(ptr), (r), 0}
+#define QD_IN8(ptr, r) QdUse{(void**)&(ptr), (r), 1}
+// makes sure every input slab is valid `radius` rows beyond what the launch will compute; exchanges
+// halos when one is not; returns the margin (rows beyond the owned band) the outputs can be computed on
+int qd_plan(qd_ctx* c, std::initializer_list<QdUse> in, int want = INT_MAX);
+void qd_mark(qd_ctx* c, std::initializer_list<const void*> out, int margin);
+int qd_vm_get(qd_ctx* c, const void* slab);
+struct QdSegs { QdGeom g[3]; int n; };
+QdSegs qd_segments(qd_ctx* c, int margin);
+int qd_exchange(qd_ctx* c, const QdUse* slots, int n);
+int qd_allreduce_f64(qd_ctx* c, double* dptr, int n, int op);          // op 0 sum, 1 max (device scalars)
+int qd_allreduce_u32(qd_ctx* c, unsigned int* dptr, int n);            // sum
+#define QD_ROWS(c, margin, G, ...) do { QdSegs _sg = qd_segments((c), (margin)); for (int _k = 0; _k < _sg.n; ++_k) { const QdGeom& G = _sg.g[_k]; __VA_ARGS__; } } while (0)
+
 static inline dim3 qd_grid2d(const QdGeom& G, int fields = 1) {
     return dim3((G.nlon + QD_BLOCK - 1) / QD_BLOCK, G.nrows, fields);
 }
@@ -196,16 +219,20 @@ struct QdFieldList {
 };
 
 // qd_stencil.hip
-void qd_launch_laplacian(qd_ctx* c, const QdFieldList& fl, const double* coslat);
-void qd_launch_hyper_apply(qd_ctx* c, const QdFieldList& fl, const double* coslat, double sub_dt);
+// `m` / `m_out`: margin (rows beyond the owned band) the launch / the final result is computed on;
+// 0 for whole-globe handles.  Callers plan the inputs with qd_plan first.
+void qd_launch_laplacian(qd_ctx* c, const QdFieldList& fl, const double* coslat, int m);
+void qd_launch_hyper_apply(qd_ctx* c, const QdFieldList& fl, const double* coslat, double sub_dt, int m);
 int  qd_hyperdiffuse_fields(qd_ctx* c, double** fields, int n, const double* k4tab, const int* skip,
-                            const double* k4s_override, double dt, int nsub, const double* coslat);
-void qd_launch_shapiro_pass(qd_ctx* c, const QdFieldList& fl, int scrub);
-int  qd_shapiro_fields(qd_ctx* c, double** fields, int n, int npass);
+                            const double* k4s_override, double dt, int nsub, const double* coslat, int m_out);
+void qd_launch_shapiro_pass(qd_ctx* c, const QdFieldList& fl, int scrub, int m);
+int  qd_shapiro_fields(qd_ctx* c, double** fields, int n, int npass, int m_out);
 void qd_launch_advect(qd_ctx* c, const double* u, const double* v, const double* coslat, double dt,
-                      const double* f0, double* o0, const double* f1, double* o1, double alpha, int clipq);
-void qd_launch_divvort(qd_ctx* c, const double* u, const double* v, double* out, int vort);
-int  qd_gaussian(qd_ctx* c, const double* in, double* out, double* tmp, double sigma, int mode_wrap);
+                      const double* f0, double* o0, const double* f1, double* o1, double alpha, int clipq, int m);
+void qd_launch_divvort(qd_ctx* c, const double* u, const double* v, double* out, int vort, int m);
+int  qd_gaussian(qd_ctx* c, const double* in, double* out, double* tmp, double sigma, int mode_wrap, int m_out);
+int  qd_gauss_radius(double sigma);
+int  qd_adv_reach(const qd_ctx* c, double dt, double vmax);
 
 // qd_reduce.hip
 int qd_reduce_field(qd_ctx* c, const double* x, int op, double* host_out);

@@ -170,7 +170,7 @@ k_eta_mean(const double* __restrict__ partial, int n, double wsum, double* __res
     if (threadIdx.x == 0) {
         double r = sm[0];
         for (int k = 1; k < QD_BLOCK / 64; ++k) r += sm[k];
-        *out = r / (wsum + 1e-15);
+        *out = (wsum < 0.0) ? r : r / (wsum + 1e-15);      // wsum < 0: raw sum (bands all-reduce it first)
     }
 }
 
@@ -357,35 +357,63 @@ k_sst_clamp_inject(QdGeom G, double* __restrict__ sst, double tmin, double tmax,
 }
 
 // ------------------------------------------------------------------ host orchestration
+// device scalars after a reduction: raw sums/maxima are all-reduced across latitude bands first
+__global__ void k_eta_mean_post(double* s, double wsum) { if (threadIdx.x == 0 && blockIdx.x == 0) *s = *s / (wsum + 1e-15); }
+
 int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask, int inject_sst) {
     const qd_params& p = c->p;
-    const QdGeom& G = c->geo;
-    const dim3 grid = qd_grid2d(G), blk(QD_BLOCK), rows(1, G.nrows);
+    const QdGeom& G0 = c->geo;
+    const dim3 blk(QD_BLOCK);
+    double** F = c->f;
+    const bool band = !G0.full;
     c->ocn_counter += 1;
     const int64_t step = c->ocn_counter;
     const double H = p.H_ocean;
+    const QdGeom Gown = qd_segments(c, 0).g[0];        // owned rows: reductions never count halo rows
+    const dim3 rows(1, Gown.nrows);
 
     if (compute_qnet) {
         QdScope sc(c, "ocean_qnet");
         QdColP P = qd_make_colp(c, dt);
         // cloud optical field: cloud_eff_last when time_step produced one, else cloud_cover
-        const double* cl = c->cloud_eff_valid ? c->f[QD_F_CLOUD_EFF] : c->f[QD_F_CLOUD];
-        hipLaunchKernelGGL(k_qnet, grid, blk, 0, c->stream, G, P, c->f[QD_F_ISR], c->f[QD_F_ALBEDO], cl, c->f[QD_F_TS],
-                           c->f[QD_F_H], c->f[QD_F_U], c->f[QD_F_V], c->land, c->f[QD_F_HICE], c->f[QD_F_LH],
-                           c->f[QD_F_QNET], c->icemask);
+        double*& cl = c->cloud_eff_valid ? F[QD_F_CLOUD_EFF] : F[QD_F_CLOUD];
+        const int m = qd_plan(c, {QD_IN(F[QD_F_ISR], 0), QD_IN(F[QD_F_ALBEDO], 0), QD_IN(cl, 0), QD_IN(F[QD_F_TS], 0),
+                                  QD_IN(F[QD_F_H], 0), QD_IN(F[QD_F_U], 0), QD_IN(F[QD_F_V], 0), QD_IN(F[QD_F_HICE], 0),
+                                  QD_IN(F[QD_F_LH], 0)});
+        if (m < 0) return -1;
+        QD_ROWS(c, m, G, hipLaunchKernelGGL(k_qnet, qd_grid2d(G), blk, 0, c->stream, G, P, F[QD_F_ISR], F[QD_F_ALBEDO], cl,
+                                            F[QD_F_TS], F[QD_F_H], F[QD_F_U], F[QD_F_V], c->land, F[QD_F_HICE], F[QD_F_LH],
+                                            F[QD_F_QNET], c->icemask));
+        qd_mark(c, {F[QD_F_QNET], c->icemask}, m);
         use_ice_mask = 1;
     }
-    double* taux = qd_scratch(c, 14);
-    double* tauy = qd_scratch(c, 15);
+    double*& taux = c->scratch[14];
+    double*& tauy = c->scratch[15];
     int n_sub;
     {
         QdScope sc(c, "ocean_stress");
-        hipLaunchKernelGGL(k_stress_max, rows, blk, 0, c->stream, G, c->f[QD_F_U], c->f[QD_F_V], c->f[QD_F_UO],
-                           c->f[QD_F_VO], p.vcap, p.rho_a_ocean * p.CD, p.tau_scale, taux, tauy, c->red_partial);
-        hipLaunchKernelGGL(k_max2_finish, dim3(1), blk, 0, c->stream, c->red_partial, G.nrows, c->dscal + QD_S_TMP0);
-        QD_HIP(c, hipMemcpyAsync(c->hpin, c->dscal + QD_S_TMP0, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        // stress on the widest valid margin (sub-steps read it under the fused kernel's halo);
+        // the CFL maxima come from the owned rows, then the bands agree on them
+        const int m = qd_plan(c, {QD_IN(F[QD_F_U], 0), QD_IN(F[QD_F_V], 0), QD_IN(F[QD_F_UO], 0), QD_IN(F[QD_F_VO], 0)});
+        if (m < 0) return -1;
+        QdSegs S = qd_segments(c, m);
+        QD_HIP(c, hipMemsetAsync(c->dscal + QD_S_TMP0, 0, 6 * sizeof(double), c->stream));
+        for (int k = 0; k < S.n; ++k) {
+            const QdGeom& G = S.g[k];
+            // partial maxima of halo segments are harmless (a max over more valid rows of the globe)
+            hipLaunchKernelGGL(k_stress_max, dim3(1, G.nrows), blk, 0, c->stream, G, F[QD_F_U], F[QD_F_V], F[QD_F_UO],
+                               F[QD_F_VO], p.vcap, p.rho_a_ocean * p.CD, p.tau_scale, taux, tauy,
+                               c->red_partial + (size_t)k * 2 * G0.lrows());
+            hipLaunchKernelGGL(k_max2_finish, dim3(1), blk, 0, c->stream, c->red_partial + (size_t)k * 2 * G0.lrows(), G.nrows,
+                               c->dscal + QD_S_TMP0 + 2 * k);
+        }
+        qd_mark(c, {taux, tauy}, m);
+        // ONE collective of fixed size on every band (polar bands have more segments than interior ones)
+        if (qd_allreduce_f64(c, c->dscal + QD_S_TMP0, 6, 1)) return -1;
+        QD_HIP(c, hipMemcpyAsync(c->hpin, c->dscal + QD_S_TMP0, 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         QD_HIP(c, hipStreamSynchronize(c->stream));
-        const double maxVa = c->hpin[0], maxUo = c->hpin[1];
+        double maxVa = 0.0, maxUo = 0.0;
+        for (int k = 0; k < 3; ++k) { maxVa = std::max(maxVa, c->hpin[2 * k]); maxUo = std::max(maxUo, c->hpin[2 * k + 1]); }
         // ocean.py:293-303
         const double dx_lat = p.a * c->dlat;
         const double min_cos = 0.5;                       // min of max(cos, 0.5) on a pole-to-pole grid
@@ -405,83 +433,152 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
     const bool do_shap = (p.ocean_shapiro_n > 0) && (p.ocean_shapiro_every > 0) && (step % p.ocean_shapiro_every == 0);
     if (do_diff) { int rc = qd_build_k4_tables(c, dt, true, sub_dt); if (rc) return rc; }
     const double ov[3] = {p.ocean_k4_u, p.ocean_k4_v, p.ocean_k4_eta};
+    const int Ro = qd_adv_reach(c, sub_dt, 4.0);           // currents are capped at QD_OCEAN_MAX_U (3 m/s)
 
     for (int s = 0; s < n_sub; ++s) {
         if (do_diff && c->use_fused && p.ocean_k4_nsub == 1) {
+            const int m = qd_plan(c, {QD_IN(F[QD_F_ETA], 5), QD_IN(F[QD_F_UO], 4), QD_IN(F[QD_F_VO], 4), QD_IN(taux, 4),
+                                      QD_IN(tauy, 4)});
+            if (m < 0) return -1;
             QdOcnArgs O;
-            O.uo = c->f[QD_F_UO]; O.vo = c->f[QD_F_VO]; O.eta = c->f[QD_F_ETA]; O.taux = taux; O.tauy = tauy; O.land = c->land;
+            O.uo = F[QD_F_UO]; O.vo = F[QD_F_VO]; O.eta = F[QD_F_ETA]; O.taux = taux; O.tauy = tauy; O.land = c->land;
             O.uo_out = qd_scratch(c, 0); O.vo_out = qd_scratch(c, 1); O.eta_out = qd_scratch(c, 2);
             for (int f = 0; f < 3; ++f) {
                 const bool sc1 = !(ov[f] != ov[f]);
-                O.k4row[f] = sc1 ? nullptr : c->k4_ocn + (size_t)f * G.nlat;
+                O.k4row[f] = sc1 ? nullptr : c->k4_ocn + (size_t)f * G0.nlat;
                 O.k4s[f] = sc1 ? ov[f] : 0.0;
                 O.skip[f] = c->k4_ocn_skip[f];
             }
             O.a = p.a; O.g = p.g_ocean; O.dlat = c->dlat; O.dlon = c->dlon; O.sub_dt = sub_dt; O.rhoH = p.rho_w * H; O.r_bot = p.r_bot;
             O.inv_2dlon = 1.0 / (2.0 * c->dlon); O.inv_2dlat = 1.0 / (2.0 * c->dlat); O.inv_a = 1.0 / p.a; O.inv_rhoH = 1.0 / (p.rho_w * H);
-            qd_launch_ocn_hyper(c, O);
+            if (qd_launch_ocn_hyper(c, O, m)) return -1;
+            qd_mark(c, {O.uo_out, O.vo_out, O.eta_out}, m);
             qd_swap(c, QD_F_UO, 0); qd_swap(c, QD_F_VO, 1); qd_swap(c, QD_F_ETA, 2);
         } else {
             {
                 QdScope sc(c, "ocean_momentum");
-                hipLaunchKernelGGL(k_ocean_momentum, grid, blk, 0, c->stream, G, c->tabs, OP, c->f[QD_F_ETA], taux, tauy,
-                                   c->land, c->f[QD_F_UO], c->f[QD_F_VO]);
+                const int m = qd_plan(c, {QD_IN(F[QD_F_ETA], 1), QD_IN(F[QD_F_UO], 0), QD_IN(F[QD_F_VO], 0), QD_IN(taux, 0),
+                                          QD_IN(tauy, 0)});
+                if (m < 0) return -1;
+                QD_ROWS(c, m, G, hipLaunchKernelGGL(k_ocean_momentum, qd_grid2d(G), blk, 0, c->stream, G, c->tabs, OP,
+                                                    F[QD_F_ETA], taux, tauy, c->land, F[QD_F_UO], F[QD_F_VO]));
+                qd_mark(c, {F[QD_F_UO], F[QD_F_VO]}, m);
             }
             if (do_diff) {
                 QdScope sc(c, "ocean_hyperdiffusion");
-                double* fl[3] = {c->f[QD_F_UO], c->f[QD_F_VO], c->f[QD_F_ETA]};
+                const int ns = std::max(1, p.ocean_k4_nsub);
+                const int m = qd_plan(c, {QD_IN(F[QD_F_UO], 4 * ns), QD_IN(F[QD_F_VO], 4 * ns), QD_IN(F[QD_F_ETA], 4 * ns)});
+                if (m < 0) return -1;
+                double* fl[3] = {F[QD_F_UO], F[QD_F_VO], F[QD_F_ETA]};
                 c->lap_tag = "ocean_k_laplacian"; c->hyp_tag = "ocean_k_hyper_apply";
-                qd_hyperdiffuse_fields(c, fl, 3, c->k4_ocn, c->k4_ocn_skip, ov, sub_dt, p.ocean_k4_nsub, c->tabs.cos05);
+                qd_hyperdiffuse_fields(c, fl, 3, c->k4_ocn, c->k4_ocn_skip, ov, sub_dt, ns, c->tabs.cos05, m);
                 c->lap_tag = "k_laplacian"; c->hyp_tag = "k_hyper_apply";
-                c->f[QD_F_UO] = fl[0]; c->f[QD_F_VO] = fl[1]; c->f[QD_F_ETA] = fl[2];
+                F[QD_F_UO] = fl[0]; F[QD_F_VO] = fl[1]; F[QD_F_ETA] = fl[2];
             }
         }
         if (do_shap) {
-            double* fl[3] = {c->f[QD_F_UO], c->f[QD_F_VO], c->f[QD_F_ETA]};
-            qd_shapiro_fields(c, fl, 3, p.ocean_shapiro_n);
-            c->f[QD_F_UO] = fl[0]; c->f[QD_F_VO] = fl[1]; c->f[QD_F_ETA] = fl[2];
+            const int np_ = p.ocean_shapiro_n;
+            const int m = qd_plan(c, {QD_IN(F[QD_F_UO], np_), QD_IN(F[QD_F_VO], np_), QD_IN(F[QD_F_ETA], np_)});
+            if (m < 0) return -1;
+            double* fl[3] = {F[QD_F_UO], F[QD_F_VO], F[QD_F_ETA]};
+            qd_shapiro_fields(c, fl, 3, np_, m);
+            F[QD_F_UO] = fl[0]; F[QD_F_VO] = fl[1]; F[QD_F_ETA] = fl[2];
         }
         {
             QdScope sc(c, "ocean_continuity");
-            hipLaunchKernelGGL(k_continuity, rows, blk, 0, c->stream, G, c->tabs, p.a, c->dlat, c->dlon, -sub_dt * H,
-                               c->f[QD_F_UO], c->f[QD_F_VO], c->land, c->f[QD_F_ETA], c->red_partial);
-            hipLaunchKernelGGL(k_eta_mean, dim3(1), blk, 0, c->stream, c->red_partial, G.nrows, c->wsum_ocean,
-                               c->dscal + QD_S_ETA_MEAN);
+            // eta update on the margin; the area-weighted sum only over owned rows
+            const int m = qd_plan(c, {QD_IN(F[QD_F_UO], 1), QD_IN(F[QD_F_VO], 1), QD_IN(F[QD_F_ETA], 0)});
+            if (m < 0) return -1;
+            if (band && m > 0) {
+                // halo rows first (their partial sums are discarded), owned rows last
+                QdSegs S = qd_segments(c, m);
+                for (int k = 0; k < S.n; ++k) {
+                    QdGeom G = S.g[k];
+                    // trim the owned part out of this segment: it is done by the dedicated owned launch below
+                    const int own0 = c->own_row0, own1 = c->own_row0 + c->own_nrows;
+                    int a0 = G.row0, a1 = G.row0 + G.nrows;
+                    auto run = [&](int r0, int r1) {
+                        if (r1 <= r0) return;
+                        QdGeom g2 = G; g2.row0 = r0; g2.nrows = r1 - r0;
+                        hipLaunchKernelGGL(k_continuity, dim3(1, g2.nrows), blk, 0, c->stream, g2, c->tabs, p.a, c->dlat, c->dlon,
+                                           -sub_dt * H, F[QD_F_UO], F[QD_F_VO], c->land, F[QD_F_ETA],
+                                           c->red_partial + (size_t)G0.lrows());
+                    };
+                    if (a1 <= own0 || a0 >= own1) run(a0, a1);
+                    else { run(a0, std::max(a0, own0)); run(std::min(a1, own1), a1); }
+                }
+            }
+            hipLaunchKernelGGL(k_continuity, rows, blk, 0, c->stream, Gown, c->tabs, p.a, c->dlat, c->dlon, -sub_dt * H,
+                               F[QD_F_UO], F[QD_F_VO], c->land, F[QD_F_ETA], c->red_partial);
+            qd_mark(c, {F[QD_F_ETA]}, m);
+            if (band) {
+                hipLaunchKernelGGL(k_eta_mean, dim3(1), blk, 0, c->stream, c->red_partial, Gown.nrows, -1.0,
+                                   c->dscal + QD_S_ETA_MEAN);      // raw sum
+                if (qd_allreduce_f64(c, c->dscal + QD_S_ETA_MEAN, 1, 0)) return -1;
+                hipLaunchKernelGGL(k_eta_mean_post, dim3(1), dim3(64), 0, c->stream, c->dscal + QD_S_ETA_MEAN, c->wsum_ocean);
+            } else {
+                hipLaunchKernelGGL(k_eta_mean, dim3(1), blk, 0, c->stream, c->red_partial, Gown.nrows, c->wsum_ocean,
+                                   c->dscal + QD_S_ETA_MEAN);
+            }
         }
         {
             QdScope sc(c, "ocean_sst");
+            const int m1 = qd_plan(c, {QD_IN(F[QD_F_SST], Ro), QD_IN(F[QD_F_UO], 0), QD_IN(F[QD_F_VO], 0), QD_IN(F[QD_F_ETA], 0)});
+            if (m1 < 0) return -1;
             double* T1 = qd_scratch(c, 0);
-            hipLaunchKernelGGL(k_sst_advect, grid, blk, 0, c->stream, G, c->tabs.cos05, sub_dt, p.a, c->dlat, c->dlon,
-                               c->f[QD_F_UO], c->f[QD_F_VO], c->f[QD_F_SST], T1, p.ocean_adv_alpha, c->f[QD_F_ETA],
-                               c->dscal + QD_S_ETA_MEAN, c->wsum_ocean > 0.0 ? 1 : 0);
+            QD_ROWS(c, m1, G, hipLaunchKernelGGL(k_sst_advect, qd_grid2d(G), blk, 0, c->stream, G, c->tabs.cos05, sub_dt, p.a,
+                                                 c->dlat, c->dlon, F[QD_F_UO], F[QD_F_VO], F[QD_F_SST], T1, p.ocean_adv_alpha,
+                                                 F[QD_F_ETA], c->dscal + QD_S_ETA_MEAN, c->wsum_ocean > 0.0 ? 1 : 0));
+            qd_mark(c, {T1, F[QD_F_ETA]}, m1);
+            double*& T1s = c->scratch[0];
             double* T2 = qd_scratch(c, 1);
             if (c->use_fused) {
+                const int m2 = qd_plan(c, {QD_IN(T1s, 2), QD_IN(F[QD_F_QNET], 0), QD_IN8(c->icemask, 0), QD_IN(F[QD_F_UO], 1),
+                                           QD_IN(F[QD_F_VO], 1), QD_IN(F[QD_F_ETA], 0)});
+                if (m2 < 0) return -1;
                 double* u2 = qd_scratch(c, 2); double* v2 = qd_scratch(c, 3);
-                hipLaunchKernelGGL(k_sst_outlier_fused, grid, blk, 0, c->stream, G, c->tabs, c->dlat, c->dlon, p.a, HP, T1, T2,
-                                   c->f[QD_F_QNET], c->land, c->icemask, c->f[QD_F_UO], c->f[QD_F_VO], u2, v2,
-                                   c->f[QD_F_ETA], p.ocean_max_u, p.eta_cap, p.ocean_outlier == 0 ? 1 : 0);
+                QD_ROWS(c, m2, G, hipLaunchKernelGGL(k_sst_outlier_fused, qd_grid2d(G), blk, 0, c->stream, G, c->tabs, c->dlat,
+                                                     c->dlon, p.a, HP, c->scratch[0], T2, F[QD_F_QNET], c->land, c->icemask,
+                                                     F[QD_F_UO], F[QD_F_VO], u2, v2, F[QD_F_ETA], p.ocean_max_u, p.eta_cap,
+                                                     p.ocean_outlier == 0 ? 1 : 0));
+                qd_mark(c, {T2, u2, v2, F[QD_F_ETA]}, m2);
                 qd_swap(c, QD_F_SST, 1); qd_swap(c, QD_F_UO, 2); qd_swap(c, QD_F_VO, 3);
             } else {
-                hipLaunchKernelGGL(k_sst_diffuse_heat, grid, blk, 0, c->stream, G, c->tabs.cos05, c->dlat, c->dlon, p.a, HP,
-                                   T1, T2, c->f[QD_F_QNET], c->land, c->icemask);
+                const int m2 = qd_plan(c, {QD_IN(T1s, 2), QD_IN(F[QD_F_QNET], 0), QD_IN8(c->icemask, 0)});
+                if (m2 < 0) return -1;
+                QD_ROWS(c, m2, G, hipLaunchKernelGGL(k_sst_diffuse_heat, qd_grid2d(G), blk, 0, c->stream, G, c->tabs.cos05,
+                                                     c->dlat, c->dlon, p.a, HP, c->scratch[0], T2, F[QD_F_QNET], c->land,
+                                                     c->icemask));
+                qd_mark(c, {T2}, m2);
                 qd_swap(c, QD_F_SST, 1);
             }
         }
         if (!c->use_fused) {
             QdScope sc(c, "ocean_outlier");
+            const int m = qd_plan(c, {QD_IN(F[QD_F_UO], 1), QD_IN(F[QD_F_VO], 1), QD_IN(F[QD_F_ETA], 0)});
+            if (m < 0) return -1;
             double* u2 = qd_scratch(c, 2); double* v2 = qd_scratch(c, 3);
-            hipLaunchKernelGGL(k_outlier, grid, blk, 0, c->stream, G, c->f[QD_F_UO], c->f[QD_F_VO], u2, v2,
-                               c->f[QD_F_ETA], p.ocean_max_u, p.eta_cap, p.ocean_outlier == 0 ? 1 : 0);
+            QD_ROWS(c, m, G, hipLaunchKernelGGL(k_outlier, qd_grid2d(G), blk, 0, c->stream, G, F[QD_F_UO], F[QD_F_VO], u2, v2,
+                                                F[QD_F_ETA], p.ocean_max_u, p.eta_cap, p.ocean_outlier == 0 ? 1 : 0));
+            qd_mark(c, {u2, v2, F[QD_F_ETA]}, m);
             qd_swap(c, QD_F_UO, 2); qd_swap(c, QD_F_VO, 3);
         }
     }
     {
         QdScope sc(c, "ocean_finish");
-        if (p.ocean_polar_fix)
-            hipLaunchKernelGGL(k_polar_fill, dim3(2), blk, 0, c->stream, G, c->tabs, c->land, c->f[QD_F_SST],
-                               c->f[QD_F_UO], c->f[QD_F_VO]);
-        hipLaunchKernelGGL(k_sst_clamp_inject, grid, blk, 0, c->stream, G, c->f[QD_F_SST], p.ts_min, p.ts_max,
-                           inject_sst, c->land, c->icemask, use_ice_mask ? 1 : 0, c->f[QD_F_TS]);
+        if (p.ocean_polar_fix) {
+            // the two pole rows are owned by the first / last band; their copies in the other polar
+            // band's wrap halo go stale -> margins drop to 0 so the next stencil refreshes them
+            hipLaunchKernelGGL(k_polar_fill, dim3(2), blk, 0, c->stream, Gown, c->tabs, c->land, F[QD_F_SST], F[QD_F_UO],
+                               F[QD_F_VO]);
+            qd_mark(c, {F[QD_F_SST], F[QD_F_UO], F[QD_F_VO]}, 0);
+        }
+        const int m = qd_plan(c, {QD_IN(F[QD_F_SST], 0), QD_IN(F[QD_F_TS], 0), QD_IN8(c->icemask, 0)});
+        if (m < 0) return -1;
+        QD_ROWS(c, m, G, hipLaunchKernelGGL(k_sst_clamp_inject, qd_grid2d(G), blk, 0, c->stream, G, F[QD_F_SST], p.ts_min, p.ts_max,
+                                            inject_sst, c->land, c->icemask, use_ice_mask ? 1 : 0, F[QD_F_TS]));
+        qd_mark(c, {F[QD_F_SST]}, m);
+        if (inject_sst) qd_mark(c, {F[QD_F_TS]}, m);
     }
     return 0;
 }

@@ -183,67 +183,154 @@ k_cloud_albedo(QdGeom G, QdAlbP P, const double* __restrict__ adv, double* __res
     albedo[o] = qd_clip(surf * (1.0 - C) + P.alpha_cloud * C, 0.0, 1.0);
 }
 
+__global__ void k_precip_scalars_post(const double* raw, double wsum, double pq_min, double p_blend, int use_fb, double* out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const double a = raw[0], b = raw[1];
+        const double den = b + 1e-20;
+        out[0] = den > 0 ? a / den : 1.0;
+        const double pq_mean = a / (wsum + 1e-15);
+        out[1] = (use_fb && pq_mean < pq_min) ? p_blend : 0.0;
+    }
+}
+// raw (num, den) sums of the owned rows -> out[0], out[1]
+__global__ void __launch_bounds__(QD_BLOCK)
+k_precip_rawsums(const double* __restrict__ partial, int n, double* __restrict__ out) {
+    __shared__ double sm[2][QD_BLOCK / 64];
+    double a = 0.0, b = 0.0;
+    for (int k = threadIdx.x; k < n; k += QD_BLOCK) { a += partial[k]; b += partial[n + k]; }
+    a = qd_wsum(a); b = qd_wsum(b);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { sm[0][wv] = a; sm[1][wv] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < QD_BLOCK / 64; ++k) { a += sm[0][k]; b += sm[1][k]; }
+        out[0] = a; out[1] = b;
+    }
+}
+
 int qd_driver_physics_impl(qd_ctx* c, double dt) {
     const qd_params& p = c->p;
-    const QdGeom& G = c->geo;
-    const dim3 grid = qd_grid2d(G), blk(QD_BLOCK), rows(1, G.nrows);
+    const QdGeom& G0 = c->geo;
+    const dim3 blk(QD_BLOCK);
+    double** F = c->f;
+    const bool band = !G0.full;
+    const QdGeom Gown = qd_segments(c, 0).g[0];
     auto isset = [](double x) { return !(x != x); };
-    double* praw = qd_scratch(c, 4);
-    double* pos = qd_scratch(c, 5);
-    double* tmp = qd_scratch(c, 6);
-    double* pdyn = qd_scratch(c, 7);
-    double* cfp = c->f[QD_F_CLOUD_FROM_P];
-    double* src = c->f[QD_F_CLOUD_SRC];
-    double* precip = c->f[QD_F_PRECIP];
+    double*& praw = c->scratch[4];
+    double*& pos = c->scratch[5];
+    double*& tmp = c->scratch[6];
+    double*& pdyn = c->scratch[7];
+    const int R1 = qd_gauss_radius(1.0);
+    const int Rc = qd_adv_reach(c, dt, 250.0);
     {
         QdScope sc(c, "phys_precip");
         // median of pos = max(0, -(div - D_crit)) over pos > 0, straight from the divergence field
-        qd_launch_divvort(c, c->f[QD_F_U], c->f[QD_F_V], tmp, 0);
-        qd_median_positive_dev(c, tmp, 1e-12, QD_S_PSCALE, 1, p.D_crit);
-        hipLaunchKernelGGL(k_precip_raw, rows, blk, 0, c->stream, G, c->tabs, c->f[QD_F_U], c->f[QD_F_V], c->f[QD_F_PCOND],
-                           p.a, c->dlat, c->dlon, p.D_crit, p.p_betadiv, c->dscal + QD_S_PSCALE, c->dcount, praw, pos,
-                           c->red_partial);
-        hipLaunchKernelGGL(k_precip_scalars, dim3(1), blk, 0, c->stream, c->red_partial, G.nrows, c->wsum_all, p.pq_min,
-                           p.p_blend, p.p_hybrid_fallback, c->dscal + QD_S_RENORM);
+        int m = qd_plan(c, {QD_IN(F[QD_F_U], 1), QD_IN(F[QD_F_V], 1), QD_IN(F[QD_F_PCOND], 0)});
+        if (m < 0) return -1;
+        qd_launch_divvort(c, F[QD_F_U], F[QD_F_V], tmp, 0, m);
+        if (qd_median_positive_dev(c, tmp, 1e-12, QD_S_PSCALE, 1, p.D_crit)) return -1;
+        // P_raw / pos on the margin; the two weighted sums over owned rows only
+        if (band && m > 0) {
+            QdSegs S = qd_segments(c, m);
+            const int own0 = c->own_row0, own1 = c->own_row0 + c->own_nrows;
+            for (int k = 0; k < S.n; ++k) {
+                const QdGeom& G = S.g[k];
+                auto run = [&](int r0, int r1) {
+                    if (r1 <= r0) return;
+                    QdGeom g2 = G; g2.row0 = r0; g2.nrows = r1 - r0;
+                    hipLaunchKernelGGL(k_precip_raw, dim3(1, g2.nrows), blk, 0, c->stream, g2, c->tabs, F[QD_F_U], F[QD_F_V],
+                                       F[QD_F_PCOND], p.a, c->dlat, c->dlon, p.D_crit, p.p_betadiv, c->dscal + QD_S_PSCALE,
+                                       c->dcount, praw, pos, c->red_partial + (size_t)2 * G0.lrows());
+                };
+                const int a0 = G.row0, a1 = G.row0 + G.nrows;
+                if (a1 <= own0 || a0 >= own1) run(a0, a1);
+                else { run(a0, std::max(a0, own0)); run(std::min(a1, own1), a1); }
+            }
+        }
+        hipLaunchKernelGGL(k_precip_raw, dim3(1, Gown.nrows), blk, 0, c->stream, Gown, c->tabs, F[QD_F_U], F[QD_F_V],
+                           F[QD_F_PCOND], p.a, c->dlat, c->dlon, p.D_crit, p.p_betadiv, c->dscal + QD_S_PSCALE, c->dcount, praw,
+                           pos, c->red_partial);
+        qd_mark(c, {praw, pos}, m);
+        if (band) {
+            hipLaunchKernelGGL(k_precip_rawsums, dim3(1), blk, 0, c->stream, c->red_partial, Gown.nrows, c->dscal + QD_S_TMP0);
+            if (qd_allreduce_f64(c, c->dscal + QD_S_TMP0, 2, 0)) return -1;
+            hipLaunchKernelGGL(k_precip_scalars_post, dim3(1), dim3(64), 0, c->stream, c->dscal + QD_S_TMP0, c->wsum_all, p.pq_min,
+                               p.p_blend, p.p_hybrid_fallback, c->dscal + QD_S_RENORM);
+        } else {
+            hipLaunchKernelGGL(k_precip_scalars, dim3(1), blk, 0, c->stream, c->red_partial, Gown.nrows, c->wsum_all, p.pq_min,
+                               p.p_blend, p.p_hybrid_fallback, c->dscal + QD_S_RENORM);
+        }
         // P = gaussian(P_raw * s); P_dyn = gaussian(k_precip * pos)
-        hipLaunchKernelGGL(k_scale_field, grid, blk, 0, c->stream, G, praw, c->dscal + QD_S_RENORM, 0.0, praw);
-        if (qd_gaussian(c, praw, praw, tmp, 1.0, 0)) return -1;
-        hipLaunchKernelGGL(k_scale_field, grid, blk, 0, c->stream, G, pos, (const double*)nullptr, p.k_precip, pdyn);
-        if (qd_gaussian(c, pdyn, pdyn, tmp, 1.0, 0)) return -1;
-        hipLaunchKernelGGL(k_precip_blend, grid, blk, 0, c->stream, G, praw, pdyn, c->dscal + QD_S_RENORM, precip);
+        QD_ROWS(c, m, G, hipLaunchKernelGGL(k_scale_field, qd_grid2d(G), blk, 0, c->stream, G, praw, c->dscal + QD_S_RENORM, 0.0, praw));
+        QD_ROWS(c, m, G, hipLaunchKernelGGL(k_scale_field, qd_grid2d(G), blk, 0, c->stream, G, pos, (const double*)nullptr,
+                                            p.k_precip, pdyn));
+        qd_mark(c, {pdyn}, m);
+        const int mg = qd_plan(c, {QD_IN(praw, R1), QD_IN(pdyn, R1)});
+        if (mg < 0) return -1;
+        if (qd_gaussian(c, praw, praw, tmp, 1.0, 0, mg)) return -1;
+        if (qd_gaussian(c, pdyn, pdyn, tmp, 1.0, 0, mg)) return -1;
+        QD_ROWS(c, mg, G, hipLaunchKernelGGL(k_precip_blend, qd_grid2d(G), blk, 0, c->stream, G, praw, pdyn,
+                                             c->dscal + QD_S_RENORM, F[QD_F_PRECIP]));
+        qd_mark(c, {F[QD_F_PRECIP]}, mg);
     }
     {
         QdScope sc(c, "phys_cloud");
         if (isset(p.pref) && p.pref != 0.0) {
             hipMemcpyAsync(c->dscal + QD_S_MED_OUT, &p.pref, sizeof(double), hipMemcpyHostToDevice, c->stream);
         } else {
-            qd_median_positive_dev(c, precip, 1e-6, QD_S_MED_OUT, 0, 0.0);
+            if (qd_median_positive_dev(c, F[QD_F_PRECIP], 1e-6, QD_S_MED_OUT, 0, 0.0)) return -1;
         }
-        hipLaunchKernelGGL(k_cloud_from_p, grid, blk, 0, c->stream, G, precip, c->dscal + QD_S_MED_OUT, p.cmax, cfp);
-        if (qd_gaussian(c, cfp, cfp, tmp, 1.0, 0)) return -1;
-        hipLaunchKernelGGL(k_clip01, grid, blk, 0, c->stream, G, cfp);
-        hipLaunchKernelGGL(k_cloud_source, grid, blk, 0, c->stream, G, c->tabs, c->f[QD_F_U], c->f[QD_F_V], c->f[QD_F_TS],
-                           p.a, c->dlat, c->dlon, src);
-        if (qd_gaussian(c, src, src, tmp, 1.0, 0)) return -1;
-        hipLaunchKernelGGL(k_clip01, grid, blk, 0, c->stream, G, src);
+        double*& cfp = F[QD_F_CLOUD_FROM_P];
+        double*& src = F[QD_F_CLOUD_SRC];
+        int m = qd_plan(c, {QD_IN(F[QD_F_PRECIP], 0)});
+        if (m < 0) return -1;
+        QD_ROWS(c, m, G, hipLaunchKernelGGL(k_cloud_from_p, qd_grid2d(G), blk, 0, c->stream, G, F[QD_F_PRECIP],
+                                            c->dscal + QD_S_MED_OUT, p.cmax, cfp));
+        qd_mark(c, {cfp}, m);
+        int ms = qd_plan(c, {QD_IN(F[QD_F_U], 1), QD_IN(F[QD_F_V], 1), QD_IN(F[QD_F_TS], 1)});
+        if (ms < 0) return -1;
+        QD_ROWS(c, ms, G, hipLaunchKernelGGL(k_cloud_source, qd_grid2d(G), blk, 0, c->stream, G, c->tabs, F[QD_F_U], F[QD_F_V],
+                                             F[QD_F_TS], p.a, c->dlat, c->dlon, src));
+        qd_mark(c, {src}, ms);
+        const int mg = qd_plan(c, {QD_IN(cfp, R1), QD_IN(src, R1), QD_IN(F[QD_F_CLOUD], 0)});
+        if (mg < 0) return -1;
+        if (qd_gaussian(c, cfp, cfp, tmp, 1.0, 0, mg)) return -1;
+        QD_ROWS(c, mg, G, hipLaunchKernelGGL(k_clip01, qd_grid2d(G), blk, 0, c->stream, G, cfp));
+        if (qd_gaussian(c, src, src, tmp, 1.0, 0, mg)) return -1;
+        QD_ROWS(c, mg, G, hipLaunchKernelGGL(k_clip01, qd_grid2d(G), blk, 0, c->stream, G, src));
         double wm = p.w_mem, wp = p.w_p, ws = p.w_src, wsum = wm + wp + ws;
         if (wsum <= 0) { wm = 0.5; wp = 0.4; ws = 0.1; wsum = 1.0; }
         wm /= wsum; wp /= wsum; ws /= wsum;
         QdBlendP B{wm, wp, ws, dt / (6 * 3600), p.cloud_from_p_floor};
-        hipLaunchKernelGGL(k_cloud_blend, grid, blk, 0, c->stream, G, B, cfp, src, c->f[QD_F_CLOUD]);
+        QD_ROWS(c, mg, G, hipLaunchKernelGGL(k_cloud_blend, qd_grid2d(G), blk, 0, c->stream, G, B, cfp, src, F[QD_F_CLOUD]));
+        qd_mark(c, {F[QD_F_CLOUD]}, mg);
     }
     {
         QdScope sc(c, "phys_albedo");
-        double* adv = qd_scratch(c, 7);
+        double*& adv = c->scratch[7];
+        int m;
         if (p.cloud_advect) {
-            qd_launch_advect(c, c->f[QD_F_U], c->f[QD_F_V], c->tabs.cos05, dt, c->f[QD_F_CLOUD], adv, nullptr, nullptr, 1.0, 0);
-            if (p.cloud_smooth_sigma > 0.0) { if (qd_gaussian(c, adv, adv, tmp, p.cloud_smooth_sigma, 1)) return -1; }
+            const int ma = qd_plan(c, {QD_IN(F[QD_F_CLOUD], Rc), QD_IN(F[QD_F_U], 0), QD_IN(F[QD_F_V], 0)});
+            if (ma < 0) return -1;
+            qd_launch_advect(c, F[QD_F_U], F[QD_F_V], c->tabs.cos05, dt, F[QD_F_CLOUD], adv, nullptr, nullptr, 1.0, 0, ma);
+            if (p.cloud_smooth_sigma > 0.0) {
+                const int rs = qd_gauss_radius(p.cloud_smooth_sigma);
+                const int mb = qd_plan(c, {QD_IN(adv, rs)});
+                if (mb < 0) return -1;
+                if (qd_gaussian(c, adv, adv, tmp, p.cloud_smooth_sigma, 1, mb)) return -1;
+            }
+            m = qd_plan(c, {QD_IN(adv, 0), QD_IN(F[QD_F_CLOUD], 0), QD_IN(F[QD_F_HICE], 0)});
+        } else {
+            m = qd_plan(c, {QD_IN(F[QD_F_CLOUD], 0), QD_IN(F[QD_F_HICE], 0)});
         }
+        if (m < 0) return -1;
+        if (c->cloud_eff_valid) { const int me = qd_plan(c, {QD_IN(F[QD_F_CLOUD_EFF], 0)}); if (me < 0) return -1; m = std::min(m, me); }
         QdAlbP A{p.cloud_adv_alpha, std::max(1e-6, p.hice_ref), p.alpha_ice, p.alpha_cloud, p.alpha_water,
                  p.cloud_advect ? 1 : 0, p.use_topo_albedo ? 1 : 0};
-        hipLaunchKernelGGL(k_cloud_albedo, grid, blk, 0, c->stream, G, A, adv, c->f[QD_F_CLOUD],
-                           c->cloud_eff_valid ? c->f[QD_F_CLOUD_EFF] : (const double*)nullptr, c->f[QD_F_HICE],
-                           c->f[QD_F_BASE_ALBEDO], c->land, c->f[QD_F_ALBEDO]);
+        QD_ROWS(c, m, G, hipLaunchKernelGGL(k_cloud_albedo, qd_grid2d(G), blk, 0, c->stream, G, A, adv, F[QD_F_CLOUD],
+                                            c->cloud_eff_valid ? F[QD_F_CLOUD_EFF] : (const double*)nullptr, F[QD_F_HICE],
+                                            F[QD_F_BASE_ALBEDO], c->land, F[QD_F_ALBEDO]));
+        qd_mark(c, {F[QD_F_CLOUD], F[QD_F_ALBEDO]}, m);
     }
     return 0;
 }

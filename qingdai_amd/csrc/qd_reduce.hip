@@ -71,11 +71,12 @@ k_reduce_stage2(const double* __restrict__ partial, int n, int ismax, double* __
 
 // reduce a resident field into device scalar slot; optionally copy to host (synchronises)
 int qd_reduce_field(qd_ctx* c, const double* x, int op, double* host_out) {
-    const QdGeom& G = c->geo;
+    const QdGeom G = qd_segments(c, 0).g[0];                 // owned rows only: a sum must not count halo rows
     dim3 grid(1, G.nrows);
     hipLaunchKernelGGL(k_reduce_stage1, grid, dim3(QD_BLOCK), 0, c->stream, G, x, c->tabs.warea, op, c->red_partial);
     hipLaunchKernelGGL(k_reduce_stage2, dim3(1), dim3(QD_BLOCK), 0, c->stream, c->red_partial, G.nrows,
                        op >= 2 ? 1 : 0, c->dscal + QD_S_TMP0);
+    if (qd_allreduce_f64(c, c->dscal + QD_S_TMP0, 1, op >= 2 ? 1 : 0)) return -1;
     if (host_out) {
         QD_HIP(c, hipMemcpyAsync(c->hpin, c->dscal + QD_S_TMP0, sizeof(double), hipMemcpyDeviceToHost, c->stream));
         QD_HIP(c, hipStreamSynchronize(c->stream));
@@ -106,7 +107,10 @@ __device__ __forceinline__ double qd_med_value(double x, int transform, double t
 // sel_state: [0] count of positives, [1] prefix_lo, [2] rank_lo, [3] prefix_hi, [4] rank_hi, [6] ticket
 __global__ void __launch_bounds__(QD_BLOCK)
 k_sel_pass(QdGeom G, const double* __restrict__ x, int transform, double tparam, unsigned long long* st,
-           unsigned int* hist, int shift, int width, int first) {
+           unsigned int* hist, int shift, int width, int first, int mode) {
+    // mode 0: histogram + scan by the last workgroup (single GPU)
+    // mode 1: histogram only   mode 2: scan only (one workgroup) -- latitude bands all-reduce the
+    //         histogram between the two
     __shared__ unsigned int sh[2 * QD_HIST_BINS];
     __shared__ unsigned int csum[2][QD_BLOCK];
     __shared__ unsigned long long s_st[8];
@@ -114,6 +118,7 @@ k_sel_pass(QdGeom G, const double* __restrict__ x, int transform, double tparam,
     const int t = threadIdx.x;
     const unsigned long long n0 = __hip_atomic_load(&st[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!first && n0 == 0ull) return;                        // no positive entry: nothing to refine
+    if (mode != 2) {
     for (int k = t; k < 2 * QD_HIST_BINS; k += QD_BLOCK) sh[k] = 0u;
     const unsigned long long plo = __hip_atomic_load(&st[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long phi = __hip_atomic_load(&st[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -136,6 +141,7 @@ k_sel_pass(QdGeom G, const double* __restrict__ x, int transform, double tparam,
     unsigned int sink = 0u;
     for (int k = t; k < 2 * QD_HIST_BINS; k += QD_BLOCK) if (sh[k]) sink += atomicAdd(&hist[k], sh[k]);
     asm volatile("s_waitcnt vmcnt(0)" ::"v"(sink) : "memory");
+    if (mode == 1) return;
     __syncthreads();
     if (t == 0) {
         const unsigned long long ticket = atomicAdd(&st[6], 1ull);
@@ -143,6 +149,7 @@ k_sel_pass(QdGeom G, const double* __restrict__ x, int transform, double tparam,
     }
     __syncthreads();
     if (!s_last) return;
+    }   // mode != 2
     // ---- last workgroup: scan
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     const int per = QD_HIST_BINS / QD_BLOCK;
@@ -202,14 +209,23 @@ __global__ void k_sel_finish(unsigned long long* st, double dflt, double* out, u
 
 // median of the positive entries of x (after `transform`) -> device scalar slot; `dflt` if none
 int qd_median_positive_dev(qd_ctx* c, const double* x, double dflt, int slot, int transform, double tparam) {
-    const QdGeom& G = c->geo;
+    const QdGeom G = qd_segments(c, 0).g[0];                 // owned rows only
     // digits from the top: bits 63..53, 52..42, 41..31, 30..20 (11 wide), 19..10, 9..0 (10 wide)
     const int shifts[6] = {53, 42, 31, 20, 10, 0};
     const int widths[6] = {11, 11, 11, 11, 10, 10};
     dim3 grid(1, G.nrows);
-    for (int p = 0; p < 6; ++p)
-        hipLaunchKernelGGL(k_sel_pass, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, c->sel_state, c->hist,
-                           shifts[p], widths[p], p == 0 ? 1 : 0);
+    for (int p = 0; p < 6; ++p) {
+        if (c->geo.full) {
+            hipLaunchKernelGGL(k_sel_pass, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, c->sel_state,
+                               c->hist, shifts[p], widths[p], p == 0 ? 1 : 0, 0);
+        } else {
+            hipLaunchKernelGGL(k_sel_pass, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, c->sel_state,
+                               c->hist, shifts[p], widths[p], p == 0 ? 1 : 0, 1);
+            if (qd_allreduce_u32(c, c->hist, 2 * QD_HIST_BINS)) return -1;
+            hipLaunchKernelGGL(k_sel_pass, dim3(1, 1), dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, c->sel_state,
+                               c->hist, shifts[p], widths[p], p == 0 ? 1 : 0, 2);
+        }
+    }
     hipLaunchKernelGGL(k_sel_finish, dim3(1), dim3(64), 0, c->stream, c->sel_state, dflt, c->dscal + slot, c->dcount);
     return 0;
 }

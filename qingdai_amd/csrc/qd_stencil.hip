@@ -41,22 +41,28 @@ k_hyper_apply(QdGeom G, QdFieldList fl, const double* __restrict__ cosf, double 
     fl.out[f][o] = qd_nn(F0 - (k4 * L2) * sub_dt);
 }
 
-void qd_launch_laplacian(qd_ctx* c, const QdFieldList& fl, const double* coslat) {
+void qd_launch_laplacian(qd_ctx* c, const QdFieldList& fl, const double* coslat, int m) {
     QdScope sc(c, c->lap_tag);
-    hipLaunchKernelGGL(k_laplacian, qd_grid2d(c->geo, fl.n), dim3(QD_BLOCK), 0, c->stream,
-                       c->geo, fl, coslat, c->dlat, c->dlon, c->p.a);
+    QD_ROWS(c, m, G, hipLaunchKernelGGL(k_laplacian, qd_grid2d(G, fl.n), dim3(QD_BLOCK), 0, c->stream,
+                                        G, fl, coslat, c->dlat, c->dlon, c->p.a));
 }
-void qd_launch_hyper_apply(qd_ctx* c, const QdFieldList& fl, const double* coslat, double sub_dt) {
+void qd_launch_hyper_apply(qd_ctx* c, const QdFieldList& fl, const double* coslat, double sub_dt, int m) {
     QdScope sc(c, c->hyp_tag);
-    hipLaunchKernelGGL(k_hyper_apply, qd_grid2d(c->geo, fl.n), dim3(QD_BLOCK), 0, c->stream,
-                       c->geo, fl, coslat, c->dlat, c->dlon, c->p.a, sub_dt);
+    QD_ROWS(c, m, G, hipLaunchKernelGGL(k_hyper_apply, qd_grid2d(G, fl.n), dim3(QD_BLOCK), 0, c->stream,
+                                        G, fl, coslat, c->dlat, c->dlon, c->p.a, sub_dt));
 }
+
+// lat reach (rows) of the semi-Lagrangian gather for winds up to vmax, + the bilinear neighbour
+int qd_adv_reach(const qd_ctx* c, double dt, double vmax) {
+    return (int)std::ceil(vmax * dt / (c->p.a * c->dlat)) + 1;
+}
+int qd_gauss_radius(double sigma) { return sigma > 1e-15 ? (int)(4.0 * sigma + 0.5) : 0; }
 
 // _hyperdiffuse on up to QD_MAXF resident fields, in place (pointer swap with scratch).
 // k4tab: [n][nlat] per-row maps; skip[f] != 0 -> field untouched (k4 <= 0 early-out);
 // k4s_override[f] not NaN -> scalar coefficient instead of the row map.
 int qd_hyperdiffuse_fields(qd_ctx* c, double** fields, int n, const double* k4tab, const int* skip,
-                           const double* k4s_override, double dt, int nsub, const double* coslat) {
+                           const double* k4s_override, double dt, int nsub, const double* coslat, int m_out) {
     if (dt <= 0.0) return 0;
     QdFieldList a; a.n = 0;
     int idx[QD_MAXF];
@@ -75,14 +81,16 @@ int qd_hyperdiffuse_fields(qd_ctx* c, double** fields, int n, const double* k4ta
     const int ns = nsub < 1 ? 1 : nsub;
     const double sub_dt = dt / ns;
     for (int s = 0; s < ns; ++s) {
-        qd_launch_laplacian(c, a, coslat);
+        const int m_apply = m_out + 4 * (ns - 1 - s);          // each sub-step eats 2 + 2 rows of margin
+        qd_launch_laplacian(c, a, coslat, m_apply + 2);
         QdFieldList b = a;
         for (int k = 0; k < a.n; ++k) {
             b.in[k] = a.out[k];                           // L1
             b.out[k] = qd_scratch(c, QD_MAXF + k);        // new F
             b.aux[k] = a.in[k];
         }
-        qd_launch_hyper_apply(c, b, coslat, sub_dt);
+        qd_launch_hyper_apply(c, b, coslat, sub_dt, m_apply);
+        for (int k = 0; k < a.n; ++k) qd_mark(c, {b.out[k]}, m_apply);
         // new F becomes the field: copy pointer roles (swap field storage with scratch slot)
         for (int k = 0; k < a.n; ++k) {
             double* newF = b.out[k];
@@ -118,17 +126,18 @@ k_shapiro_pass(QdGeom G, QdFieldList fl, int scrub) {
     fl.out[f][(size_t)qd_lrow(G, i) * G.nlon + j] = (lc[0] * 0.25 + lc[1] * 0.5) + lc[2] * 0.25;
 }
 
-void qd_launch_shapiro_pass(qd_ctx* c, const QdFieldList& fl, int scrub) {
-    hipLaunchKernelGGL(k_shapiro_pass, qd_grid2d(c->geo, fl.n), dim3(QD_BLOCK), 0, c->stream, c->geo, fl, scrub);
+void qd_launch_shapiro_pass(qd_ctx* c, const QdFieldList& fl, int scrub, int m) {
+    QD_ROWS(c, m, G, hipLaunchKernelGGL(k_shapiro_pass, qd_grid2d(G, fl.n), dim3(QD_BLOCK), 0, c->stream, G, fl, scrub));
 }
 
-int qd_shapiro_fields(qd_ctx* c, double** fields, int n, int npass) {
+int qd_shapiro_fields(qd_ctx* c, double** fields, int n, int npass, int m_out) {
     if (npass < 1) npass = 1;
     QdFieldList a; a.n = n;
     for (int p = 0; p < npass; ++p) {
         for (int k = 0; k < n; ++k) { a.in[k] = fields[k]; a.out[k] = qd_scratch(c, k); a.aux[k] = nullptr; a.k4row[k] = nullptr; a.k4s[k] = 0; }
-        qd_launch_shapiro_pass(c, a, p == 0);
-        for (int k = 0; k < n; ++k) { double* t = fields[k]; fields[k] = c->scratch[k]; c->scratch[k] = t; }
+        const int m = m_out + (npass - 1 - p);
+        qd_launch_shapiro_pass(c, a, p == 0, m);
+        for (int k = 0; k < n; ++k) { double* t = fields[k]; fields[k] = c->scratch[k]; c->scratch[k] = t; qd_mark(c, {fields[k]}, m); }
     }
     return 0;
 }
@@ -161,9 +170,10 @@ k_advect(QdGeom G, const double* __restrict__ u, const double* __restrict__ v, c
 }
 
 void qd_launch_advect(qd_ctx* c, const double* u, const double* v, const double* coslat, double dt,
-                      const double* f0, double* o0, const double* f1, double* o1, double alpha, int clipq) {
-    hipLaunchKernelGGL(k_advect, qd_grid2d(c->geo), dim3(QD_BLOCK), 0, c->stream, c->geo, u, v, coslat, dt,
-                       c->p.a, c->dlat, c->dlon, f0, o0, f1, o1, alpha, clipq);
+                      const double* f0, double* o0, const double* f1, double* o1, double alpha, int clipq, int m) {
+    QD_ROWS(c, m, G, hipLaunchKernelGGL(k_advect, qd_grid2d(G), dim3(QD_BLOCK), 0, c->stream, G, u, v, coslat, dt,
+                                        c->p.a, c->dlat, c->dlon, f0, o0, f1, o1, alpha, clipq));
+    qd_mark(c, {o0, o1}, m);
 }
 
 // ------------------------------------------------------------------ divergence / vorticity
@@ -181,9 +191,10 @@ k_divvort(QdGeom G, QdTabs T, const double* __restrict__ u, const double* __rest
         vort ? qd_divvort_point(G, T, v, u, i, j, a, dlat, dlon, 1) : qd_divvort_point(G, T, u, v, i, j, a, dlat, dlon, 0);
 }
 
-void qd_launch_divvort(qd_ctx* c, const double* u, const double* v, double* out, int vort) {
-    hipLaunchKernelGGL(k_divvort, qd_grid2d(c->geo), dim3(QD_BLOCK), 0, c->stream, c->geo, c->tabs, u, v, out,
-                       c->p.a, c->dlat, c->dlon, vort);
+void qd_launch_divvort(qd_ctx* c, const double* u, const double* v, double* out, int vort, int m) {
+    QD_ROWS(c, m, G, hipLaunchKernelGGL(k_divvort, qd_grid2d(G), dim3(QD_BLOCK), 0, c->stream, G, c->tabs, u, v, out,
+                                        c->p.a, c->dlat, c->dlon, vort));
+    qd_mark(c, {out}, m);
 }
 
 // ------------------------------------------------------------------ Gaussian blur (separable)
@@ -225,9 +236,10 @@ k_gauss_axis(QdGeom G, const double* __restrict__ in, double* __restrict__ out, 
 }
 
 // gaussian_filter(in, sigma, mode): axis 0 then axis 1.  out may alias in; tmp is a distinct slab.
-int qd_gaussian(qd_ctx* c, const double* in, double* out, double* tmp, double sigma, int mode_wrap) {
+int qd_gaussian(qd_ctx* c, const double* in, double* out, double* tmp, double sigma, int mode_wrap, int m_out) {
     if (!(sigma > 1e-15)) {
         if (out != in) hipMemcpyAsync(out, in, c->geo.cells() * sizeof(double), hipMemcpyDeviceToDevice, c->stream);
+        qd_mark(c, {out}, m_out);
         return 0;
     }
     QdGaussW W;
@@ -252,7 +264,9 @@ int qd_gaussian(qd_ctx* c, const double* in, double* out, double* tmp, double si
         for (; k < m; ++k) tot += phi[k];
     }
     for (int k = 0; k <= r; ++k) W.w[k] = phi[r + k] / tot;
-    hipLaunchKernelGGL(k_gauss_axis, qd_grid2d(c->geo), dim3(QD_BLOCK), 0, c->stream, c->geo, in, tmp, W, 0, mode_wrap);
-    hipLaunchKernelGGL(k_gauss_axis, qd_grid2d(c->geo), dim3(QD_BLOCK), 0, c->stream, c->geo, tmp, out, W, 1, mode_wrap);
+    // axis 0 reaches r rows; axis 1 is row-local.  Both passes run on the output margin.
+    QD_ROWS(c, m_out, G, hipLaunchKernelGGL(k_gauss_axis, qd_grid2d(G), dim3(QD_BLOCK), 0, c->stream, G, in, tmp, W, 0, mode_wrap));
+    QD_ROWS(c, m_out, G, hipLaunchKernelGGL(k_gauss_axis, qd_grid2d(G), dim3(QD_BLOCK), 0, c->stream, G, tmp, out, W, 1, mode_wrap));
+    qd_mark(c, {tmp, out}, m_out);
     return 0;
 }

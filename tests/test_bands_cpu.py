@@ -1,0 +1,94 @@
+"""CPU (world_size 2, gloo): the latitude-band host logic -- band ranges, ring neighbours (period
+n_lat at the poles), halo sizing -- exercised with the ORACLE's operators on NumPy slabs.  Each rank
+owns a band + halo, refreshes the halo with a ring send/recv exactly like qd_exchange does, applies
+the global-operator on the rows it can see and must reproduce the whole-globe result on its band."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, nlat, nlon, H, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch
+    import torch.distributed as dist
+    import qd_oracle as qo
+    from qd_oracle import atmos as oat
+    from qingdai_amd.bands import band_ranges
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = qo.Grid(nlat, nlon)
+    r = np.random.default_rng(11)
+    F = 8000.0 + r.normal(0, 5.0, (nlat, nlon))
+    u = r.normal(0, 30.0, (nlat, nlon))
+    v = r.normal(0, 20.0, (nlat, nlon))
+    r0, n = band_ranges(nlat, world)[rank]
+    up, dn = (rank + 1) % world, (rank - 1) % world
+    # local slab: owned rows + H halo rows each side, halos initially garbage
+    slab = np.full((n + 2 * H, nlon), np.nan)
+    slab[H:H + n] = F[r0:r0 + n]
+    # ring exchange (same four messages as qd_exchange): top rows -> up's south halo, bottom rows -> dn's north halo
+    top = torch.from_numpy(slab[n:n + H].copy())
+    bot = torch.from_numpy(slab[H:2 * H].copy())
+    south = torch.empty_like(top)
+    north = torch.empty_like(bot)
+    reqs = [dist.isend(top, up), dist.irecv(south, dn), dist.isend(bot, dn), dist.irecv(north, up)]
+    for rq in reqs:
+        rq.wait()
+    slab[:H] = south.numpy()
+    slab[n + H:] = north.numpy()
+    # every slab row must now equal the global row (r0 - H + l) mod nlat
+    rows = (r0 - H + np.arange(n + 2 * H)) % nlat
+    ok_halo = bool(np.array_equal(slab, F[rows]))
+    # embed into a NaN globe and apply the oracle's del^4 (reach 4) and gather (reach R): owned rows must match
+    globe = np.full((nlat, nlon), np.nan)
+    globe[rows] = slab
+    cos02 = np.maximum(np.cos(np.deg2rad(g.lat_mesh)), 0.2)
+    k4 = 1e14
+    ref = oat.hyperdiffuse(F, k4, 300.0, 1, g.dlat_rad, g.dlon_rad, cos02, 6.371e6)
+    with np.errstate(all="ignore"):
+        Fn = np.where(np.isnan(globe), 1e300, globe)       # poison instead of NaN (nan_to_num would hide NaN)
+        got = oat.hyperdiffuse(Fn, k4, 300.0, 1, g.dlat_rad, g.dlon_rad, cos02, 6.371e6)
+    ok_h4 = bool(np.array_equal(got[r0:r0 + n], ref[r0:r0 + n]))
+    cos6 = np.maximum(1e-6, np.cos(np.deg2rad(g.lat_mesh)))
+    refa = oat.advect_semilag(F, u, v, 300.0, 6.371e6, g.dlat_rad, g.dlon_rad, cos6)
+    gota = oat.advect_semilag(Fn, u, v, 300.0, 6.371e6, g.dlat_rad, g.dlon_rad, cos6)
+    ok_adv = bool(np.array_equal(gota[r0:r0 + n], refa[r0:r0 + n]))
+    q.put((rank, ok_halo, ok_h4, ok_adv))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_band_ranges_and_halo_sizing():
+    from qingdai_amd.bands import band_ranges, required_halo, adv_reach
+    for n, w in ((721, 8), (1441, 8), (37, 3), (181, 2)):
+        rr = band_ranges(n, w)
+        assert rr[0][0] == 0 and sum(k for _, k in rr) == n
+        assert all(rr[i][0] + rr[i][1] == rr[i + 1][0] for i in range(w - 1))
+        assert max(k for _, k in rr) - min(k for _, k in rr) <= 1
+    assert adv_reach(1441, 300.0) == 7 and required_halo(1441) == 22
+    assert required_halo(721) >= 2 * adv_reach(721, 300.0) + 8
+
+
+@pytest.mark.timeout(180)
+def test_ring_halo_exchange_two_ranks_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world, nlat, nlon, H = 2, 37, 48, 6
+    port = 29650 + (os.getpid() % 200)
+    ps = [ctx.Process(target=_worker, args=(r, world, port, nlat, nlon, H, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=150) for _ in range(world)]
+    for p in ps:
+        p.join(timeout=60)
+    for rank, ok_halo, ok_h4, ok_adv in res:
+        assert ok_halo, f"rank {rank}: ring halo rows wrong"
+        assert ok_h4, f"rank {rank}: del^4 on the band differs from the globe"
+        assert ok_adv, f"rank {rank}: gather on the band differs from the globe"

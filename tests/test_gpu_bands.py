@@ -1,0 +1,78 @@
+"""GPU (-m gpu): latitude-band decomposition on ONE device.  N band handles (ring halos, validity
+margins, deep-halo recompute, band-wise reductions / histogram all-reduce) driven by N host threads
+must reproduce the whole-globe handle: bit-for-bit for the atmosphere (no global sums on its path
+except the exact median), to rounding of the eta-mean / weighted sums for the coupled run."""
+import numpy as np
+import pytest
+
+from util import STATE, surface, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(nlat, nlon, over):
+    import qingdai_amd as qa
+    _, mask, alb, fric = surface(nlat, nlon)
+    grid = qa.SphericalGrid(nlat, nlon)
+    p = qa.QdParams(**over)
+    p.has_csmap = 0
+    return qa, grid, mask, alb, fric, p
+
+
+def _seed_state(nlat, nlon, seed):
+    r = np.random.default_rng(seed)
+    lat = np.linspace(-np.pi / 2, np.pi / 2, nlat)[:, None]
+    lon = np.linspace(0, 2 * np.pi, nlon)[None, :]
+    st = {"U": 25.0 * np.cos(lat) * np.sin(2 * lon) + r.normal(0, 3.0, (nlat, nlon)),
+          "V": 8.0 * np.sin(2 * lat) * np.cos(3 * lon) + r.normal(0, 2.0, (nlat, nlon)),
+          "H": 8000.0 + 300 * np.sin(lat) ** 2 + 40.0 * np.cos(lat) * np.cos(2 * lon) + r.normal(0, 2.0, (nlat, nlon)),
+          "TS": 262.0 + 38.0 * np.cos(lat) ** 2 + r.normal(0, 1.0, (nlat, nlon)),
+          "Q": np.clip(0.006 + 0.004 * np.cos(lat) ** 2 + r.normal(0, 5e-4, (nlat, nlon)), 0, 0.5),
+          "CLOUD": np.clip(0.3 + 0.3 * np.sin(3 * lon) * np.cos(lat) + r.normal(0, 0.05, (nlat, nlon)), 0, 1),
+          "HICE": np.where(np.abs(lat) > 1.1, 0.4 + 0.3 * r.random((nlat, nlon)), 0.0)}
+    return st
+
+
+def _run(world, nlat, nlon, nsteps, over, with_ocean, with_phys, seed=3):
+    from qingdai_amd.bands import BandGroup
+    from qingdai_amd.device import Device
+    qa, grid, mask, alb, fric, p = _setup(nlat, nlon, over)
+    forcing = qa.ThermalForcing(qa.SphericalGrid(nlat, nlon), qa.OrbitalSystem())
+    stars = forcing.star_table([i * 300.0 for i in range(nsteps)])
+    st = _seed_state(nlat, nlon, seed)
+    static = {"LAND_MASK": mask, "FRICTION": fric, "BASE_ALBEDO": alb}
+    names = ["U", "V", "H", "TS", "Q", "CLOUD", "HICE"] + (["UO", "VO", "ETA", "SST"] if with_ocean else [])
+    if world == 1:
+        dev = Device(grid, p)
+        for k, v in {**static, **st}.items():
+            dev.upload_now(k, v)
+        dev.step_n(stars, 300.0, with_ocean=with_ocean, with_physics=with_phys, pass_albedo=True)
+        out = {k: dev.get(k).copy() for k in names}
+        dev.close()
+        return out, None
+    grp = BandGroup(grid, world, p)
+    for k, v in {**static, **st}.items():
+        grp.set(k, v)
+    grp.run(lambda d, r: d.step_n(stars, 300.0, with_ocean=with_ocean, with_physics=with_phys, pass_albedo=True))
+    out = {k: grp.get(k) for k in names}
+    ex = grp.exchanges()
+    grp.close()
+    return out, ex
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bands_atmosphere_bit_identical(gpu, world):
+    ref, _ = _run(1, 61, 96, 7, dict(energy_w=1.0), False, False)
+    got, ex = _run(world, 61, 96, 7, dict(energy_w=1.0), False, False)
+    print("halo exchanges per band:", ex)
+    for k in ref:
+        assert np.array_equal(got[k], ref[k]), (k, relerr(got[k], ref[k]))
+
+
+def test_bands_full_step_with_ocean_and_physics(gpu):
+    ref, _ = _run(1, 91, 144, 4, dict(energy_w=1.0, ocean_cfl=0.05), True, True)
+    got, ex = _run(4, 91, 144, 4, dict(energy_w=1.0, ocean_cfl=0.05), True, True)
+    print("halo exchanges per band:", ex)
+    for k in ref:
+        e = relerr(got[k], ref[k])
+        assert e < 1e-12, (k, e)          # only the band-wise order of the global sums differs
