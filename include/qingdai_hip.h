@@ -58,6 +58,8 @@ enum qd_field {
     QD_F_PRECIP, QD_F_CLOUD_FROM_P, QD_F_CLOUD_SRC,
     /* land hydrology reservoirs (run_simulation.py:1289-1290; hydrology.py) */
     QD_F_W_LAND, QD_F_S_SNOW, QD_F_C_SNOW,
+    /* P019 provisional snow / land bucket working fields (run_simulation.py:1946-2019, 2290-2339) */
+    QD_F_S_SNOW_NEXT, QD_F_MELT, QD_F_P_RAIN, QD_F_GLACIER, QD_F_RUNOFF,
     QD_F_COUNT_F64,
     /* uint8 masks */
     QD_F_LAND_MASK = 100, QD_F_ICE_MASK = 101
@@ -85,6 +87,10 @@ typedef struct qd_params {
     /* driver physics: run_simulation.py:1605-1613,1777,1866-1934 */
     double D_crit, k_precip, alpha_water, alpha_ice, alpha_cloud, p_betadiv, pq_min, p_blend;
     double pref, cmax, w_mem, w_p, w_src, cloud_from_p_floor, cloud_adv_alpha, cloud_smooth_sigma;
+    /* land hydrology + P019 lapse / snow: hydrology.py:27-80, run_simulation.py:1616-1627 */
+    double runoff_tau_days, wland_cap_mm, snow_thresh_K, snow_melt_rate_mm_day, snow_t_band_K;
+    double snow_ddf_mm_per_k_day, snow_melt_tref_K, swe_ref_mm, swe_max_mm, snow_albedo_fresh;
+    double lapse_k_kpm, land_elev_max_m, polar_ice_thick_max_m, polar_lat_thresh, rho_snow, glacier_frac, glacier_swe_mm;
     /* integer switches */
     int32_t seaice_enabled, cloud_couple, lw_v2, gh_lock, polar_freeze_fix_s, polar_freeze_fix_n;
     int32_t mom_scheme;        /* 0 geos, 1 primitive (QD_MOM_SCHEME) */
@@ -94,7 +100,8 @@ typedef struct qd_params {
     int32_t ocean_outlier;     /* 0 mean4, 1 clamp */
     int32_t ocean_use_qnet, ocean_polar_fix;
     int32_t p_hybrid_fallback, cloud_advect, use_topo_albedo, has_csmap;
-    int32_t _pad;
+    int32_t snow_melt_mode;    /* 0 degree_day, 1 constant (QD_SNOW_MELT_MODE) */
+    int32_t swe_enable, lapse_enable;
 } qd_params;
 
 /* ---- lifetime ------------------------------------------------------------------ */
@@ -129,9 +136,11 @@ int qd_ocean_step(qd_handle h, double dt, int compute_qnet, int use_ice_mask, in
 /* run_simulation.py:1766-1934,2063-2146: hybrid precipitation, cloud-from-precip, cloud source,
  * cloud blend + advection, dynamic albedo (physics.py:12-354). */
 int qd_driver_physics(qd_handle h, double dt);
+/* run_simulation.py:2290-2339: commit the provisional snowpack, update the land bucket (hydrology.py:219-260) */
+int qd_hydrology_commit(qd_handle h, double dt);
 /* benchmark_jax.py:124-158 as one resident loop of n steps: forcing -> albedo -> time_step [-> ocean
- * coupling].  flags bit0 = with_ocean, bit1 = with_driver_physics (else the simple ocean/land albedo of
- * benchmark_jax.py:129), bit2 = pass albedo to time_step.  `stars` holds n rows of 7 host scalars
+ * coupling] [-> hydrology commit].  flags bit0 = with_ocean, bit1 = with_driver_physics (else the simple
+ * ocean/land albedo of benchmark_jax.py:129), bit2 = pass albedo to time_step, bit3 = hydrology commit.  `stars` holds n rows of 7 host scalars
  * (flux_A, decl_A, ra_A, flux_B, decl_B, ra_B, theta), evaluated by the caller as forcing.py:85-125 does. */
 int qd_step_n(qd_handle h, int n, double dt, int flags, const double* stars);
 int qd_last_ocean_nsub(qd_handle h, int* n_sub);

@@ -67,6 +67,14 @@ def defaults(**over):
         pref=NAN, cmax=0.95, w_mem=0.4, w_p=0.4, w_src=0.2,
         cloud_from_p_floor=0.8, cloud_advect=1, cloud_adv_alpha=0.7,
         cloud_smooth_sigma=0.2, use_topo_albedo=1,
+        # ---- land hydrology / P019 lapse + snow (hydrology.py:27-80; run_simulation.py:1616-1627)
+        runoff_tau_days=10.0, wland_cap_mm=NAN, snow_thresh_K=273.15, snow_melt_rate_mm_day=5.0,
+        snow_t_band_K=1.5, snow_ddf_mm_per_k_day=3.0, snow_melt_tref_K=273.15, swe_ref_mm=15.0,
+        swe_max_mm=NAN, snow_albedo_fresh=0.70,
+        lapse_k_kpm=6.5, land_elev_max_m=10000.0, polar_ice_thick_max_m=4500.0, polar_lat_thresh=60.0,
+        rho_snow=300.0, glacier_frac=0.60, glacier_swe_mm=50.0,
+        snow_melt_mode=0,      # 0 = degree_day, 1 = constant
+        swe_enable=1, lapse_enable=1,
     )
     for k, v in over.items():
         if not hasattr(p, k):

@@ -18,7 +18,8 @@ LIB_PATH = os.path.join(_HERE, "libqingdai_hip.so")
 # field ids (enum qd_field)
 FIELDS = ["U", "V", "H", "TS", "Q", "CLOUD", "HICE", "ISR", "ISR_A", "ISR_B", "TEQ", "ALBEDO",
           "OLR", "EFLUX", "PCOND", "LH", "LHREL", "CLOUD_EFF", "FRICTION", "CSMAP", "BASE_ALBEDO", "ELEVATION",
-          "UO", "VO", "ETA", "SST", "QNET", "PRECIP", "CLOUD_FROM_P", "CLOUD_SRC", "W_LAND", "S_SNOW", "C_SNOW"]
+          "UO", "VO", "ETA", "SST", "QNET", "PRECIP", "CLOUD_FROM_P", "CLOUD_SRC", "W_LAND", "S_SNOW", "C_SNOW",
+          "S_SNOW_NEXT", "MELT", "P_RAIN", "GLACIER", "RUNOFF"]
 F = {n: i for i, n in enumerate(FIELDS)}
 F["LAND_MASK"] = 100
 F["ICE_MASK"] = 101
@@ -28,7 +29,7 @@ R_SUM, R_COSMEAN, R_MAX, R_MIN, R_MAXABS = 0, 1, 2, 3, 4
 SYMBOLS = [
     "qd_abi_version", "qd_create", "qd_destroy", "qd_last_error", "qd_upload", "qd_download", "qd_set_params",
     "qd_get_step_counter", "qd_set_step_counter", "qd_forcing", "qd_simple_albedo", "qd_atmos_step",
-    "qd_ocean_step", "qd_driver_physics", "qd_step_n", "qd_last_ocean_nsub", "qd_sync",
+    "qd_ocean_step", "qd_driver_physics", "qd_hydrology_commit", "qd_step_n", "qd_last_ocean_nsub", "qd_sync",
     "qd_op_laplacian", "qd_op_hyperdiffuse", "qd_op_advect", "qd_op_shapiro", "qd_op_divergence",
     "qd_op_vorticity", "qd_op_gaussian", "qd_op_median_positive", "qd_reduce",
     "qd_comm_unique_id", "qd_comm_init", "qd_comm_init_local", "qd_comm_stats", "qd_comm_barrier", "qd_comm_allreduce_max",
@@ -73,6 +74,7 @@ def load():
     lib.qd_atmos_step.argtypes = [vp, dbl, i32]
     lib.qd_ocean_step.argtypes = [vp, dbl, i32, i32, i32]
     lib.qd_driver_physics.argtypes = [vp, dbl]
+    lib.qd_hydrology_commit.argtypes = [vp, dbl]
     lib.qd_step_n.argtypes = [vp, i32, dbl, i32, dp]
     lib.qd_last_ocean_nsub.argtypes = [vp, ctypes.POINTER(i32)]
     lib.qd_sync.argtypes = [vp]

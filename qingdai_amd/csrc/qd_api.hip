@@ -111,6 +111,7 @@ static int build_tables(qd_ctx* c) {
     T.cos_raw = dev_table(c, cr); T.sin_raw = dev_table(c, sr); T.cos6 = dev_table(c, c6); T.cos3 = dev_table(c, c3);
     T.cos02 = dev_table(c, c02); T.cos05 = dev_table(c, c05); T.fcor = dev_table(c, fc); T.warea = dev_table(c, wa);
     T.r_extra = dev_table(c, rx);
+    T.lat_deg = dev_table(c, lat);
     T.lon_rad = dev_table(c, lr); T.sin_lon = dev_table(c, sl); T.cos_lon = dev_table(c, cl);
     if (!T.cos_raw || !T.lon_rad || !T.cos_lon) return -1;
     double ws = 0.0;
@@ -416,10 +417,20 @@ extern "C" int qd_driver_physics(qd_handle c, double dt) {
     return 0;
 }
 
+extern "C" int qd_hydrology_commit(qd_handle c, double dt) {
+    if (!c) return -1;
+    hipSetDevice(c->desc.device);
+    int rc = qd_hydrology_commit_impl(c, dt);
+    if (rc) return rc;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return qd_fail(c, "qd_hydrology_commit: launch", e);
+    return 0;
+}
+
 extern "C" int qd_step_n(qd_handle c, int n, double dt, int flags, const double* stars) {
     if (!c || !stars) return -1;
     hipSetDevice(c->desc.device);
-    const int with_ocean = flags & 1, with_phys = flags & 2, pass_alb = flags & 4;
+    const int with_ocean = flags & 1, with_phys = flags & 2, pass_alb = flags & 4, with_hydro = flags & 8;
     for (int s = 0; s < n; ++s) {
         const double* st = stars + (size_t)7 * s;
         int rc;
@@ -428,6 +439,7 @@ extern "C" int qd_step_n(qd_handle c, int n, double dt, int flags, const double*
         if ((rc = qd_forcing_impl(c, st, st + 3, st[6], 1))) return rc;
         if ((rc = qd_atmos_step_impl(c, dt, pass_alb ? 1 : 0))) return rc;
         if (with_ocean && (rc = qd_ocean_step_impl(c, dt, 1, 1, 1))) return rc;
+        if (with_hydro && (rc = qd_hydrology_commit_impl(c, dt))) return rc;
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return qd_fail(c, "qd_step_n: launch", e);

@@ -55,6 +55,7 @@ struct QdTabs {
     const double* mom_cv;    //   g / (f_safe a)         geostrophic v_g coefficient
     const double* mom_px;    // -(g / (a cos6))          primitive PGF_x coefficient
     const double* ocn_igx;   // 1 / (a cos05)
+    const double* lat_deg;   // np.linspace(-90, 90, n_lat)
     const double* lon_rad;   // deg2rad(lon) [n_lon]
     const double* sin_lon;   // [n_lon]
     const double* cos_lon;   // [n_lon]
@@ -248,6 +249,7 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
 
 // qd_physics.hip
 int qd_driver_physics_impl(qd_ctx* c, double dt);
+int qd_hydrology_commit_impl(qd_ctx* c, double dt);
 
 // qd_api.hip
 int qd_build_k4_tables(qd_ctx* c, double dt, bool ocean, double sub_dt);

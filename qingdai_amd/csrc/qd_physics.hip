@@ -160,13 +160,14 @@ k_cloud_blend(QdGeom G, QdBlendP P, const double* __restrict__ cfp, const double
     cloud[o] = qd_clip(c, 0.0, 1.0);
 }
 
-struct QdAlbP { double alpha, hice_ref_safe, alpha_ice, alpha_cloud, alpha_water; int do_adv, use_topo; };
+struct QdAlbP { double alpha, hice_ref_safe, alpha_ice, alpha_cloud, alpha_water, alpha_snow; int do_adv, use_topo, snow; };
 
 // cloud <- clip((1-a) cloud + a adv, 0, 1)  and  the dynamic albedo (physics.py:164-250)
 __global__ void __launch_bounds__(QD_BLOCK)
 k_cloud_albedo(QdGeom G, QdAlbP P, const double* __restrict__ adv, double* __restrict__ cloud,
                const double* __restrict__ cloud_eff, const double* __restrict__ hice,
-               const double* __restrict__ base, const uint8_t* __restrict__ land, double* __restrict__ albedo) {
+               const double* __restrict__ base, const uint8_t* __restrict__ land, const double* __restrict__ csnow,
+               double* __restrict__ albedo) {
     const QdTile tl = qd_tile();
     const int j = tl.seg * QD_BLOCK + threadIdx.x;
     if (j >= G.nlon) return;
@@ -178,7 +179,11 @@ k_cloud_albedo(QdGeom G, QdAlbP P, const double* __restrict__ adv, double* __res
     const double ice_frac = 1.0 - exp(-qd_max(hice[o], 0.0) / P.hice_ref_safe);
     double fi = qd_clip(ice_frac, 0.0, 1.0);
     fi = fi * ((land[o] == 0) ? 1.0 : 0.0);
-    const double b0 = P.use_topo ? base[o] : P.alpha_water;
+    double b0 = P.use_topo ? base[o] : P.alpha_water;
+    if (P.snow && land[o] == 1) {                            // run_simulation.py:2130-2141: snow cover over land
+        const double cs = csnow[o];
+        b0 = qd_clip((1.0 - cs) * b0 + cs * P.alpha_snow, 0.0, 1.0);
+    }
     const double surf = b0 * (1.0 - fi) + P.alpha_ice * fi;
     albedo[o] = qd_clip(surf * (1.0 - C) + P.alpha_cloud * C, 0.0, 1.0);
 }
@@ -206,6 +211,105 @@ k_precip_rawsums(const double* __restrict__ partial, int n, double* __restrict__
         for (int k = 1; k < QD_BLOCK / 64; ++k) { a += sm[0][k]; b += sm[1][k]; }
         out[0] = a; out[1] = b;
     }
+}
+
+// ------------------------------------------------------------------ P019 lapse + snow, land bucket
+struct QdSnowP {
+    double dt, ga, rho_snow_safe, polar_lat, ice_max, elev_max, gamma, t_thresh, dT, ddf_s, tref, rate_s, swe_max, swe_ref_safe,
+           gl_frac, gl_swe;
+    int lapse, mode, swe;
+};
+
+// run_simulation.py:1946-2019 + hydrology.py:100-177: lapse-adjusted air temperature, sigmoid rain/snow
+// split, provisional snowpack (degree-day | constant melt), optical snow cover, glacier mask
+__global__ void __launch_bounds__(QD_BLOCK)
+k_snow_provisional(QdGeom G, QdTabs T, QdSnowP P, const double* __restrict__ precip, const double* __restrict__ h,
+                   const double* __restrict__ S_snow, const double* __restrict__ elev, const uint8_t* __restrict__ land,
+                   double* __restrict__ P_rain, double* __restrict__ S_next, double* __restrict__ melt,
+                   double* __restrict__ C_snow, double* __restrict__ glacier) {
+    const QdTile tl = qd_tile();
+    const int j = tl.seg * QD_BLOCK + threadIdx.x;
+    if (j >= G.nlon) return;
+    const int i = G.row0 + tl.row;
+    const size_t o = (size_t)qd_lrow(G, i) * G.nlon + j;
+    const bool is_land = land[o] == 1;
+    const double T_a = 288.0 + P.ga * h[o];
+    const double S0 = S_snow[o];
+    const double h_snow = is_land ? qd_max(S0, 0.0) / P.rho_snow_safe : 0.0;
+    const bool polar = fabs(T.lat_deg[i]) >= P.polar_lat;
+    const double h_ice_eff = polar ? qd_min(h_snow, P.ice_max) : h_snow;
+    const double H_eff = qd_min(elev[o] + h_ice_eff, P.elev_max);
+    const double T_hat = P.lapse ? T_a - P.gamma * (H_eff / 1000.0) : T_a;
+    const double Pf = precip[o];
+    double f_snow = 1.0 / (1.0 + exp((T_hat - P.t_thresh) / P.dT));
+    f_snow = qd_clip(f_snow, 0.0, 1.0);
+    const double Ps = qd_nn(f_snow * Pf);
+    const double Pr = qd_nn((1.0 - f_snow) * Pf);
+    P_rain[o] = Pr;
+    if (!P.swe) { S_next[o] = S0; melt[o] = 0.0; C_snow[o] = 0.0; glacier[o] = 0.0; return; }
+    const double Ps_land = Ps * (is_land ? 1.0 : 0.0);
+    double melt_flux;
+    if (P.mode == 0) melt_flux = P.ddf_s * qd_max(T_hat - P.tref, 0.0);
+    else melt_flux = (T_hat >= P.t_thresh) ? P.rate_s : 0.0;
+    const double actual = qd_min(qd_max(S0, 0.0), melt_flux * P.dt);
+    double Sn = S0 + Ps_land * P.dt - actual;
+    if (P.swe_max > 0.0) Sn = qd_min(Sn, P.swe_max);
+    Sn = qd_max(0.0, Sn);
+    const double melt_out = (P.dt > 0) ? actual / P.dt : 0.0;
+    const double Cs = qd_clip(1.0 - exp(-qd_max(Sn, 0.0) / P.swe_ref_safe), 0.0, 1.0);
+    Sn = qd_nn(Sn);
+    const bool gl = is_land && ((Cs >= P.gl_frac) || (Sn >= P.gl_swe));
+    // rain on an ice cap is deposited into the snowpack (run_simulation.py:1996-2001)
+    const double Pr_gl = (Pr * (is_land ? 1.0 : 0.0)) * (gl ? 1.0 : 0.0);
+    if (Pr_gl != 0.0) Sn = Sn + Pr_gl * P.dt;
+    S_next[o] = Sn; melt[o] = qd_nn(melt_out); C_snow[o] = Cs; glacier[o] = gl ? 1.0 : 0.0;
+}
+
+struct QdBucketP { double dt, tau_s, cap; };
+
+// run_simulation.py:2290-2339 + hydrology.py:219-260
+__global__ void __launch_bounds__(QD_BLOCK)
+k_hydro_commit(QdGeom G, QdBucketP P, const double* __restrict__ P_rain, const double* __restrict__ melt,
+               const double* __restrict__ glacier, const double* __restrict__ E, const uint8_t* __restrict__ land,
+               const double* __restrict__ S_next, double* __restrict__ S_snow, double* __restrict__ W_land,
+               double* __restrict__ runoff) {
+    const QdTile tl = qd_tile();
+    const int j = tl.seg * QD_BLOCK + threadIdx.x;
+    if (j >= G.nlon) return;
+    const size_t o = (size_t)qd_lrow(G, G.row0 + tl.row) * G.nlon + j;
+    const double L = land[o] == 1 ? 1.0 : 0.0;
+    const double gl = glacier[o];
+    const double non_gl = (L != 0.0 && gl == 0.0) ? 1.0 : 0.0;
+    const double ml = melt[o];
+    const double P_in = (P_rain[o] * L + ml) * non_gl;
+    const double E_l = (E[o] * L) * non_gl;
+    const double W = W_land[o];
+    const double R_base = W / P.tau_s;
+    double Wn = qd_max(0.0, W + (P_in - E_l - R_base) * P.dt);
+    double R_fast = 0.0;
+    if (P.cap > 0.0) {
+        const double over = qd_max(0.0, Wn - P.cap);
+        Wn = Wn - over;
+        R_fast = (P.dt > 0) ? over / P.dt : 0.0;
+    }
+    W_land[o] = qd_nn(Wn);
+    runoff[o] = qd_nn(R_base + R_fast) + ml * gl;
+    S_snow[o] = S_next[o];
+}
+
+int qd_hydrology_commit_impl(qd_ctx* c, double dt) {
+    const qd_params& p = c->p;
+    double** F = c->f;
+    QdScope sc(c, "hydrology");
+    const int m = qd_plan(c, {QD_IN(F[QD_F_P_RAIN], 0), QD_IN(F[QD_F_MELT], 0), QD_IN(F[QD_F_GLACIER], 0), QD_IN(F[QD_F_EFLUX], 0),
+                              QD_IN(F[QD_F_S_SNOW_NEXT], 0), QD_IN(F[QD_F_W_LAND], 0)});
+    if (m < 0) return -1;
+    QdBucketP B{dt, std::max(1.0, p.runoff_tau_days * 86400.0), (p.wland_cap_mm == p.wland_cap_mm && p.wland_cap_mm > 0) ? p.wland_cap_mm : -1.0};
+    QD_ROWS(c, m, G, hipLaunchKernelGGL(k_hydro_commit, qd_grid2d(G), dim3(QD_BLOCK), 0, c->stream, G, B, F[QD_F_P_RAIN], F[QD_F_MELT],
+                                        F[QD_F_GLACIER], F[QD_F_EFLUX], c->land, F[QD_F_S_SNOW_NEXT], F[QD_F_S_SNOW], F[QD_F_W_LAND],
+                                        F[QD_F_RUNOFF]));
+    qd_mark(c, {F[QD_F_S_SNOW], F[QD_F_W_LAND], F[QD_F_RUNOFF]}, m);
+    return 0;
 }
 
 int qd_driver_physics_impl(qd_ctx* c, double dt) {
@@ -325,11 +429,28 @@ int qd_driver_physics_impl(qd_ctx* c, double dt) {
         }
         if (m < 0) return -1;
         if (c->cloud_eff_valid) { const int me = qd_plan(c, {QD_IN(F[QD_F_CLOUD_EFF], 0)}); if (me < 0) return -1; m = std::min(m, me); }
-        QdAlbP A{p.cloud_adv_alpha, std::max(1e-6, p.hice_ref), p.alpha_ice, p.alpha_cloud, p.alpha_water,
-                 p.cloud_advect ? 1 : 0, p.use_topo_albedo ? 1 : 0};
+        QdAlbP A{p.cloud_adv_alpha, std::max(1e-6, p.hice_ref), p.alpha_ice, p.alpha_cloud, p.alpha_water, p.snow_albedo_fresh,
+                 p.cloud_advect ? 1 : 0, p.use_topo_albedo ? 1 : 0, p.swe_enable ? 1 : 0};
+        // P019 lapse + phase split + provisional snowpack (run_simulation.py:1946-2019): pointwise
+        {
+            const int msn = qd_plan(c, {QD_IN(F[QD_F_PRECIP], 0), QD_IN(F[QD_F_H], 0), QD_IN(F[QD_F_S_SNOW], 0), QD_IN(F[QD_F_ELEVATION], 0)});
+            if (msn < 0) return -1;
+            QdSnowP S;
+            S.dt = dt; S.ga = 9.81 / 1004.0; S.rho_snow_safe = std::max(p.rho_snow, 1e-6); S.polar_lat = p.polar_lat_thresh;
+            S.ice_max = p.polar_ice_thick_max_m; S.elev_max = p.land_elev_max_m; S.gamma = p.lapse_k_kpm; S.lapse = p.lapse_enable;
+            S.t_thresh = p.snow_thresh_K; S.dT = std::max(1e-6, p.snow_t_band_K); S.mode = p.snow_melt_mode;
+            S.ddf_s = p.snow_ddf_mm_per_k_day / 86400.0; S.tref = p.snow_melt_tref_K; S.rate_s = p.snow_melt_rate_mm_day / 86400.0;
+            S.swe_max = (p.swe_max_mm == p.swe_max_mm && p.swe_max_mm > 0) ? p.swe_max_mm : -1.0;
+            S.swe_ref_safe = std::max(1e-6, p.swe_ref_mm); S.gl_frac = p.glacier_frac; S.gl_swe = p.glacier_swe_mm; S.swe = p.swe_enable;
+            QD_ROWS(c, msn, G, hipLaunchKernelGGL(k_snow_provisional, qd_grid2d(G), blk, 0, c->stream, G, c->tabs, S, F[QD_F_PRECIP],
+                                                  F[QD_F_H], F[QD_F_S_SNOW], F[QD_F_ELEVATION], c->land, F[QD_F_P_RAIN],
+                                                  F[QD_F_S_SNOW_NEXT], F[QD_F_MELT], F[QD_F_C_SNOW], F[QD_F_GLACIER]));
+            qd_mark(c, {F[QD_F_P_RAIN], F[QD_F_S_SNOW_NEXT], F[QD_F_MELT], F[QD_F_C_SNOW], F[QD_F_GLACIER]}, msn);
+            m = std::min(m, msn);
+        }
         QD_ROWS(c, m, G, hipLaunchKernelGGL(k_cloud_albedo, qd_grid2d(G), blk, 0, c->stream, G, A, adv, F[QD_F_CLOUD],
                                             c->cloud_eff_valid ? F[QD_F_CLOUD_EFF] : (const double*)nullptr, F[QD_F_HICE],
-                                            F[QD_F_BASE_ALBEDO], c->land, F[QD_F_ALBEDO]));
+                                            F[QD_F_BASE_ALBEDO], c->land, F[QD_F_C_SNOW], F[QD_F_ALBEDO]));
         qd_mark(c, {F[QD_F_CLOUD], F[QD_F_ALBEDO]}, m);
     }
     return 0;

@@ -57,6 +57,14 @@ _DOUBLES = [
     ("w_mem", "QD_W_MEM", 0.4), ("w_p", "QD_W_P", 0.4), ("w_src", "QD_W_SRC", 0.2),
     ("cloud_from_p_floor", "QD_CLOUD_FROM_P_FLOOR", 0.8), ("cloud_adv_alpha", "QD_CLOUD_ADV_ALPHA", 0.7),
     ("cloud_smooth_sigma", "QD_CLOUD_SMOOTH_SIGMA", 0.2),
+    ("runoff_tau_days", "QD_RUNOFF_TAU_DAYS", 10.0), ("wland_cap_mm", "QD_WLAND_CAP", NAN),
+    ("snow_thresh_K", "QD_SNOW_THRESH", 273.15), ("snow_melt_rate_mm_day", "QD_SNOW_MELT_RATE", 5.0),
+    ("snow_t_band_K", "QD_SNOW_T_BAND", 1.5), ("snow_ddf_mm_per_k_day", "QD_SNOW_DDF_MM_PER_K_DAY", 3.0),
+    ("snow_melt_tref_K", "QD_SNOW_MELT_TREF", 273.15), ("swe_ref_mm", "QD_SWE_REF_MM", 15.0),
+    ("swe_max_mm", "QD_SWE_MAX_MM", NAN), ("snow_albedo_fresh", "QD_SNOW_ALBEDO_FRESH", 0.70),
+    ("lapse_k_kpm", "QD_LAPSE_K_KPM", 6.5), ("land_elev_max_m", "QD_LAND_ELEV_MAX_M", 10000.0),
+    ("polar_ice_thick_max_m", "QD_POLAR_ICE_THICK_MAX_M", 4500.0), ("polar_lat_thresh", "QD_POLAR_LAT_THRESH", 60.0),
+    ("rho_snow", "QD_RHO_SNOW", 300.0), ("glacier_frac", "QD_GLACIER_FRAC", 0.60), ("glacier_swe_mm", "QD_GLACIER_SWE_MM", 50.0),
 ]
 # (field, env var, default) -- int32 switches
 _INTS = [
@@ -72,7 +80,8 @@ _INTS = [
     ("ocean_outlier", "QD_OCEAN_OUTLIER", 0), ("ocean_use_qnet", "QD_OCEAN_USE_QNET", 1),
     ("ocean_polar_fix", "QD_OCEAN_POLAR_FIX", 1),
     ("p_hybrid_fallback", "QD_P_HYBRID_FALLBACK", 1), ("cloud_advect", "QD_CLOUD_ADVECT", 1),
-    ("use_topo_albedo", "QD_USE_TOPO_ALBEDO", 1), ("has_csmap", None, 0), ("_pad", None, 0),
+    ("use_topo_albedo", "QD_USE_TOPO_ALBEDO", 1), ("has_csmap", None, 0),
+    ("snow_melt_mode", "QD_SNOW_MELT_MODE", 0), ("swe_enable", "QD_SWE_ENABLE", 1), ("lapse_enable", "QD_LAPSE_ENABLE", 1),
 ]
 
 
@@ -83,7 +92,7 @@ class qd_params(ctypes.Structure):
 
 def _env_float(name, default):
     v = os.environ.get(name)
-    if v is None or v == "":
+    if v is None or v == "" or v in ("None", "none", "null"):
         return default
     try:
         return float(v)
@@ -101,6 +110,8 @@ def _env_int(name, default):
         return _FILTER_CODES.get(v.strip().lower(), 4)
     if name == "QD_OCEAN_OUTLIER":
         return 0 if v.strip().lower() == "mean4" else 1
+    if name == "QD_SNOW_MELT_MODE":
+        return 0 if v.strip().lower() == "degree_day" else 1
     try:
         return int(v)
     except Exception:
@@ -154,7 +165,7 @@ class QdParams:
         """Same values under the oracle's names (filter_type / ocean_outlier as strings)."""
         inv = {v: k for k, v in _FILTER_CODES.items()}
         d = {n: getattr(self, n) for n, _, _ in _DOUBLES}
-        d.update({n: getattr(self, n) for n, _, _ in _INTS if n not in ("has_csmap", "_pad")})
+        d.update({n: getattr(self, n) for n, _, _ in _INTS if n not in ("has_csmap",)})
         d["filter_type"] = inv.get(self.filter_type, "other")
         d["ocean_outlier"] = "mean4" if self.ocean_outlier == 0 else "clamp"
         d["q_init_rh"] = self.q_init_rh

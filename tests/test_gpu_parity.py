@@ -160,3 +160,49 @@ def test_driver_physics_vs_reference(gpu, shape):
     print(errs)
     for k, e in errs.items():
         assert e < STEP_TOL, (k, e)
+
+
+@pytest.mark.parametrize("use_ocean", [1, 0])
+def test_driver_loop_vs_oracle(gpu, use_ocean):
+    """The whole driver iteration (run_simulation.py:1760-2340: precipitation, clouds, P019 snow, albedo,
+    time_step without albedo, ocean coupling, snow commit + land bucket) resident on the device against
+    DriverOracle, which tests/test_oracle_golden.py pins to the reference's real driver run.
+    A cold, low-h state makes the snow / glacier branches fire."""
+    import qd_oracle as qo
+    from qd_oracle.driver import DriverOracle
+    from qingdai_amd.driver import Simulation
+    nlat, nlon, nsteps = 61, 96, 4
+    sim = Simulation(nlat, nlon, params=__import__("qingdai_amd").QdParams(), use_ocean=bool(use_ocean), quiet=True)
+    lat = np.deg2rad(sim.grid.lat_mesh)
+    h0 = 8000.0 - 10500.0 * np.sin(lat) ** 2                       # T_a = 263 K at the poles -> snowfall
+    Ts0 = 262.0 + 36.0 * np.cos(lat) ** 2
+    S0 = np.where((sim.land_mask == 1) & (np.abs(sim.grid.lat_mesh) > 55), 30.0, 0.0)
+    sim.gcm.h, sim.gcm.T_s = h0, Ts0
+    sim.dev.set("S_SNOW", S0)
+    g = qo.Grid(nlat, nlon)
+    P = qo.defaults()
+    m = qo.AtmosOracle(g, sim.friction, sim.land_mask, P, C_s_map=np.where(sim.land_mask == 1, 3e6, P.Cs_ocean).astype(float))
+    m.h, m.T_s = h0.copy(), Ts0.copy()
+    oc = qo.OceanOracle(g, sim.land_mask, P, init_Ts=np.full((nlat, nlon), 288.0)) if use_ocean else None
+    d = DriverOracle(g, m, oc, qo.Forcing(g), sim.land_mask, sim.base_albedo, P)
+    d.S_snow = S0.copy()
+    sim.run_steps(nsteps)
+    for i in range(nsteps):
+        d.step(i * 300.0, 300)
+    pairs = {"u": (sim.gcm.u, m.u), "v": (sim.gcm.v, m.v), "h": (sim.gcm.h, m.h), "T_s": (sim.gcm.T_s, m.T_s),
+             "q": (sim.gcm.q, m.q), "cloud": (sim.gcm.cloud_cover, m.cloud_cover), "precip": (sim.dev.get("PRECIP"), d.precip),
+             "albedo": (sim.dev.get("ALBEDO"), d.albedo), "S_snow": (sim.dev.get("S_SNOW"), d.S_snow),
+             "C_snow": (sim.dev.get("C_SNOW"), d.C_snow), "W_land": (sim.dev.get("W_LAND"), d.W_land),
+             "runoff": (sim.dev.get("RUNOFF"), d.R_flux)}
+    if use_ocean:
+        pairs.update(uo=(sim.ocean.uo, oc.uo), eta=(sim.ocean.eta, oc.eta), SST=(sim.ocean.Ts, oc.Ts))
+    errs = {k: relerr(a, b) for k, (a, b) in pairs.items()}
+    print(errs, "snow cells:", int((d.S_snow > 0).sum()), "glacier-ish:", int((d.C_snow >= 0.6).sum()))
+    assert (d.S_snow > 0).sum() > 0 and (d.C_snow >= 0.6).sum() > 0     # the branches really fired
+    # The slab ocean's eta sits at its +-5 m clip from the first step (SURVEY Appendix A) and its two polar rows
+    # (cos floor 0.5, d2/dlambda2 over 96..1440 cells) amplify rounding differences by ~400x per step -- in the
+    # reference-order kernels (QD_FUSED=0) as much as in the reciprocal-form fused ones (measured: 4e-15 ->
+    # 1e-12 -> 5e-10 at eta[0, :]).  Ocean dynamics fields of a coupled run are therefore compared after 4
+    # steps at 1e-7; everything else at the usual bound.
+    for k, e in errs.items():
+        assert e < (1e-7 if k in ("uo", "eta") else STEP_TOL), (k, e)

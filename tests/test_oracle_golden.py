@@ -117,3 +117,38 @@ def test_known_answers_appendix_a4():
           "T_s": 197315.43946512075, "q": 3.8377409006693473}
     for k, s in ka.items():
         assert abs(float(np.sum(getattr(m, k))) - s) <= 1e-11 * max(1.0, abs(s)), k
+
+
+@pytest.mark.parametrize("use_ocean,ka", [
+    (1, {"u": -234004.94882386696, "v": 28.279164765879422, "h": 224666201.89422357, "T_s": 8364474.288207765,
+         "q": 154.87061864197833, "cloud_cover": 9024.394981981939, "E_flux_last": 1.3207955778646714,
+         "W_land": 12872405247.524658, "uo": -27.408644099087475, "vo": -2.4226231764406703,
+         "eta": 8.601978767987557, "Ts": 8364361.425071081}),
+    (0, {"u": -234004.83009789028, "v": 28.038551435024658, "h": 224666226.2721218, "T_s": 8365678.517250543,
+         "q": 154.84011427916005, "cloud_cover": 9024.591677566821, "E_flux_last": 1.3163780338066378,
+         "W_land": 12848601558.929781}),
+])
+def test_driver_known_answers_appendix_a5_a6(use_ocean, ka):
+    """the reference's real driver (scripts.run_simulation.main(), 121x240,
+    24 steps, ecology/phyto/routing off) -- pins the whole driver composition of DriverOracle:
+    precipitation, clouds, P019 snow, albedo, time_step without albedo, ocean coupling, land bucket."""
+    from qd_oracle.driver import DriverOracle
+    from qingdai_amd.topography import create_land_sea_mask, generate_base_properties
+    g = qo.Grid(121, 240)
+    mask = create_land_sea_mask(g)
+    assert int(mask.sum()) == 7288
+    alb, fric = generate_base_properties(mask)
+    P = qo.defaults()
+    m = qo.AtmosOracle(g, fric, mask, P, C_s_map=np.where(mask == 1, 3e6, P.Cs_ocean).astype(float))
+    oc = qo.OceanOracle(g, mask, P, init_Ts=np.where(mask == 0, m.T_s, 288.0)) if use_ocean else None
+    d = DriverOracle(g, m, oc, qo.Forcing(g), mask, alb, P)
+    day = 2 * np.pi / 8.726646259971648e-5
+    for t in np.arange(0.0, 0.1 * day, 300):
+        d.step(float(t), 300)
+    got = {k: getattr(m, k) for k in ("u", "v", "h", "T_s", "q", "cloud_cover", "E_flux_last")}
+    got["W_land"] = d.W_land
+    if oc is not None:
+        got.update(uo=oc.uo, vo=oc.vo, eta=oc.eta, Ts=oc.Ts)
+    for k, s in ka.items():
+        val = float(np.sum(got[k]))
+        assert abs(val - s) <= 2e-11 * max(1.0, abs(s)), (k, val, s)
