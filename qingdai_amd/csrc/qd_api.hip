@@ -232,7 +232,7 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
     if (build_tables(c)) return bail("table allocation", hipErrorOutOfMemory);
     if ((e = hipMalloc(&c->k4_atm, (size_t)5 * d->n_lat * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc(&c->k4_ocn, (size_t)3 * d->n_lat * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
-    c->red_blocks = 8 * c->geo.lrows() + 64;
+    c->red_blocks = (8 + (d->n_lon + QD_BLOCK - 1) / QD_BLOCK) * c->geo.lrows() + 64;
     if ((e = hipMalloc(&c->red_partial, (size_t)c->red_blocks * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc(&c->dscal, QD_S_COUNT * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc(&c->dcount, 8 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);

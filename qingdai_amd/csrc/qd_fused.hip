@@ -99,7 +99,7 @@ template <int TR> struct QdPl {
 };
 
 // del^4 of the field currently in plane B (valid rows [1,TR+9), lanes 1..62), written to `out`.
-// Caller has synchronised after filling B; this routine ends with a barrier so B/D may be reused.
+// Caller has synchronised after filling B.  The routine does NOT end with a barrier (see its last comment).
 template <int TR>
 __device__ __forceinline__ void qd_del4_from_B(const double* __restrict__ B, double* __restrict__ D,
                                                double* __restrict__ out, const QdGeom& G, int i0, int j0,
@@ -126,7 +126,9 @@ __device__ __forceinline__ void qd_del4_from_B(const double* __restrict__ B, dou
             out[(size_t)qd_lrow(G, g) * G.nlon + j] = qd_nnf(B[rho * QD_S + lane] - (k4 * L2) * dt);
         }
     }
-    __syncthreads();
+    // no barrier here: this phase reads B only at the thread's OWN cells, which are exactly the cells the
+    // thread overwrites when it fills B for the next field; D is rewritten only after the barrier that
+    // follows that fill, i.e. after every wave has left this phase.
 }
 
 // store owned cells straight from per-thread register values (field skipped by the k4<=0 early-out)

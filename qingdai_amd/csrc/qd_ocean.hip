@@ -174,6 +174,72 @@ k_eta_mean(const double* __restrict__ partial, int n, double wsum, double* __res
     }
 }
 
+// ------------------------------------------------------------------ continuity + SST advection, merged
+// ocean.py:365-374 (eta += -dt H div, land zero, area-weighted sum over the OWNED rows) and ocean.py:380-382
+// (SST semi-Lagrangian blend) read the same uo, vo: one pass.  The eta mean is removed later, in
+// k_sst_outlier_fused, right before the clip (same arithmetic: clip(nan_to_num(eta - mean))).
+// One workgroup per row; when `ticket` is non-null the last workgroup to finish turns the row partials into
+// eta_mean = sum / (wsum + 1e-15) (whole-globe handles; bands all-reduce the raw sum instead).
+__global__ void __launch_bounds__(QD_BLOCK)
+k_cont_sstadv(QdGeom G, QdTabs T, double a, double dlat, double dlon, double msdtH, double sub_dt, double alpha,
+              const double* __restrict__ uo, const double* __restrict__ vo, const uint8_t* __restrict__ land,
+              double* __restrict__ eta, const double* __restrict__ Ts, double* __restrict__ Ts_out,
+              int own0, int own1, double* __restrict__ partial, unsigned long long* ticket, double wsum,
+              double* __restrict__ eta_mean) {
+    __shared__ double sm[QD_BLOCK / 64];
+    __shared__ int s_last;
+    const int i = G.row0 + blockIdx.y;
+    const size_t b = (size_t)qd_lrow(G, i) * G.nlon;
+    const double w = (i >= own0 && i < own1) ? T.warea[i] : 0.0;
+    const double cosl = T.cos05[i];
+    const int pidx = blockIdx.y * gridDim.x + blockIdx.x, pcount = gridDim.x * gridDim.y;
+    double acc = 0.0;
+    for (int j = blockIdx.x * QD_BLOCK + threadIdx.x; j < G.nlon; j += gridDim.x * QD_BLOCK) {
+        const size_t o = b + j;
+        const double div = qd_divvort_point(G, T, uo, vo, i, j, a, dlat, dlon, 0);
+        double e = eta[o] + msdtH * div;
+        const bool island = land[o] == 1;
+        if (island) e = 0.0;
+        eta[o] = e;
+        acc += e * (island ? 0.0 : w);
+        const QdBilin bl = qd_departure(G, i, j, uo[o], vo[o], sub_dt, a, cosl, dlat, dlon);
+        Ts_out[o] = (1.0 - alpha) * Ts[o] + alpha * qd_gather(Ts, G, bl);
+    }
+    acc = qd_wave_sum_d(acc);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) sm[wv] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = sm[0];
+        for (int k = 1; k < QD_BLOCK / 64; ++k) r += sm[k];
+        if (!ticket) partial[pidx] = r;
+        else {
+            // write-through (agent-scope) store, drained, then the ticket: the last workgroup reads the
+            // partials back with agent-scope loads -- no cache flush on thousands of workgroups
+            __hip_atomic_store(&partial[pidx], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long t = atomicAdd(ticket, 1ull);
+            s_last = (t == (unsigned long long)pcount - 1ull) ? 1 : 0;
+        }
+    }
+    if (!ticket) return;
+    __syncthreads();
+    if (!s_last) return;
+    double a2 = 0.0;
+    for (int k = threadIdx.x; k < pcount; k += QD_BLOCK)
+        a2 += __hip_atomic_load(&partial[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a2 = qd_wave_sum_d(a2);
+    __syncthreads();
+    if (lane == 0) sm[wv] = a2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = sm[0];
+        for (int k = 1; k < QD_BLOCK / 64; ++k) r += sm[k];
+        *eta_mean = r / (wsum + 1e-15);
+        __hip_atomic_store(ticket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // ------------------------------------------------------------------ SST advection: ocean.py:375,380-382
 __global__ void __launch_bounds__(QD_BLOCK)
 k_sst_advect(QdGeom G, const double* __restrict__ cos05, double sub_dt, double a, double dlat, double dlon,
@@ -254,7 +320,8 @@ k_sst_outlier_fused(QdGeom G, QdTabs T, double dlat, double dlon, double a, QdHe
                     const double* __restrict__ Ts1, double* __restrict__ Ts_out, const double* __restrict__ qnet,
                     const uint8_t* __restrict__ land, const uint8_t* __restrict__ ice,
                     const double* __restrict__ uo, const double* __restrict__ vo, double* __restrict__ uo_out,
-                    double* __restrict__ vo_out, double* __restrict__ eta, double cap, double eta_cap, int mean4) {
+                    double* __restrict__ vo_out, double* __restrict__ eta, double cap, double eta_cap, int mean4,
+                    const double* __restrict__ eta_mean) {
     const QdTile tl = qd_tile();
     const int j = tl.seg * QD_BLOCK + threadIdx.x;
     if (j >= G.nlon) return;
@@ -290,7 +357,9 @@ k_sst_outlier_fused(QdGeom G, QdTabs T, double dlat, double dlon, double a, QdHe
         u = u * sc; v = v * sc;
     }
     uo_out[o] = u; vo_out[o] = v;
-    eta[o] = qd_clip(qd_nn(eta[o]), -eta_cap, eta_cap);
+    // eta -= area-weighted ocean mean (ocean.py:375), then nan_to_num + clip (ocean.py:436-443)
+    const double e = eta_mean ? eta[o] - *eta_mean : eta[o];
+    eta[o] = qd_clip(qd_nn(e), -eta_cap, eta_cap);
 }
 
 // ------------------------------------------------------------------ polar ring fills: ocean.py:197-262
@@ -484,6 +553,52 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
             qd_shapiro_fields(c, fl, 3, np_, m);
             F[QD_F_UO] = fl[0]; F[QD_F_VO] = fl[1]; F[QD_F_ETA] = fl[2];
         }
+        if (c->use_fused) {
+            QdScope sc(c, "ocean_cont_sst");
+            const int m = qd_plan(c, {QD_IN(F[QD_F_UO], 1), QD_IN(F[QD_F_VO], 1), QD_IN(F[QD_F_ETA], 0), QD_IN(F[QD_F_SST], Ro)});
+            if (m < 0) return -1;
+            double* T1 = qd_scratch(c, 0);
+            const int own0 = c->own_row0, own1 = c->own_row0 + c->own_nrows;
+            const int has_ocean = c->wsum_ocean > 0.0 ? 1 : 0;
+            if (!band) {
+                // (a last-workgroup ticket here costs more than the 5 us finishing kernel: thousands of workgroups
+                //  contending on one counter word run at ~90 tickets/us)
+                const dim3 g2 = qd_grid2d(Gown);
+                hipLaunchKernelGGL(k_cont_sstadv, g2, blk, 0, c->stream, Gown, c->tabs, p.a, c->dlat, c->dlon, -sub_dt * H, sub_dt,
+                                   p.ocean_adv_alpha, F[QD_F_UO], F[QD_F_VO], c->land, F[QD_F_ETA], F[QD_F_SST], T1, own0, own1,
+                                   c->red_partial, (unsigned long long*)nullptr, 0.0, (double*)nullptr);
+                hipLaunchKernelGGL(k_eta_mean, dim3(1), blk, 0, c->stream, c->red_partial, (int)(g2.x * g2.y), c->wsum_ocean,
+                                   c->dscal + QD_S_ETA_MEAN);
+            } else {
+                // halo segments first (their partials are zero-weighted), the owned rows' partials are summed below
+                QdSegs S = qd_segments(c, m);
+                size_t off = 0;
+                for (int k = 0; k < S.n; ++k) {
+                    hipLaunchKernelGGL(k_cont_sstadv, qd_grid2d(S.g[k]), blk, 0, c->stream, S.g[k], c->tabs, p.a, c->dlat, c->dlon,
+                                       -sub_dt * H, sub_dt, p.ocean_adv_alpha, F[QD_F_UO], F[QD_F_VO], c->land, F[QD_F_ETA],
+                                       F[QD_F_SST], T1, own0, own1, c->red_partial + off, (unsigned long long*)nullptr, 0.0,
+                                       (double*)nullptr);
+                    off += (size_t)S.g[k].nrows * qd_grid2d(S.g[k]).x;
+                }
+                hipLaunchKernelGGL(k_eta_mean, dim3(1), blk, 0, c->stream, c->red_partial, (int)off, -1.0, c->dscal + QD_S_ETA_MEAN);
+                if (qd_allreduce_f64(c, c->dscal + QD_S_ETA_MEAN, 1, 0)) return -1;
+                hipLaunchKernelGGL(k_eta_mean_post, dim3(1), dim3(64), 0, c->stream, c->dscal + QD_S_ETA_MEAN, c->wsum_ocean);
+            }
+            qd_mark(c, {T1, F[QD_F_ETA]}, m);
+            double*& T1s = c->scratch[0];
+            double* T2 = qd_scratch(c, 1);
+            const int m2 = qd_plan(c, {QD_IN(T1s, 2), QD_IN(F[QD_F_QNET], 0), QD_IN8(c->icemask, 0), QD_IN(F[QD_F_UO], 1),
+                                       QD_IN(F[QD_F_VO], 1), QD_IN(F[QD_F_ETA], 0)});
+            if (m2 < 0) return -1;
+            double* u2 = qd_scratch(c, 2); double* v2 = qd_scratch(c, 3);
+            QD_ROWS(c, m2, G, hipLaunchKernelGGL(k_sst_outlier_fused, qd_grid2d(G), blk, 0, c->stream, G, c->tabs, c->dlat,
+                                                 c->dlon, p.a, HP, c->scratch[0], T2, F[QD_F_QNET], c->land, c->icemask,
+                                                 F[QD_F_UO], F[QD_F_VO], u2, v2, F[QD_F_ETA], p.ocean_max_u, p.eta_cap,
+                                                 p.ocean_outlier == 0 ? 1 : 0,
+                                                 has_ocean ? c->dscal + QD_S_ETA_MEAN : (const double*)nullptr));
+            qd_mark(c, {T2, u2, v2, F[QD_F_ETA]}, m2);
+            qd_swap(c, QD_F_SST, 1); qd_swap(c, QD_F_UO, 2); qd_swap(c, QD_F_VO, 3);
+        } else {
         {
             QdScope sc(c, "ocean_continuity");
             // eta update on the margin; the area-weighted sum only over owned rows
@@ -532,7 +647,7 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
             qd_mark(c, {T1, F[QD_F_ETA]}, m1);
             double*& T1s = c->scratch[0];
             double* T2 = qd_scratch(c, 1);
-            if (c->use_fused) {
+            if (false) {
                 const int m2 = qd_plan(c, {QD_IN(T1s, 2), QD_IN(F[QD_F_QNET], 0), QD_IN8(c->icemask, 0), QD_IN(F[QD_F_UO], 1),
                                            QD_IN(F[QD_F_VO], 1), QD_IN(F[QD_F_ETA], 0)});
                 if (m2 < 0) return -1;
@@ -540,7 +655,7 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
                 QD_ROWS(c, m2, G, hipLaunchKernelGGL(k_sst_outlier_fused, qd_grid2d(G), blk, 0, c->stream, G, c->tabs, c->dlat,
                                                      c->dlon, p.a, HP, c->scratch[0], T2, F[QD_F_QNET], c->land, c->icemask,
                                                      F[QD_F_UO], F[QD_F_VO], u2, v2, F[QD_F_ETA], p.ocean_max_u, p.eta_cap,
-                                                     p.ocean_outlier == 0 ? 1 : 0));
+                                                     p.ocean_outlier == 0 ? 1 : 0, (const double*)nullptr));
                 qd_mark(c, {T2, u2, v2, F[QD_F_ETA]}, m2);
                 qd_swap(c, QD_F_SST, 1); qd_swap(c, QD_F_UO, 2); qd_swap(c, QD_F_VO, 3);
             } else {
@@ -552,6 +667,7 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
                 qd_mark(c, {T2}, m2);
                 qd_swap(c, QD_F_SST, 1);
             }
+        }
         }
         if (!c->use_fused) {
             QdScope sc(c, "ocean_outlier");

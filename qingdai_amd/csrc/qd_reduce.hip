@@ -10,6 +10,8 @@
 // of the positive entries (order-isomorphic to their values), 11 bits per pass, tracking the
 // two middle ranks at once for even counts.
 #include "qd_internal.h"
+#include <algorithm>
+#include <cstdlib>
 
 __device__ __forceinline__ double qd_wave_sum(double x) {
 #pragma unroll
@@ -107,7 +109,7 @@ __device__ __forceinline__ double qd_med_value(double x, int transform, double t
 // sel_state: [0] count of positives, [1] prefix_lo, [2] rank_lo, [3] prefix_hi, [4] rank_hi, [6] ticket
 __global__ void __launch_bounds__(QD_BLOCK)
 k_sel_pass(QdGeom G, const double* __restrict__ x, int transform, double tparam, unsigned long long* st,
-           unsigned int* hist, int shift, int width, int first, int mode) {
+           unsigned int* hist, int shift, int width, int first, int mode, int dbg) {
     // mode 0: histogram + scan by the last workgroup (single GPU)
     // mode 1: histogram only   mode 2: scan only (one workgroup) -- latitude bands all-reduce the
     //         histogram between the two
@@ -118,31 +120,68 @@ k_sel_pass(QdGeom G, const double* __restrict__ x, int transform, double tparam,
     const int t = threadIdx.x;
     const unsigned long long n0 = __hip_atomic_load(&st[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!first && n0 == 0ull) return;                        // no positive entry: nothing to refine
+    if (dbg & 16) return;
     if (mode != 2) {
     for (int k = t; k < 2 * QD_HIST_BINS; k += QD_BLOCK) sh[k] = 0u;
     const unsigned long long plo = __hip_atomic_load(&st[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long phi = __hip_atomic_load(&st[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    const int i = G.row0 + blockIdx.y;
-    const size_t b = (size_t)qd_lrow(G, i) * G.nlon;
     const int up = shift + width;                            // bits above the current digit
-    for (int j = blockIdx.x * QD_BLOCK + t; j < G.nlon; j += gridDim.x * QD_BLOCK) {
-        const double v = qd_med_value(x[b + j], transform, tparam);
-        if (!(v > 0.0)) continue;
+    const int jstep = gridDim.x * QD_BLOCK;
+    // few, fat workgroups: each walks several rows so its LDS histogram is dense (fewer global atomics,
+    // fewer tickets on the single counter word)
+    for (int i = G.row0 + (int)blockIdx.y; i < G.row0 + ((dbg & 32) ? 0 : G.nrows); i += (int)gridDim.y) {
+    const size_t b = (size_t)qd_lrow(G, i) * G.nlon;
+    for (int jb = blockIdx.x * QD_BLOCK; jb < G.nlon; jb += 8 * jstep) {
+    // issue up to 8 independent loads per thread before touching the (wave-synchronising) histogram code:
+    // one exposed memory latency per batch instead of one per element
+    double vbuf[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int j = jb + q * jstep + t;
+        vbuf[q] = x[b + (j < G.nlon ? j : G.nlon - 1)];     // unconditional load from a clamped index (no branch)
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {                                            // wave-uniform trip count (ballots inside)
+        const int j0 = jb + q * jstep;
+        if (j0 >= G.nlon) break;
+        const int j = j0 + t;
+        const double v = (j < G.nlon) ? qd_med_value(vbuf[q], transform, tparam) : 0.0;
+        const bool pos = (v > 0.0);
         const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
         const unsigned long long hi_bits = up >= 64 ? 0ull : (bits >> up);
         const unsigned int digit = (unsigned int)((bits >> shift) & ((1u << width) - 1u));
-        if (first || hi_bits == (plo >> up)) atomicAdd(&sh[digit], 1u);
-        if (!first && plo != phi && hi_bits == (phi >> up)) atomicAdd(&sh[QD_HIST_BINS + digit], 1u);
+        const bool in_lo = pos && (first || hi_bits == (plo >> up));
+        const bool in_hi = pos && !first && plo != phi && hi_bits == (phi >> up);
+        // Digits of the leading passes (sign + exponent bits) are shared by most of a wavefront: peel up to
+        // four wave-wide groups with one LDS atomic each before falling back to per-lane atomics, which
+        // would otherwise serialise 64-deep on one bank.
+        bool todo = in_lo;
+        if (dbg & 2) todo = false;
+        for (int it = 0; it < ((dbg & 1) ? 4 : 0); ++it) {
+            const unsigned long long act = __ballot(todo);
+            if (!act) break;
+            const int leader = __ffsll((long long)act) - 1;
+            const unsigned int d0 = (unsigned int)__shfl((int)digit, leader, 64);
+            const unsigned long long same = __ballot(todo && digit == d0);
+            if ((int)(threadIdx.x & 63) == leader) atomicAdd(&sh[d0], (unsigned int)__popcll(same));
+            if (todo && digit == d0) todo = false;
+        }
+        if (todo) atomicAdd(&sh[digit], 1u);
+        if (in_hi) atomicAdd(&sh[QD_HIST_BINS + digit], 1u);
+    }
+    }
     }
     __syncthreads();
-    // returning atomics: the wave cannot pass its s_waitcnt until every add has been performed at the
-    // memory side, so the ticket below is ordered after this workgroup's counts without a cache flush
-    unsigned int sink = 0u;
-    for (int k = t; k < 2 * QD_HIST_BINS; k += QD_BLOCK) if (sh[k]) sink += atomicAdd(&hist[k], sh[k]);
-    asm volatile("s_waitcnt vmcnt(0)" ::"v"(sink) : "memory");
+    // fire-and-forget device-scope atomics, all in flight at once; vmcnt(0) drains them (a write leaves the
+    // counter when it has reached L2), so the ticket below is ordered after this workgroup's counts without
+    // a cache flush and without paying one round trip per bin
+    if (!(dbg & 4)) for (int k = t; k < 2 * QD_HIST_BINS; k += QD_BLOCK) if (sh[k]) atomicAdd(&hist[k], sh[k]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (dbg & 8) return;
     if (mode == 1) return;
     __syncthreads();
+    if (dbg & 64) return;
     if (t == 0) {
         const unsigned long long ticket = atomicAdd(&st[6], 1ull);
         s_last = (ticket == (unsigned long long)(gridDim.x * gridDim.y) - 1ull) ? 1 : 0;
@@ -156,15 +195,31 @@ k_sel_pass(QdGeom G, const double* __restrict__ x, int transform, double tparam,
     for (int k = t; k < 2 * QD_HIST_BINS; k += QD_BLOCK) sh[k] = __hip_atomic_load(&hist[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (t < 8) s_st[t] = __hip_atomic_load(&st[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
+    // chunk sums (8 bins per thread) and their exclusive prefix over the workgroup, both histograms at once:
+    // wave-level shuffle scan + one LDS hop across the 4 waves -- no serial walk over 256 chunks
+    __shared__ unsigned int wtot[2][QD_BLOCK / 64];
+    unsigned int mysum[2], excl[2];
+    const int lane = t & 63, wv = t >> 6;
     for (int hsel = 0; hsel < 2; ++hsel) {
         unsigned int sacc = 0;
         for (int k = 0; k < per; ++k) sacc += sh[hsel * QD_HIST_BINS + t * per + k];
-        csum[hsel][t] = sacc;
+        mysum[hsel] = sacc;
+        unsigned int inc = sacc;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned int y = __shfl_up(inc, o, 64); if (lane >= o) inc += y; }
+        if (lane == 63) wtot[hsel][wv] = inc;
+        excl[hsel] = inc - sacc;
     }
     __syncthreads();
+    unsigned long long total0 = 0;
+    for (int hsel = 0; hsel < 2; ++hsel) {
+        unsigned int base = 0;
+        for (int k = 0; k < wv; ++k) base += wtot[hsel][k];
+        excl[hsel] += base;
+    }
+    for (int k = 0; k < QD_BLOCK / 64; ++k) total0 += wtot[0][k];
     if (t == 0 && first) {
-        unsigned long long n = 0;
-        for (int k = 0; k < QD_BLOCK; ++k) n += csum[0][k];
+        const unsigned long long n = total0;
         s_st[0] = n;
         s_st[2] = n ? (n - 1) / 2 : 0;   // lower middle rank (0-based)
         s_st[4] = n / 2;                 // upper middle rank
@@ -172,18 +227,21 @@ k_sel_pass(QdGeom G, const double* __restrict__ x, int transform, double tparam,
     }
     __syncthreads();
     const bool same = (s_st[1] == s_st[3]);
-    if (t < 2 && s_st[0] > 0) {
-        const int hsel = (t == 1 && !same) ? 1 : 0;
-        unsigned long long r = s_st[t == 0 ? 2 : 4], cum = 0;
-        int ch = 0;
-        for (; ch < QD_BLOCK; ++ch) { if (cum + csum[hsel][ch] > r) break; cum += csum[hsel][ch]; }
-        if (ch >= QD_BLOCK) ch = QD_BLOCK - 1;
-        int d = ch * per;
-        for (; d < ch * per + per; ++d) { const unsigned int hv = sh[hsel * QD_HIST_BINS + d]; if (cum + hv > r) break; cum += hv; }
-        if (d >= ch * per + per) d = ch * per + per - 1;
-        __hip_atomic_store(&st[t == 0 ? 2 : 4], r - cum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&st[t == 0 ? 1 : 3], s_st[t == 0 ? 1 : 3] | ((unsigned long long)d << shift), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+    if (s_st[0] > 0) {
+        // the thread whose chunk [excl, excl + mysum) holds the target rank walks its 8 bins
+        for (int which = 0; which < 2; ++which) {
+            const int hsel = (which == 1 && !same) ? 1 : 0;
+            const unsigned long long r = s_st[which == 0 ? 2 : 4];
+            if (mysum[hsel] > 0 && r >= excl[hsel] && r < (unsigned long long)excl[hsel] + mysum[hsel]) {
+                unsigned long long cum = excl[hsel];
+                int d = t * per;
+                for (; d < t * per + per; ++d) { const unsigned int hv = sh[hsel * QD_HIST_BINS + d]; if (cum + hv > r) break; cum += hv; }
+                if (d >= t * per + per) d = t * per + per - 1;
+                __hip_atomic_store(&st[which == 0 ? 2 : 4], r - cum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&st[which == 0 ? 1 : 3], s_st[which == 0 ? 1 : 3] | ((unsigned long long)d << shift),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
     if (t == 0) {
         if (first) __hip_atomic_store(&st[0], s_st[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -213,17 +271,19 @@ int qd_median_positive_dev(qd_ctx* c, const double* x, double dflt, int slot, in
     // digits from the top: bits 63..53, 52..42, 41..31, 30..20 (11 wide), 19..10, 9..0 (10 wide)
     const int shifts[6] = {53, 42, 31, 20, 10, 0};
     const int widths[6] = {11, 11, 11, 11, 10, 10};
-    dim3 grid(1, G.nrows);
+    static const int dbg = std::getenv("QD_SEL_DBG") ? std::atoi(std::getenv("QD_SEL_DBG")) : 0;
+    static const int nblk = std::getenv("QD_SEL_BLOCKS") ? std::atoi(std::getenv("QD_SEL_BLOCKS")) : 128;
+    dim3 grid(1, std::min(G.nrows, nblk));
     for (int p = 0; p < 6; ++p) {
         if (c->geo.full) {
             hipLaunchKernelGGL(k_sel_pass, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, c->sel_state,
-                               c->hist, shifts[p], widths[p], p == 0 ? 1 : 0, 0);
+                               c->hist, shifts[p], widths[p], p == 0 ? 1 : 0, 0, dbg);
         } else {
             hipLaunchKernelGGL(k_sel_pass, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, c->sel_state,
-                               c->hist, shifts[p], widths[p], p == 0 ? 1 : 0, 1);
+                               c->hist, shifts[p], widths[p], p == 0 ? 1 : 0, 1, dbg);
             if (qd_allreduce_u32(c, c->hist, 2 * QD_HIST_BINS)) return -1;
             hipLaunchKernelGGL(k_sel_pass, dim3(1, 1), dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, c->sel_state,
-                               c->hist, shifts[p], widths[p], p == 0 ? 1 : 0, 2);
+                               c->hist, shifts[p], widths[p], p == 0 ? 1 : 0, 2, dbg);
         }
     }
     hipLaunchKernelGGL(k_sel_finish, dim3(1), dim3(64), 0, c->stream, c->sel_state, dflt, c->dscal + slot, c->dcount);
