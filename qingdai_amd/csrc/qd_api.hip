@@ -90,7 +90,18 @@ static int build_tables(qd_ctx* c) {
                 P[i] = 1.0 / ((a * a) * ck[i] * (2.0 * dphi));
                 Q[i] = 1.0 / ((a * a) * (dlam * dlam) * (ck[i] * ck[i]));
             }
+            // rows 0,1,n-2,n-1 (one-sided np.gradient, grid.py:41-88) in the same reciprocal form:
+            //   L = P[g] * (Ab * dFb - Aa * dFa) + Q[g] * d2,  (Aa, Ab) per pole-row type t = 0..3 (g = 0, 1, n-2, n-1)
+            std::vector<double> PA(8, 0.0);
+            if (nlat >= 5) {
+                const int n = nlat;
+                PA[0] = ck[0] / dphi;               PA[1] = ck[1] / (2.0 * dphi);      P[0] = 1.0 / ((a * a) * ck[0] * dphi);
+                PA[2] = ck[0] / dphi;               PA[3] = ck[2] / (2.0 * dphi);      P[1] = 1.0 / ((a * a) * ck[1] * (2.0 * dphi));
+                PA[4] = ck[n - 3] / (2.0 * dphi);   PA[5] = ck[n - 1] / dphi;          P[n - 2] = 1.0 / ((a * a) * ck[n - 2] * (2.0 * dphi));
+                PA[6] = ck[n - 2] / (2.0 * dphi);   PA[7] = ck[n - 1] / dphi;          P[n - 1] = 1.0 / ((a * a) * ck[n - 1] * dphi);
+            }
             c->tabs.lapA[k] = dev_table(c, A); c->tabs.lapP[k] = dev_table(c, P); c->tabs.lapQ[k] = dev_table(c, Q);
+            c->tabs.lapPoleA[k] = dev_table(c, PA);
         }
         std::vector<double> cu(nlat), cv(nlat), px(nlat), igx(nlat);
         for (int i = 0; i < nlat; ++i) {
@@ -211,6 +222,7 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
     qd_ctx* c = new qd_ctx();
     c->desc = *d; c->p = *params;
     { const char* ef = std::getenv("QD_FUSED"); if (ef && ef[0] == '0') c->use_fused = 0; }
+    { const char* ef = std::getenv("QD_FUSED_FAST"); if (ef) c->fused_fast = std::atoi(ef); }
     c->geo = QdGeom{d->n_lat, d->n_lon, d->row0, d->n_rows, d->halo, full ? 1 : 0, d->row0 - d->halo, d->n_rows + 2 * d->halo};
     c->own_row0 = d->row0; c->own_nrows = d->n_rows;
     auto bail = [&](const char* w, hipError_t e) { qd_fail(nullptr, w, e); qd_destroy(c); return -1; };

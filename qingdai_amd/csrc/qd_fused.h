@@ -11,6 +11,7 @@ struct QdDynArgs {
     double g, a, dt, dlat, dlon, f_min;
     double inv_dlon, inv_2dlon, inv_dlat, inv_2dlat, pgf_y;
     int primitive;
+    int fast;                   // interior tiles may take the FAST path (QD_FUSED_FAST=0 disables)
     QdTileShape ts;
 };
 
@@ -24,6 +25,7 @@ struct QdOcnArgs {
     int skip[3];
     double a, g, dlat, dlon, sub_dt, rhoH, r_bot;
     double inv_2dlon, inv_2dlat, inv_a, inv_rhoH;
+    int fast;
     QdTileShape ts;
 };
 

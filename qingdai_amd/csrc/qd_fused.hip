@@ -49,29 +49,25 @@ __device__ __forceinline__ double qd_nnf(double x) {
 struct QdLapC {                  // scalars + reciprocal row tables of the spherical Laplacian
     double dphi, dlam, a;
     int n;                       // nlat
-    const double* cosf;          // global table (pole rows only)
+    const double* poleA;         // QdTabs::lapPoleA of the cos-floor kind (pole rows only)
     const double *sA, *sP, *sQ;  // LDS copies of lapA/lapP/lapQ indexed by PLANE row rho
 };
 
-// the two rows next to each pole: literal reference expressions (one-sided np.gradient); kept out of
-// line so the unrolled interior path stays small
-__device__ __noinline__ double qd_lap_lds_pole(const double* __restrict__ p, int g, const QdLapC& C) {
-    const int n = C.n, S = QD_S;
+// pole-row type of global row g: 0,1,2,3 for g = 0, 1, n-2, n-1; -1 otherwise
+__device__ __forceinline__ int qd_pole_type(int g, int n) { return g == 0 ? 0 : (g == 1 ? 1 : (g == n - 2 ? 2 : (g == n - 1 ? 3 : -1))); }
+
+// the two rows next to each pole: one-sided np.gradient (grid.py:41-88) in the same reciprocal form, with the
+// host-computed coefficients of the row type (QdTabs::lapPoleA; lapP holds the row's P)
+__device__ __forceinline__ double qd_lap_lds_pole(const double* __restrict__ p, int g, int rho, const QdLapC& C) {
+    const int S = QD_S, t = qd_pole_type(g, C.n);
     const double cc = p[0];
-    auto dF = [&](int gr, int off) -> double {      // off: plane-row offset of global row gr from p
-        if (gr == 0) return (p[(off + 1) * S] - p[off * S]) / C.dphi;
-        if (gr == n - 1) return (p[off * S] - p[(off - 1) * S]) / C.dphi;
-        return (p[(off + 1) * S] - p[(off - 1) * S]) / (2.0 * C.dphi);
-    };
-    double Ga, Gb, den;
-    if (g == 0) { Ga = C.cosf[0] * dF(0, 0); Gb = C.cosf[1] * dF(1, 1); den = C.dphi; }
-    else if (g == n - 1) { Ga = C.cosf[n - 2] * dF(n - 2, -1); Gb = C.cosf[n - 1] * dF(n - 1, 0); den = C.dphi; }
-    else { Ga = C.cosf[g - 1] * dF(g - 1, -1); Gb = C.cosf[g + 1] * dF(g + 1, 1); den = 2.0 * C.dphi; }
-    const double ci = C.cosf[g];
-    const double term_phi = (1.0 / ci) * ((Gb - Ga) / den);
-    const double d2 = ((p[1] - 2.0 * cc) + p[-1]) / (C.dlam * C.dlam);
-    const double term_lam = d2 / (ci * ci);
-    return (term_phi + term_lam) / (C.a * C.a);
+    double ahi = cc, alo, bhi, blo = cc;
+    if (t == 0) { ahi = p[S]; alo = cc; } else if (t == 1) alo = p[-S]; else alo = p[-2 * S];
+    if (t == 2) bhi = p[S]; else if (t == 3) { bhi = cc; blo = p[-S]; } else bhi = p[2 * S];
+    const double Gb = C.poleA[2 * t + 1] * (bhi - blo);
+    const double Ga = C.poleA[2 * t] * (ahi - alo);
+    const double d2 = (p[1] - 2.0 * cc) + p[-1];
+    return C.sP[rho] * (Gb - Ga) + C.sQ[rho] * d2;
 }
 
 // Laplacian at plane position p (row stride QD_S) whose global row is g.  Plane values are already
@@ -86,7 +82,7 @@ __device__ __forceinline__ double qd_lap_lds(const double* __restrict__ p, int g
         const double d2 = (p[1] - 2.0 * cc) + p[-1];
         return C.sP[rho] * (Gb - Ga) + C.sQ[rho] * d2;
     }
-    return qd_lap_lds_pole(p, g, C);
+    return qd_lap_lds_pole(p, g, rho, C);
 }
 
 // Plane geometry shared by both kernels.  Common origin: plane row rho <-> global row i0-5+rho,
@@ -153,10 +149,14 @@ __device__ __forceinline__ int qd_wrapj(int j, int n) {   // periodic column; na
     return j;
 }
 
-__device__ __forceinline__ void qd_tile_origin(int ntc, int tr, int row0, int& i0, int& j0) {
+// Tiles are dealt to the 8 XCDs in contiguous chunks; the first and last tile rows (the pole tiles, which
+// take the slower EXACT path) come first in the order so they never form the tail of the launch.
+__device__ __forceinline__ void qd_tile_origin(int ntc, int ntr, int tr, int row0, int& i0, int& j0) {
     const unsigned nb = gridDim.x, L = blockIdx.x, per = nb >> 3, rem = nb & 7u, x = L & 7u;
     const unsigned w = x * per + (x < rem ? x : rem) + (L >> 3);      // XCD-contiguous dealing
-    i0 = row0 + (int)(w / (unsigned)ntc) * tr;
+    int ti = (int)(w / (unsigned)ntc);
+    ti = ti == 0 ? 0 : (ti == 1 ? ntr - 1 : ti - 1);
+    i0 = row0 + ti * tr;
     j0 = (int)(w % (unsigned)ntc) * QD_TC;
 }
 
@@ -194,16 +194,14 @@ __device__ __forceinline__ double qd_mom_cell(const double* __restrict__ p, int 
     return vn + (-fr * vn) * P.dt;
 }
 
+// EXACT path: any tile (pole rows, slab edges, narrow grids, non-finite values): literal nan_to_num at
+// every stage, one-sided np.gradient rows, every cell masked individually.
 template <int TR>
-__global__ void __launch_bounds__(QD_FBLOCK, 4)
-k_dyn_hyper(QdGeom G, QdTabs T, QdDynArgs P) {
-    extern __shared__ __align__(16) double lds[];
+__device__ __forceinline__ void qd_dyn_exact(const QdGeom& G, const QdTabs& T, const QdDynArgs& P, int i0, int j0, double* lds) {
     constexpr int RA = QdPl<TR>::RA, K = QdPl<TR>::K;
     double* A = lds;
     double* B = A + RA * QD_S;
     double* D = B + RA * QD_S;
-    int i0, j0;
-    qd_tile_origin(P.ts.ntc, TR, G.row0, i0, j0);
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: row math + table loads go scalar
     const int j = qd_wrapj(j0 - 3 + lane, G.nlon);
     // row tables of this tile's plane rows, staged once in LDS (broadcast reads afterwards):
@@ -220,7 +218,7 @@ k_dyn_hyper(QdGeom G, QdTabs T, QdDynArgs P) {
         sT[8 * RA + rho] = ok ? (P.primitive ? T.mom_px[gg] : T.mom_cu[gg]) : 0.0;
         sT[9 * RA + rho] = ok ? (P.primitive ? T.fcor[gg] : T.mom_cv[gg]) : 0.0;
     }
-    const QdLapC C{P.dlat, P.dlon, P.a, G.nlat, T.cos02, sT, sT + RA, sT + 2 * RA};
+    const QdLapC C{P.dlat, P.dlon, P.a, G.nlat, T.lapPoleA[0], sT, sT + RA, sT + 2 * RA};
 
     // ---- every global load of the tile, issued back to back (unconditional loads from clamped
     //      offsets, masked afterwards: no branch and no wait sits between two loads)
@@ -293,15 +291,11 @@ k_dyn_hyper(QdGeom G, QdTabs T, QdDynArgs P) {
 // ocean
 // =========================================================================================
 template <int TR>
-__global__ void __launch_bounds__(QD_FBLOCK, 4)
-k_ocn_hyper(QdGeom G, QdTabs T, QdOcnArgs P) {
-    extern __shared__ __align__(16) double lds[];
+__device__ __forceinline__ void qd_ocn_exact(const QdGeom& G, const QdTabs& T, const QdOcnArgs& P, int i0, int j0, double* lds) {
     constexpr int RA = QdPl<TR>::RA, K = QdPl<TR>::K;
     double* A = lds;
     double* B = A + RA * QD_S;
     double* D = B + RA * QD_S;
-    int i0, j0;
-    qd_tile_origin(P.ts.ntc, TR, G.row0, i0, j0);
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: row math + table loads go scalar
     const int j = qd_wrapj(j0 - 3 + lane, G.nlon);
     // staged row tables: 0 lapA 1 lapP 2 lapQ 3..5 k4[uo,vo,eta] 6 fcor 7 ocn_igx 8 r_extra
@@ -318,7 +312,7 @@ k_ocn_hyper(QdGeom G, QdTabs T, QdOcnArgs P) {
         sT[7 * RA + rho] = ok ? T.ocn_igx[gg] : 0.0;
         sT[8 * RA + rho] = ok ? T.r_extra[gg] : 0.0;
     }
-    const QdLapC C{P.dlat, P.dlon, P.a, G.nlat, T.cos05, sT, sT + RA, sT + 2 * RA};
+    const QdLapC C{P.dlat, P.dlon, P.a, G.nlat, T.lapPoleA[1], sT, sT + RA, sT + 2 * RA};
 
     double ae[K], ru[K], rv[K], rtx[K], rty[K];
     int rl[K];
@@ -398,6 +392,351 @@ k_ocn_hyper(QdGeom G, QdTabs T, QdOcnArgs P) {
     qd_del4_from_B<TR>(B, D, P.eta_out, G, i0, j0, C, sT + 5 * RA, P.sub_dt);
 }
 
+
+// =========================================================================================
+// FAST path
+// =========================================================================================
+// What limits the EXACT kernels is not HBM but the per-CU LDS pipe, the VALU instruction count and the
+// latency of 11 barrier phases (profiles/: ~10 LDS reads and ~75 VALU instructions per Laplacian point).
+// For finite values the same arithmetic needs far less machinery:
+//   * wave w owns K = (TR+10)/8 CONSECUTIVE plane rows; a thread keeps its K cells of every plane in
+//     registers, so the +-2 row neighbours of a Laplacian are registers except across a wave boundary
+//     (only the first/last two rows of each wave travel through LDS: 4 writes + 4 reads per phase
+//     instead of ~60 reads);
+//   * east / west neighbours come from the adjacent lanes with DPP wave shifts of the register value;
+//   * per-row metric tables are read with scalar loads (constant address space -> s_load into SGPRs);
+//   * nan_to_num is the identity on finite values: the fast path omits it, tests every owned output (and
+//     every clip input) with one v_cmp_class_f64 and, if any thread of the workgroup saw a non-finite
+//     value, the whole tile is recomputed on the EXACT path (outputs go to separate buffers, so that is
+//     safe).  A non-finite value anywhere in the stencil inputs of an owned cell reaches that cell.
+//   * POLE = false: interior tiles, straight-line code.  POLE = true: tiles holding a pole row, rows
+//     beyond a pole or rows off the slab: same code plus per-row (wave-uniform) patches -- literal
+//     one-sided np.gradient expressions for rows 0,1,n-2,n-1, zero for rows outside the domain.
+typedef const double __attribute__((address_space(4)))* qd_cptr;
+__device__ __forceinline__ double qd_sload(const double* p, int idx) { return ((qd_cptr)(unsigned long long)p)[idx]; }
+__device__ __forceinline__ bool qd_nonfinite(double x) { return __builtin_amdgcn_class(x, 0x207); }   // sNaN|qNaN|-inf|+inf
+// value held by lane+1 / lane-1 (the edge lanes keep their own value: they are halo columns)
+__device__ __forceinline__ double qd_east(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);     // wave_shl:1
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double qd_west(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);     // wave_shr:1
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <int TR> struct QdFast {
+    static constexpr int RA = TR + 10;
+    static constexpr int K = RA / QD_NW;                   // consecutive rows per wave
+    static constexpr bool ok = (RA % QD_NW) == 0 && K >= 2;
+};
+
+// Tile geometry of the FAST path.  A tile owns global rows [o0, o1) (o0 = row0 + t*TR) and works on the RA = TR+10
+// plane rows [p0, p0+RA).  Normally p0 = o0-5; next to a pole (or to the end of the row segment) the plane is
+// shifted so that it never leaves [0, n) (or the segment +-5 rows): there are no out-of-domain rows, hence no
+// masks.  An owned row needs 4 plane rows on each side except towards a pole, where the stencils stop anyway.
+__device__ __forceinline__ int qd_clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+struct QdFastTile { int p0, o0, o1; bool fits, interior; };
+template <int TR>
+__device__ __forceinline__ QdFastTile qd_fast_tile(const QdGeom& G, int i0) {
+    constexpr int RA = TR + 10;
+    const int n = G.nlat, s0 = G.row0, s1 = G.row0 + G.nrows;
+    const int lo = s0 == 0 ? 0 : s0 - 5, hi = s1 == n ? n : s1 + 5;
+    QdFastTile t;
+    t.o0 = i0; t.o1 = i0 + TR < s1 ? i0 + TR : s1;
+    t.p0 = qd_clampi(i0 - 5, lo, hi - RA);
+    t.fits = hi - lo >= RA && lo >= 0 && hi <= n && qd_lrow(G, t.p0) + RA <= G.lrows() && G.nlon >= 64;
+    t.interior = t.p0 >= 2 && t.p0 + RA <= n - 2;
+    return t;
+}
+
+struct QdPoleC { int n; const double* poleA; };
+
+// one spherical Laplacian over the wave's K rows.  X: the rows in registers, Xp: LDS plane for the rows that
+// cross a wave boundary.
+template <int TR, bool POLE>
+__device__ __forceinline__ void qd_lap_rows(const double (&X)[QdFast<TR>::K], double (&L)[QdFast<TR>::K], double* __restrict__ Xp,
+                                            int lane, int rho0, int g0, const double (&sA)[QdFast<TR>::K + 2],
+                                            const double (&sP)[QdFast<TR>::K], const double (&sQ)[QdFast<TR>::K], const QdPoleC& C) {
+    constexpr int K = QdFast<TR>::K, RA = QdFast<TR>::RA, S = QD_S;
+    Xp[(rho0 + 0) * S + lane] = X[0];
+    Xp[(rho0 + 1) * S + lane] = X[1];
+    Xp[(rho0 + K - 2) * S + lane] = X[K - 2];
+    Xp[(rho0 + K - 1) * S + lane] = X[K - 1];
+    __syncthreads();
+    double Y[K + 4];                                          // rows rho0-2 .. rho0+K+1 (clamped at the plane edges: halo rows)
+    Y[0] = Xp[qd_clampi(rho0 - 2, 0, RA - 1) * S + lane];
+    Y[1] = Xp[qd_clampi(rho0 - 1, 0, RA - 1) * S + lane];
+    Y[K + 2] = Xp[qd_clampi(rho0 + K, 0, RA - 1) * S + lane];
+    Y[K + 3] = Xp[qd_clampi(rho0 + K + 1, 0, RA - 1) * S + lane];
+#pragma unroll
+    for (int k = 0; k < K; ++k) Y[k + 2] = X[k];
+    const bool top = POLE && g0 == 0, bot = POLE && g0 + K == C.n;
+    double pA[8];
+    if (POLE) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pA[i] = qd_sload(C.poleA, i);
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const double c = Y[k + 2];
+        double ahi = c, alo = Y[k], bhi = Y[k + 4], blo = c, Aa = sA[k], Ab = sA[k + 2];
+        if (POLE) {
+            // the plane of a pole tile starts at row 0 or ends at row n-1, so the pole rows can only be the first
+            // two rows of wave 0 (types 0, 1) or the last two rows of the last wave (types 2, 3): wave-uniform tests
+            if (k == 0 && top) { ahi = Y[k + 3]; alo = c; Aa = pA[0]; Ab = pA[1]; }
+            if (k == 1 && top) { alo = Y[k + 1]; Aa = pA[2]; Ab = pA[3]; }
+            if (k == K - 2 && bot) { bhi = Y[k + 3]; Aa = pA[4]; Ab = pA[5]; }
+            if (k == K - 1 && bot) { bhi = c; blo = Y[k + 1]; Aa = pA[6]; Ab = pA[7]; }
+        }
+        const double Gb = Ab * (bhi - blo);
+        const double Ga = Aa * (ahi - alo);
+        const double d2 = (qd_east(c) - 2.0 * c) + qd_west(c);
+        L[k] = sP[k] * (Gb - Ga) + sQ[k] * d2;
+    }
+}
+
+// del^4 of the register field Bk (the wave's K rows) -> out.
+template <int TR, bool POLE>
+__device__ __forceinline__ void qd_del4_fast(const double (&Bk)[QdFast<TR>::K], double* __restrict__ Bp, double* __restrict__ Dp,
+                                             double* __restrict__ out, const QdGeom& G, const QdFastTile& t, int jraw, int lane, int rho0,
+                                             const double (&sA)[QdFast<TR>::K + 2], const double (&sP)[QdFast<TR>::K],
+                                             const double (&sQ)[QdFast<TR>::K], const double* k4row, double k4s, double dt,
+                                             const QdPoleC& C, bool& bad) {
+    constexpr int K = QdFast<TR>::K;
+    const int g0 = t.p0 + rho0;
+    double sK[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) sK[k] = k4row ? qd_sload(k4row, g0 + k) : k4s;
+    double Dk[K], L2[K];
+    qd_lap_rows<TR, POLE>(Bk, Dk, Bp, lane, rho0, g0, sA, sP, sQ, C);
+    qd_lap_rows<TR, POLE>(Dk, L2, Dp, lane, rho0, g0, sA, sP, sQ, C);
+    const bool col_ok = lane >= 3 && lane <= 60 && jraw < G.nlon;
+    double* op = out + (size_t)qd_lrow(G, g0) * G.nlon + jraw;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const double val = Bk[k] - (sK[k] * L2[k]) * dt;
+        const int g = g0 + k;
+        if (g >= t.o0 && g < t.o1) {                          // wave-uniform
+            bad |= qd_nonfinite(val);
+            if (col_ok) op[(size_t)k * G.nlon] = val;
+        }
+    }
+}
+
+template <int TR>
+__device__ __forceinline__ void qd_store_fast(const double (&Bk)[QdFast<TR>::K], double* __restrict__ out, const QdGeom& G,
+                                              const QdFastTile& t, int jraw, int lane, int rho0) {
+    constexpr int K = QdFast<TR>::K;
+    const int g0 = t.p0 + rho0;
+    const bool col_ok = lane >= 3 && lane <= 60 && jraw < G.nlon;
+    double* op = out + (size_t)qd_lrow(G, g0) * G.nlon + jraw;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int g = g0 + k;
+        if (g >= t.o0 && g < t.o1 && col_ok) op[(size_t)k * G.nlon] = Bk[k];
+    }
+}
+
+// atmosphere.  Returns this thread's "saw a non-finite value" flag.
+template <int TR, bool POLE>
+__device__ __forceinline__ bool qd_dyn_fast(const QdGeom& G, const QdTabs& T, const QdDynArgs& P, const QdFastTile& t, int j0, double* lds) {
+    constexpr int RA = QdFast<TR>::RA, K = QdFast<TR>::K, S = QD_S;
+    double* Ap = lds;
+    double* Bp = Ap + RA * S;
+    double* Dp = Bp + RA * S;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rho0 = wv * K, g0 = t.p0 + rho0;
+    const int jraw = j0 - 3 + lane, mlon = G.nlon, n = G.nlat;
+    const int j = jraw < 0 ? jraw + mlon : (jraw >= mlon ? jraw - mlon : jraw);
+    // ---- global loads of the momentum inputs (the wave's K rows), issued back to back; q and cloud are
+    //      loaded later into the registers u' and v' free up (they are not needed before their own del^4)
+    const unsigned o0 = (unsigned)qd_lrow(G, g0) * (unsigned)mlon + (unsigned)j;
+    double ah[K], ru[K], rv[K], rf[K], rq[K], rc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const unsigned o = o0 + (unsigned)k * (unsigned)mlon;
+        ah[k] = P.h[o]; ru[k] = P.u[o]; rv[k] = P.v[o]; rf[k] = P.fric[o];
+    }
+    // ---- row tables through the scalar cache
+    double sA[K + 2], sP[K], sQ[K], c8[K], c9[K];
+#pragma unroll
+    for (int k = 0; k < K + 2; ++k) sA[k] = qd_sload(T.lapA[0], POLE ? qd_clampi(g0 - 1 + k, 0, n - 1) : g0 - 1 + k);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        sP[k] = qd_sload(T.lapP[0], g0 + k); sQ[k] = qd_sload(T.lapQ[0], g0 + k);
+        c8[k] = qd_sload(P.primitive ? T.mom_px : T.mom_cu, g0 + k);
+        c9[k] = qd_sload(P.primitive ? T.fcor : T.mom_cv, g0 + k);
+    }
+    // ---- h rows that cross a wave boundary
+    Ap[rho0 * S + lane] = ah[0];
+    Ap[(rho0 + K - 1) * S + lane] = ah[K - 1];
+    __syncthreads();
+    const double hs_edge = Ap[qd_clampi(rho0 - 1, 0, RA - 1) * S + lane];
+    const double hn_edge = Ap[qd_clampi(rho0 + K, 0, RA - 1) * S + lane];
+    // ---- momentum (dynamics.py:488-530); np.gradient is one-sided at both ends of both axes
+    bool bad = false;
+    const bool west_edge = j == 0, east_edge = j == mlon - 1;
+    const double inv_lon = (west_edge || east_edge) ? P.inv_dlon : P.inv_2dlon;
+#define QD_MOM_ROWS(PRIM)                                                                                   \
+    _Pragma("unroll") for (int k = 0; k < K; ++k) {                                                         \
+        const int g = g0 + k;                                                                               \
+        const double hc = ah[k], hw = qd_west(hc), he = qd_east(hc);                                        \
+        const double hs = k > 0 ? ah[k > 0 ? k - 1 : 0] : hs_edge, hn = k < K - 1 ? ah[k < K - 1 ? k + 1 : 0] : hn_edge; \
+        const double dh_dlon = ((east_edge ? hc : he) - (west_edge ? hc : hw)) * inv_lon;                   \
+        double dh_dlat = (hn - hs) * P.inv_2dlat;                                                           \
+        if (POLE) { if (k == 0 && g == 0) dh_dlat = (hn - hc) * P.inv_dlat; if (k == K - 1 && g == n - 1) dh_dlat = (hc - hs) * P.inv_dlat; } \
+        const double u0 = ru[k], v0 = rv[k], fr = rf[k];                                                    \
+        if (PRIM) {                                                                                         \
+            const double ux = u0 + (c8[k] * dh_dlon + c9[k] * v0 - fr * u0) * P.dt;                         \
+            const double vx = v0 + (P.pgf_y * dh_dlat - c9[k] * u0 - fr * v0) * P.dt;                       \
+            bad |= qd_nonfinite(ux) | qd_nonfinite(vx);                                                     \
+            ru[k] = fmin(fmax(ux, -200.0), 200.0); rv[k] = fmin(fmax(vx, -200.0), 200.0);                   \
+        } else {                                                                                            \
+            const double ugx = c8[k] * dh_dlat, vgx = c9[k] * dh_dlon;                                      \
+            bad |= qd_nonfinite(ugx) | qd_nonfinite(vgx);                                                   \
+            const double u_g = fmin(fmax(ugx, -200.0), 200.0), v_g = fmin(fmax(vgx, -200.0), 200.0);        \
+            const double ur = u0 * 0.8 + u_g * 0.2;                                                         \
+            ru[k] = ur + (-fr * ur) * P.dt;                                                                 \
+            const double vr = v0 * 0.8 + v_g * 0.2;                                                         \
+            rv[k] = vr + (-fr * vr) * P.dt;                                                                 \
+        }                                                                                                   \
+    }
+    if (P.primitive) { QD_MOM_ROWS(true) } else { QD_MOM_ROWS(false) }
+#undef QD_MOM_ROWS
+    // the EXACT path zeroes the momentum result in lanes 0 and 63 (no east/west neighbour): keep the planes identical
+    if (lane == 0 || lane == 63) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) { ru[k] = 0.0; rv[k] = 0.0; }
+    }
+    const QdPoleC C{n, T.lapPoleA[0]};
+#define QD_FIELD(ARR, OUT, FI)                                                                              \
+    if (P.skip[FI]) qd_store_fast<TR>(ARR, OUT, G, t, jraw, lane, rho0);                                    \
+    else qd_del4_fast<TR, POLE>(ARR, Bp, Dp, OUT, G, t, jraw, lane, rho0, sA, sP, sQ, P.k4row[FI], P.k4s[FI], P.dt, C, bad);
+    QD_FIELD(ru, P.uo, 0)
+#pragma unroll
+    for (int k = 0; k < K; ++k) rq[k] = P.q[o0 + (unsigned)k * (unsigned)mlon];
+    QD_FIELD(rv, P.vo, 1)
+#pragma unroll
+    for (int k = 0; k < K; ++k) rc[k] = P.cloud[o0 + (unsigned)k * (unsigned)mlon];
+    QD_FIELD(ah, P.ho, 2)
+    QD_FIELD(rq, P.qo, 3)
+    QD_FIELD(rc, P.co, 4)
+#undef QD_FIELD
+    return bad;
+}
+
+// ocean sub-step
+template <int TR, bool POLE>
+__device__ __forceinline__ bool qd_ocn_fast(const QdGeom& G, const QdTabs& T, const QdOcnArgs& P, const QdFastTile& t, int j0, double* lds) {
+    constexpr int RA = QdFast<TR>::RA, K = QdFast<TR>::K, S = QD_S;
+    double* Ap = lds;
+    double* Bp = Ap + RA * S;
+    double* Dp = Bp + RA * S;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rho0 = wv * K, g0 = t.p0 + rho0;
+    const int jraw = j0 - 3 + lane, mlon = G.nlon, n = G.nlat;
+    const int j = jraw < 0 ? jraw + mlon : (jraw >= mlon ? jraw - mlon : jraw);
+    const unsigned o0 = (unsigned)qd_lrow(G, g0) * (unsigned)mlon + (unsigned)j;
+    double ae[K], ru[K], rv[K], rtx[K], rty[K];
+    int rl[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const unsigned o = o0 + (unsigned)k * (unsigned)mlon;
+        ae[k] = P.eta[o]; ru[k] = P.uo[o]; rv[k] = P.vo[o]; rtx[k] = P.taux[o]; rty[k] = P.tauy[o]; rl[k] = (int)P.land[o];
+    }
+    // eta rows wrap across the poles (np.roll(axis=0), ocean.py:308): the row beyond a pole is the other pole's row
+    double wrap_s = 0.0, wrap_n = 0.0;
+    if (POLE) {
+        if (g0 == 0) wrap_s = P.eta[(unsigned)qd_lrow(G, n - 1) * (unsigned)mlon + (unsigned)j];
+        if (g0 + K == n) wrap_n = P.eta[(unsigned)qd_lrow(G, 0) * (unsigned)mlon + (unsigned)j];
+    }
+    double sA[K + 2], sP[K], sQ[K], sF[K], sI[K], sX[K];
+#pragma unroll
+    for (int k = 0; k < K + 2; ++k) sA[k] = qd_sload(T.lapA[1], POLE ? qd_clampi(g0 - 1 + k, 0, n - 1) : g0 - 1 + k);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        sP[k] = qd_sload(T.lapP[1], g0 + k); sQ[k] = qd_sload(T.lapQ[1], g0 + k);
+        sF[k] = qd_sload(T.fcor, g0 + k); sI[k] = qd_sload(T.ocn_igx, g0 + k); sX[k] = qd_sload(T.r_extra, g0 + k);
+    }
+    Ap[rho0 * S + lane] = ae[0];
+    Ap[(rho0 + K - 1) * S + lane] = ae[K - 1];
+    __syncthreads();
+    double es_edge = Ap[qd_clampi(rho0 - 1, 0, RA - 1) * S + lane];
+    double en_edge = Ap[qd_clampi(rho0 + K, 0, RA - 1) * S + lane];
+    if (POLE) { if (g0 == 0) es_edge = wrap_s; if (g0 + K == n) en_edge = wrap_n; }
+    bool bad = false;
+    // ocean.py:306-336
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const double ec = ae[k];
+        const double es = k > 0 ? ae[k > 0 ? k - 1 : 0] : es_edge, en = k < K - 1 ? ae[k < K - 1 ? k + 1 : 0] : en_edge;
+        const double f = sF[k];
+        const double gx = ((qd_east(ec) - qd_west(ec)) * P.inv_2dlon) * sI[k];
+        const double gy = ((en - es) * P.inv_2dlat) * P.inv_a;
+        const double u0 = ru[k], v0 = rv[k];
+        const double du = (f * v0 - P.g * gx + rtx[k] * P.inv_rhoH - P.r_bot * u0);
+        const double dv = (-f * u0 - P.g * gy + rty[k] * P.inv_rhoH - P.r_bot * v0);
+        double un = u0 + P.sub_dt * du, vn = v0 + P.sub_dt * dv;
+        if (rl[k] == 1) { un = 0.0; vn = 0.0; }
+        const double sx = P.sub_dt * sX[k];
+        ru[k] = un - sx * un;
+        rv[k] = vn - sx * vn;
+    }
+    if (lane == 0 || lane == 63) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) { ru[k] = 0.0; rv[k] = 0.0; }
+    }
+    const QdPoleC C{n, T.lapPoleA[1]};
+#define QD_FIELD(ARR, OUT, FI)                                                                              \
+    if (P.skip[FI]) qd_store_fast<TR>(ARR, OUT, G, t, jraw, lane, rho0);                                    \
+    else qd_del4_fast<TR, POLE>(ARR, Bp, Dp, OUT, G, t, jraw, lane, rho0, sA, sP, sQ, P.k4row[FI], P.k4s[FI], P.sub_dt, C, bad);
+    QD_FIELD(ru, P.uo_out, 0)
+    QD_FIELD(rv, P.vo_out, 1)
+    QD_FIELD(ae, P.eta_out, 2)
+#undef QD_FIELD
+    return bad;
+}
+
+template <int TR>
+__global__ void __launch_bounds__(QD_FBLOCK, 4)
+k_dyn_hyper(QdGeom G, QdTabs T, QdDynArgs P) {
+    extern __shared__ __align__(16) double lds[];
+    int i0, j0;
+    qd_tile_origin(P.ts.ntc, P.ts.ntr, TR, G.row0, i0, j0);
+    if constexpr (QdFast<TR>::ok) {
+        const QdFastTile t = qd_fast_tile<TR>(G, i0);
+        if (P.fast && t.fits) {                                         // workgroup-uniform
+            const bool bad = t.interior ? qd_dyn_fast<TR, false>(G, T, P, t, j0, lds) : qd_dyn_fast<TR, true>(G, T, P, t, j0, lds);
+            if (!__syncthreads_or(bad)) return;
+        }
+    }
+    qd_dyn_exact<TR>(G, T, P, i0, j0, lds);
+}
+
+template <int TR>
+__global__ void __launch_bounds__(QD_FBLOCK, 4)
+k_ocn_hyper(QdGeom G, QdTabs T, QdOcnArgs P) {
+    extern __shared__ __align__(16) double lds[];
+    int i0, j0;
+    qd_tile_origin(P.ts.ntc, P.ts.ntr, TR, G.row0, i0, j0);
+    if constexpr (QdFast<TR>::ok) {
+        const QdFastTile t = qd_fast_tile<TR>(G, i0);
+        // a pole tile also reads the other pole's eta row (np.roll): it must be on this slab
+        const bool wrap_ok = t.interior || (qd_lrow(G, 0) < G.lrows() && qd_lrow(G, G.nlat - 1) < G.lrows());
+        if (P.fast && t.fits && wrap_ok) {
+            const bool bad = t.interior ? qd_ocn_fast<TR, false>(G, T, P, t, j0, lds) : qd_ocn_fast<TR, true>(G, T, P, t, j0, lds);
+            if (!__syncthreads_or(bad)) return;
+        }
+    }
+    qd_ocn_exact<TR>(G, T, P, i0, j0, lds);
+}
+
 // =========================================================================================
 // host side
 // =========================================================================================
@@ -447,14 +786,16 @@ static void qd_tile_init(qd_ctx* c) {
 template <int TR> static void launch_dyn(qd_ctx* c, const QdDynArgs& P, int margin) {
     static bool once = false;
     if (!once) { hipFuncSetAttribute((const void*)k_dyn_hyper<TR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)QdPl<TR>::lds_bytes); once = true; }
-    QD_ROWS(c, margin, G, hipLaunchKernelGGL(k_dyn_hyper<TR>, dim3(((G.nrows + TR - 1) / TR) * P.ts.ntc), dim3(QD_FBLOCK),
-                                             QdPl<TR>::lds_bytes, c->stream, G, c->tabs, P));
+    QdDynArgs Q = P;
+    QD_ROWS(c, margin, G, Q.ts.ntr = (G.nrows + TR - 1) / TR; hipLaunchKernelGGL(k_dyn_hyper<TR>, dim3(Q.ts.ntr * Q.ts.ntc), dim3(QD_FBLOCK),
+                                             QdPl<TR>::lds_bytes, c->stream, G, c->tabs, Q));
 }
 template <int TR> static void launch_ocn(qd_ctx* c, const QdOcnArgs& P, int margin) {
     static bool once = false;
     if (!once) { hipFuncSetAttribute((const void*)k_ocn_hyper<TR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)QdPl<TR>::lds_bytes); once = true; }
-    QD_ROWS(c, margin, G, hipLaunchKernelGGL(k_ocn_hyper<TR>, dim3(((G.nrows + TR - 1) / TR) * P.ts.ntc), dim3(QD_FBLOCK),
-                                             QdPl<TR>::lds_bytes, c->stream, G, c->tabs, P));
+    QdOcnArgs Q = P;
+    QD_ROWS(c, margin, G, Q.ts.ntr = (G.nrows + TR - 1) / TR; hipLaunchKernelGGL(k_ocn_hyper<TR>, dim3(Q.ts.ntr * Q.ts.ntc), dim3(QD_FBLOCK),
+                                             QdPl<TR>::lds_bytes, c->stream, G, c->tabs, Q));
 }
 
 #define QD_DISPATCH_TR(tr, CALL)                                                                              \
@@ -467,6 +808,7 @@ template <int TR> static void launch_ocn(qd_ctx* c, const QdOcnArgs& P, int marg
 int qd_launch_dyn_hyper(qd_ctx* c, QdDynArgs& P, int margin) {
     qd_tile_init(c);
     P.ts = c->tile;
+    P.fast = c->fused_fast;
     QdScope sc(c, "k_dyn_hyper");
 #define QD_CALL_DYN(N) launch_dyn<N>(c, P, margin)
     QD_DISPATCH_TR(P.ts.tr, QD_CALL_DYN)
@@ -476,6 +818,7 @@ int qd_launch_dyn_hyper(qd_ctx* c, QdDynArgs& P, int margin) {
 int qd_launch_ocn_hyper(qd_ctx* c, QdOcnArgs& P, int margin) {
     qd_tile_init(c);
     P.ts = c->tile;
+    P.fast = c->fused_fast;
     QdScope sc(c, "k_ocn_hyper");
 #define QD_CALL_OCN(N) launch_ocn<N>(c, P, margin)
     QD_DISPATCH_TR(P.ts.tr, QD_CALL_OCN)

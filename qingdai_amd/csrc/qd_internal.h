@@ -51,6 +51,7 @@ struct QdTabs {
     const double* lapA[2];
     const double* lapP[2];
     const double* lapQ[2];
+    const double* lapPoleA[2];   // [8]: (Aa, Ab) of the pole-row types g = 0, 1, n-2, n-1; lapP holds their P
     const double* mom_cu;    // -(g / (f_safe a cos6))   geostrophic u_g coefficient
     const double* mom_cv;    //   g / (f_safe a)         geostrophic v_g coefficient
     const double* mom_px;    // -(g / (a cos6))          primitive PGF_x coefficient
@@ -151,6 +152,7 @@ struct qd_ctx {
     int64_t atm_counter = 0, ocn_counter = 0;
     QdTileShape tile{0, 0, 0, 0};   // fused-kernel tile (qd_pick_tile)
     int use_fused = 1;              // QD_FUSED=0 selects the unfused reference-order kernels
+    int fused_fast = 1;             // QD_FUSED_FAST=0: every tile of the LDS-tiled kernels takes the EXACT path
     int cloud_eff_valid = 0;
     int last_nsub = 0;
     // host staging

@@ -76,3 +76,25 @@ def test_bands_full_step_with_ocean_and_physics(gpu):
     for k in ref:
         e = relerr(got[k], ref[k])
         assert e < 1e-12, (k, e)          # only the band-wise order of the global sums differs
+
+
+@pytest.mark.parametrize("shape", [(181, 360), (91, 144)])
+def test_fused_kernel_paths_agree(gpu, shape, monkeypatch):
+    """The fused momentum + del^4 kernels have a FAST path (register rows + DPP + scalar-loaded tables, no
+    nan_to_num) for interior and pole tiles and an EXACT path (every cell masked, literal nan_to_num) they fall
+    back to.  Same arithmetic in the same order: the two must agree bit for bit; both must agree with the
+    unfused reference-order kernels (QD_FUSED=0, true divisions instead of reciprocal tables) to rounding."""
+    nlat, nlon = shape
+    over = dict(energy_w=1.0, ocean_cfl=0.05)
+    monkeypatch.setenv("QD_FUSED_FAST", "0")
+    exact, _ = _run(1, nlat, nlon, 3, over, True, True)
+    monkeypatch.setenv("QD_FUSED_FAST", "1")
+    fast, _ = _run(1, nlat, nlon, 3, over, True, True)
+    monkeypatch.setenv("QD_FUSED", "0")
+    unfused, _ = _run(1, nlat, nlon, 3, over, True, True)
+    for k in exact:
+        assert np.array_equal(fast[k], exact[k]), (k, relerr(fast[k], exact[k]))
+    errs = {k: relerr(fast[k], unfused[k]) for k in fast}
+    print(errs)
+    for k, e in errs.items():
+        assert e < (1e-7 if k in ("UO", "VO", "ETA") else 1e-9), (k, e)
