@@ -254,6 +254,11 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
     hipMemsetAsync(c->dcount, 0, 8 * sizeof(unsigned long long), c->stream);
     hipMemsetAsync(c->hist, 0, 2 * QD_HIST_BINS * sizeof(unsigned int), c->stream);
     hipMemsetAsync(c->sel_state, 0, 8 * sizeof(unsigned long long), c->stream);
+    if (full) {
+        if ((e = hipMalloc(&c->sel_cand, 2 * cells * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
+        if ((e = hipMalloc(&c->sel_ccount, 2 * sizeof(unsigned int))) != hipSuccess) return bail("hipMalloc", e);
+        hipMemsetAsync(c->sel_ccount, 0, 2 * sizeof(unsigned int), c->stream);
+    }
     if ((e = hipHostMalloc((void**)&c->hpin, 64 * sizeof(double))) != hipSuccess) return bail("hipHostMalloc", e);
     // reference initial state
     const double q0 = std::min(std::max(q_init_rh, 0.0), 1.0) * host_qsat(288.0, params->p0);
@@ -280,6 +285,7 @@ extern "C" int qd_destroy(qd_handle c) {
     if (c->k4_atm) hipFree(c->k4_atm); if (c->k4_ocn) hipFree(c->k4_ocn);
     if (c->red_partial) hipFree(c->red_partial); if (c->dscal) hipFree(c->dscal);
     if (c->dcount) hipFree(c->dcount); if (c->hist) hipFree(c->hist); if (c->sel_state) hipFree(c->sel_state);
+    if (c->sel_cand) hipFree(c->sel_cand); if (c->sel_ccount) hipFree(c->sel_ccount);
     if (c->hpin) hipHostFree(c->hpin);
     if (c->stage) hipHostFree(c->stage);
     qd_resolve_timers(c);

@@ -147,6 +147,8 @@ struct qd_ctx {
     unsigned long long* dcount = nullptr;  // device counters
     unsigned int* hist = nullptr;  // [2][QD_HIST_BINS]
     unsigned long long* sel_state = nullptr; // radix-select state
+    double* sel_cand = nullptr;      // [2][cells] candidates of the two middle ranks after two radix passes (whole-globe handles)
+    unsigned int* sel_ccount = nullptr; // [2] candidate counts
     double* hpin = nullptr;        // pinned host scalars
     double wsum_ocean = 0, wsum_all = 0;
     int64_t atm_counter = 0, ocn_counter = 0;

@@ -250,6 +250,131 @@ k_sel_pass(QdGeom G, const double* __restrict__ x, int transform, double tparam,
     for (int k = t; k < 2 * QD_HIST_BINS; k += QD_BLOCK) __hip_atomic_store(&hist[k], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// After two histogram passes (22 bits: sign, exponent, 10 mantissa bits) the bucket of each middle rank holds
+// ~N/1000 entries of a continuous field.  Instead of four more passes over the whole field, ONE pass copies
+// the entries of the two buckets to a candidate list (wave-aggregated append), and one workgroup finishes the
+// radix select on the list.  The result does not depend on the order of the list.  Capacity = the whole field
+// (a constant field puts every entry in one bucket: slow, still exact).
+__global__ void __launch_bounds__(QD_BLOCK)
+k_sel_collect(QdGeom G, const double* __restrict__ x, int transform, double tparam, const unsigned long long* __restrict__ st,
+              double* __restrict__ cand, unsigned int* __restrict__ ccount, unsigned long long cap, int bits_done) {
+    const unsigned long long n0 = __hip_atomic_load(&st[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (n0 == 0ull) return;
+    const int up = 64 - bits_done;
+    const unsigned long long plo = __hip_atomic_load(&st[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> up;
+    const unsigned long long phi = __hip_atomic_load(&st[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> up;
+    const int t = threadIdx.x, lane = t & 63;
+    const int jstep = gridDim.x * QD_BLOCK;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int i = G.row0 + (int)blockIdx.y; i < G.row0 + G.nrows; i += (int)gridDim.y) {
+        const size_t b = (size_t)qd_lrow(G, i) * G.nlon;
+        for (int jb = blockIdx.x * QD_BLOCK; jb < G.nlon; jb += 8 * jstep) {
+            double vbuf[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int j = jb + q * jstep + t;
+                vbuf[q] = x[b + (j < G.nlon ? j : G.nlon - 1)];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int j0 = jb + q * jstep;
+                if (j0 >= G.nlon) break;                                  // wave-uniform
+                const int j = j0 + t;
+                const double v = (j < G.nlon) ? qd_med_value(vbuf[q], transform, tparam) : 0.0;
+                const unsigned long long hb = (unsigned long long)__double_as_longlong(v) >> up;
+                const bool pos = v > 0.0;
+                const bool in_lo = pos && hb == plo, in_hi = pos && plo != phi && hb == phi;
+                const unsigned long long mlo = __ballot(in_lo), mhi = __ballot(in_hi);
+                if (mlo) {
+                    unsigned int base = 0;
+                    const int leader = __ffsll((long long)mlo) - 1;
+                    if (lane == leader) base = atomicAdd(&ccount[0], (unsigned int)__popcll(mlo));
+                    base = (unsigned int)__shfl((int)base, leader, 64);
+                    if (in_lo) cand[base + (unsigned int)__popcll(mlo & lt)] = v;
+                }
+                if (mhi) {
+                    unsigned int base = 0;
+                    const int leader = __ffsll((long long)mhi) - 1;
+                    if (lane == leader) base = atomicAdd(&ccount[1], (unsigned int)__popcll(mhi));
+                    base = (unsigned int)__shfl((int)base, leader, 64);
+                    if (in_hi) cand[cap + base + (unsigned int)__popcll(mhi & lt)] = v;
+                }
+            }
+        }
+    }
+}
+
+#define QD_FIN_BLOCK 1024
+// one workgroup: remaining digits of both middle ranks on the candidate lists, the median, and the reset of all
+// select state (the job of k_sel_finish on the six-pass path)
+__global__ void __launch_bounds__(QD_FIN_BLOCK)
+k_sel_final(unsigned long long* st, const double* __restrict__ cand, unsigned int* ccount, unsigned long long cap, int bits_done,
+            double dflt, double* out, unsigned long long* count_out) {
+    __shared__ unsigned int sh[QD_HIST_BINS];
+    __shared__ unsigned int wtot[QD_FIN_BLOCK / 64];
+    __shared__ unsigned long long s_prefix, s_rank;
+    __shared__ unsigned long long s_res[2];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const unsigned long long n = st[0];
+    if (n > 0) {
+        const int up0 = 64 - bits_done;
+        const bool same = (st[1] >> up0) == (st[3] >> up0);
+        const int shifts[6] = {53, 42, 31, 20, 10, 0};
+        const int widths[6] = {11, 11, 11, 11, 10, 10};
+        for (int which = 0; which < 2; ++which) {
+            const int li = (which == 1 && !same) ? 1 : 0;
+            const double* list = cand + (size_t)li * cap;
+            const unsigned int M = ccount[li];
+            if (t == 0) { s_prefix = st[which == 0 ? 1 : 3]; s_rank = st[which == 0 ? 2 : 4]; }
+            __syncthreads();
+            int done = 0;
+            for (int p = 0; p < 6; ++p) {
+                done += widths[p];
+                if (done <= bits_done) continue;
+                const int shift = shifts[p], width = widths[p], up = shift + width;
+                for (int k = t; k < QD_HIST_BINS; k += QD_FIN_BLOCK) sh[k] = 0u;
+                __syncthreads();
+                const unsigned long long pre = s_prefix >> up, r = s_rank;
+                for (unsigned int k = t; k < M; k += QD_FIN_BLOCK) {
+                    const unsigned long long bits = (unsigned long long)__double_as_longlong(list[k]);
+                    if ((bits >> up) == pre) atomicAdd(&sh[(unsigned int)((bits >> shift) & ((1u << width) - 1u))], 1u);
+                }
+                __syncthreads();
+                // exclusive scan of the 2048 bins, 2 per thread
+                const unsigned int h0 = sh[2 * t], h1 = sh[2 * t + 1];
+                const unsigned int mine = h0 + h1;
+                unsigned int inc = mine;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const unsigned int y = __shfl_up(inc, o, 64); if (lane >= o) inc += y; }
+                if (lane == 63) wtot[wv] = inc;
+                __syncthreads();
+                unsigned int base = 0;
+                for (int k = 0; k < wv; ++k) base += wtot[k];
+                const unsigned long long excl = (unsigned long long)base + inc - mine;
+                if (mine > 0 && r >= excl && r < excl + mine) {
+                    const int d = (r < excl + h0) ? 2 * t : 2 * t + 1;
+                    s_prefix = s_prefix | ((unsigned long long)d << shift);
+                    s_rank = r - (d == 2 * t ? excl : excl + h0);
+                }
+                __syncthreads();
+            }
+            if (t == 0) s_res[which] = s_prefix;
+            __syncthreads();
+        }
+    }
+    if (t == 0) {
+        if (n == 0) *out = dflt;
+        else {
+            const double lo = __longlong_as_double((long long)s_res[0]);
+            const double hi = __longlong_as_double((long long)s_res[1]);
+            *out = (n & 1ull) ? lo : (lo + hi) / 2.0;     // np.median: mean of the two middles
+        }
+        if (count_out) *count_out = n;
+        for (int k = 0; k < 8; ++k) st[k] = 0ull;
+        ccount[0] = 0u; ccount[1] = 0u;
+    }
+}
+
 // result + reset of the select state for the next call; `count_out` (optional) keeps the count
 __global__ void k_sel_finish(unsigned long long* st, double dflt, double* out, unsigned long long* count_out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -274,6 +399,17 @@ int qd_median_positive_dev(qd_ctx* c, const double* x, double dflt, int slot, in
     static const int dbg = std::getenv("QD_SEL_DBG") ? std::atoi(std::getenv("QD_SEL_DBG")) : 0;
     static const int nblk = std::getenv("QD_SEL_BLOCKS") ? std::atoi(std::getenv("QD_SEL_BLOCKS")) : 128;
     dim3 grid(1, std::min(G.nrows, nblk));
+    if (c->geo.full && c->sel_cand) {
+        // two histogram passes, one collecting pass, one finishing workgroup
+        for (int p = 0; p < 2; ++p)
+            hipLaunchKernelGGL(k_sel_pass, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, c->sel_state,
+                               c->hist, shifts[p], widths[p], p == 0 ? 1 : 0, 0, dbg);
+        hipLaunchKernelGGL(k_sel_collect, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, c->sel_state,
+                           c->sel_cand, c->sel_ccount, (unsigned long long)c->geo.cells(), 22);
+        hipLaunchKernelGGL(k_sel_final, dim3(1), dim3(QD_FIN_BLOCK), 0, c->stream, c->sel_state, c->sel_cand, c->sel_ccount,
+                           (unsigned long long)c->geo.cells(), 22, dflt, c->dscal + slot, c->dcount);
+        return 0;
+    }
     for (int p = 0; p < 6; ++p) {
         if (c->geo.full) {
             hipLaunchKernelGGL(k_sel_pass, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, c->sel_state,

@@ -66,6 +66,18 @@ def test_median_exact(gpu):
         assert dev.op_median_positive(x, 1e-6) == want, n_pos          # bit-exact
     x = np.full((37, 72), 3.25)                                       # all equal
     assert dev.op_median_positive(x, 1e-6) == 3.25
+    # the two middle ranks in different 22-bit buckets, heavy ties, and a larger ragged grid
+    x = np.where(np.arange(37 * 72) % 2 == 0, 1.0, 4096.0).reshape(37, 72)
+    assert dev.op_median_positive(x, 1e-6) == float(np.median(x))
+    x = r.integers(1, 4, (37, 72)).astype(float) * 0.1
+    assert dev.op_median_positive(x, 1e-6) == float(np.median(x))
+    big = qa.SphericalGrid(181, 300)
+    bdev = big._ops()
+    for trial in range(3):
+        x = np.exp(r.normal(-9, 2, (181, 300))) * (r.random((181, 300)) < 0.6 + 0.2 * trial)
+        x[r.random(x.shape) < 0.01] *= -1.0
+        pos = x[x > 0]
+        assert bdev.op_median_positive(x, 1e-6) == float(np.median(pos)), trial
 
 
 @pytest.mark.parametrize("case", TS_CASES)
