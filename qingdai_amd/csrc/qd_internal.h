@@ -235,7 +235,8 @@ int  qd_shapiro_fields(qd_ctx* c, double** fields, int n, int npass, int m_out);
 void qd_launch_advect(qd_ctx* c, const double* u, const double* v, const double* coslat, double dt,
                       const double* f0, double* o0, const double* f1, double* o1, double alpha, int clipq, int m);
 void qd_launch_divvort(qd_ctx* c, const double* u, const double* v, double* out, int vort, int m);
-int  qd_gaussian(qd_ctx* c, const double* in, double* out, double* tmp, double sigma, int mode_wrap, int m_out);
+int  qd_gaussian(qd_ctx* c, const double* in, double* out, double* tmp, double sigma, int mode_wrap, int m_out, int clip01 = 0);
+int  qd_gaussian_swap(qd_ctx* c, double*& field, double*& tmp, double sigma, int mode_wrap, int m_out, int clip01 = 0);
 int  qd_gauss_radius(double sigma);
 int  qd_adv_reach(const qd_ctx* c, double dt, double vmax);
 

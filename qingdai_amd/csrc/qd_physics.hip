@@ -371,8 +371,8 @@ int qd_driver_physics_impl(qd_ctx* c, double dt) {
         qd_mark(c, {pdyn}, m);
         const int mg = qd_plan(c, {QD_IN(praw, R1), QD_IN(pdyn, R1)});
         if (mg < 0) return -1;
-        if (qd_gaussian(c, praw, praw, tmp, 1.0, 0, mg)) return -1;
-        if (qd_gaussian(c, pdyn, pdyn, tmp, 1.0, 0, mg)) return -1;
+        if (qd_gaussian_swap(c, praw, tmp, 1.0, 0, mg)) return -1;
+        if (qd_gaussian_swap(c, pdyn, tmp, 1.0, 0, mg)) return -1;
         QD_ROWS(c, mg, G, hipLaunchKernelGGL(k_precip_blend, qd_grid2d(G), blk, 0, c->stream, G, praw, pdyn,
                                              c->dscal + QD_S_RENORM, F[QD_F_PRECIP]));
         qd_mark(c, {F[QD_F_PRECIP]}, mg);
@@ -398,10 +398,8 @@ int qd_driver_physics_impl(qd_ctx* c, double dt) {
         qd_mark(c, {src}, ms);
         const int mg = qd_plan(c, {QD_IN(cfp, R1), QD_IN(src, R1), QD_IN(F[QD_F_CLOUD], 0)});
         if (mg < 0) return -1;
-        if (qd_gaussian(c, cfp, cfp, tmp, 1.0, 0, mg)) return -1;
-        QD_ROWS(c, mg, G, hipLaunchKernelGGL(k_clip01, qd_grid2d(G), blk, 0, c->stream, G, cfp));
-        if (qd_gaussian(c, src, src, tmp, 1.0, 0, mg)) return -1;
-        QD_ROWS(c, mg, G, hipLaunchKernelGGL(k_clip01, qd_grid2d(G), blk, 0, c->stream, G, src));
+        if (qd_gaussian_swap(c, cfp, tmp, 1.0, 0, mg, 1)) return -1;      // np.clip(gaussian(...), 0, 1)
+        if (qd_gaussian_swap(c, src, tmp, 1.0, 0, mg, 1)) return -1;
         double wm = p.w_mem, wp = p.w_p, ws = p.w_src, wsum = wm + wp + ws;
         if (wsum <= 0) { wm = 0.5; wp = 0.4; ws = 0.1; wsum = 1.0; }
         wm /= wsum; wp /= wsum; ws /= wsum;
@@ -421,7 +419,7 @@ int qd_driver_physics_impl(qd_ctx* c, double dt) {
                 const int rs = qd_gauss_radius(p.cloud_smooth_sigma);
                 const int mb = qd_plan(c, {QD_IN(adv, rs)});
                 if (mb < 0) return -1;
-                if (qd_gaussian(c, adv, adv, tmp, p.cloud_smooth_sigma, 1, mb)) return -1;
+                if (qd_gaussian_swap(c, adv, tmp, p.cloud_smooth_sigma, 1, mb)) return -1;
             }
             m = qd_plan(c, {QD_IN(adv, 0), QD_IN(F[QD_F_CLOUD], 0), QD_IN(F[QD_F_HICE], 0)});
         } else {

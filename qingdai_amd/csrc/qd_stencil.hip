@@ -235,8 +235,48 @@ k_gauss_axis(QdGeom G, const double* __restrict__ in, double* __restrict__ out, 
     out[o] = tmp;
 }
 
+__global__ void __launch_bounds__(QD_BLOCK) k_clip01_field(QdGeom G, double* __restrict__ x) {
+    const QdTile tl = qd_tile();
+    const int j = tl.seg * QD_BLOCK + threadIdx.x;
+    if (j >= G.nlon) return;
+    const size_t o = (size_t)qd_lrow(G, G.row0 + tl.row) * G.nlon + j;
+    x[o] = qd_clip(x[o], 0.0, 1.0);
+}
+
+// both axes in one launch: the axis-0 result of a row segment (+- r halo columns, recomputed, never exchanged)
+// goes to LDS and the axis-1 pass reads it from there -- same arithmetic in the same order as the two-kernel form,
+// without the round trip of the intermediate field through memory.  out must not alias in.
+__global__ void __launch_bounds__(QD_BLOCK)
+k_gauss_fused(QdGeom G, const double* __restrict__ in, double* __restrict__ out, QdGaussW W, int mode_wrap, int clip01) {
+    __shared__ double sm[QD_BLOCK + 2 * QD_GAUSS_MAXR];
+    const QdTile tl = qd_tile();
+    const int i = G.row0 + tl.row;
+    const int jbase = tl.seg * QD_BLOCK;
+    const int r = W.r;
+    for (int s = threadIdx.x; s < QD_BLOCK + 2 * r; s += QD_BLOCK) {
+        const int jj = jbase - r + s;
+        if (jj >= G.nlon + r) break;
+        const int j = qd_ext(jj, G.nlon, mode_wrap);
+        double tmp = in[(size_t)qd_lrow(G, i) * G.nlon + j] * W.w[0];
+        for (int k = r; k >= 1; --k) {
+            const double lo = in[(size_t)qd_lrow(G, qd_ext(i - k, G.nlat, mode_wrap)) * G.nlon + j];
+            const double hi = in[(size_t)qd_lrow(G, qd_ext(i + k, G.nlat, mode_wrap)) * G.nlon + j];
+            tmp += (lo + hi) * W.w[k];
+        }
+        sm[s] = tmp;
+    }
+    __syncthreads();
+    const int j = jbase + threadIdx.x;
+    if (j >= G.nlon) return;
+    const int c0 = threadIdx.x + r;
+    double acc = sm[c0] * W.w[0];
+    for (int k = r; k >= 1; --k) acc += (sm[c0 - k] + sm[c0 + k]) * W.w[k];
+    if (clip01) acc = qd_clip(acc, 0.0, 1.0);              // np.clip(blurred, 0, 1) of the caller, folded in
+    out[(size_t)qd_lrow(G, i) * G.nlon + j] = acc;
+}
+
 // gaussian_filter(in, sigma, mode): axis 0 then axis 1.  out may alias in; tmp is a distinct slab.
-int qd_gaussian(qd_ctx* c, const double* in, double* out, double* tmp, double sigma, int mode_wrap, int m_out) {
+int qd_gaussian(qd_ctx* c, const double* in, double* out, double* tmp, double sigma, int mode_wrap, int m_out, int clip01) {
     if (!(sigma > 1e-15)) {
         if (out != in) hipMemcpyAsync(out, in, c->geo.cells() * sizeof(double), hipMemcpyDeviceToDevice, c->stream);
         qd_mark(c, {out}, m_out);
@@ -265,8 +305,30 @@ int qd_gaussian(qd_ctx* c, const double* in, double* out, double* tmp, double si
     }
     for (int k = 0; k <= r; ++k) W.w[k] = phi[r + k] / tot;
     // axis 0 reaches r rows; axis 1 is row-local.  Both passes run on the output margin.
+    if (c->use_fused && out != in && c->geo.nlon > 2 * r) {
+        QD_ROWS(c, m_out, G, hipLaunchKernelGGL(k_gauss_fused, qd_grid2d(G), dim3(QD_BLOCK), 0, c->stream, G, in, out, W, mode_wrap, clip01));
+        qd_mark(c, {out}, m_out);
+        return 0;
+    }
     QD_ROWS(c, m_out, G, hipLaunchKernelGGL(k_gauss_axis, qd_grid2d(G), dim3(QD_BLOCK), 0, c->stream, G, in, tmp, W, 0, mode_wrap));
     QD_ROWS(c, m_out, G, hipLaunchKernelGGL(k_gauss_axis, qd_grid2d(G), dim3(QD_BLOCK), 0, c->stream, G, tmp, out, W, 1, mode_wrap));
     qd_mark(c, {tmp, out}, m_out);
+    if (clip01) {
+        QD_ROWS(c, m_out, G, hipLaunchKernelGGL(k_clip01_field, qd_grid2d(G), dim3(QD_BLOCK), 0, c->stream, G, out));
+    }
     return 0;
+}
+
+// in-place form for fields held in context slots: blur `field` into `tmp`, then exchange the two slots
+int qd_gaussian_swap(qd_ctx* c, double*& field, double*& tmp, double sigma, int mode_wrap, int m_out, int clip01) {
+    if (!(sigma > 1e-15)) {
+        if (clip01) QD_ROWS(c, m_out, G, hipLaunchKernelGGL(k_clip01_field, qd_grid2d(G), dim3(QD_BLOCK), 0, c->stream, G, field));
+        return 0;
+    }
+    if (c->use_fused && c->geo.nlon > 2 * qd_gauss_radius(sigma)) {
+        if (qd_gaussian(c, field, tmp, nullptr, sigma, mode_wrap, m_out, clip01)) return -1;
+        std::swap(field, tmp);
+        return 0;
+    }
+    return qd_gaussian(c, field, field, tmp, sigma, mode_wrap, m_out, clip01);
 }
