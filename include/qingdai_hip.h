@@ -156,6 +156,7 @@ int qd_op_hyperdiffuse(qd_handle h, const double* F, const double* k4_row, doubl
 int qd_op_advect(qd_handle h, const double* field, const double* u, const double* v, double dt,
                  int cos_kind, double* out);
 int qd_op_shapiro(qd_handle h, const double* F, int n, double* out);                /* dynamics.py:215-231 */
+int qd_op_zonal_filter(qd_handle h, const double* F, double cutoff, double damp, double* out); /* dynamics.py:233-258 */
 int qd_op_divergence(qd_handle h, const double* u, const double* v, double* out);   /* grid.py:41-68 */
 int qd_op_vorticity(qd_handle h, const double* u, const double* v, double* out);    /* grid.py:70-88 */
 int qd_op_gaussian(qd_handle h, const double* F, double sigma, int mode_wrap, double* out); /* physics.py:44 */

@@ -30,7 +30,7 @@ SYMBOLS = [
     "qd_abi_version", "qd_create", "qd_destroy", "qd_last_error", "qd_upload", "qd_download", "qd_set_params",
     "qd_get_step_counter", "qd_set_step_counter", "qd_forcing", "qd_simple_albedo", "qd_atmos_step",
     "qd_ocean_step", "qd_driver_physics", "qd_hydrology_commit", "qd_step_n", "qd_last_ocean_nsub", "qd_sync",
-    "qd_op_laplacian", "qd_op_hyperdiffuse", "qd_op_advect", "qd_op_shapiro", "qd_op_divergence",
+    "qd_op_laplacian", "qd_op_hyperdiffuse", "qd_op_advect", "qd_op_shapiro", "qd_op_zonal_filter", "qd_op_divergence",
     "qd_op_vorticity", "qd_op_gaussian", "qd_op_median_positive", "qd_reduce",
     "qd_comm_unique_id", "qd_comm_init", "qd_comm_init_local", "qd_comm_stats", "qd_comm_barrier", "qd_comm_allreduce_max",
     "qd_timing_enable", "qd_timing_select", "qd_timing_get", "qd_timing_reset",
@@ -82,6 +82,7 @@ def load():
     lib.qd_op_hyperdiffuse.argtypes = [vp, vp, vp, dbl, dbl, i32, i32, vp]
     lib.qd_op_advect.argtypes = [vp, vp, vp, vp, dbl, i32, vp]
     lib.qd_op_shapiro.argtypes = [vp, vp, i32, vp]
+    lib.qd_op_zonal_filter.argtypes = [vp, vp, dbl, dbl, vp]
     lib.qd_op_divergence.argtypes = [vp, vp, vp, vp]
     lib.qd_op_vorticity.argtypes = [vp, vp, vp, vp]
     lib.qd_op_gaussian.argtypes = [vp, vp, dbl, i32, vp]

@@ -21,7 +21,13 @@ static hipEvent_t qd_get_event(qd_ctx* c) {
     return e;
 }
 QdScope::QdScope(qd_ctx* c_, const char* n) : c(c_), name(n) {
-    on = c->timing == 1 || (c->timing == 2 && c->timing_sel == n);
+    on = c->timing == 1;
+    if (c->timing == 2) {                       // selection: one name or a comma-separated list
+        const std::string& sel = c->timing_sel;
+        const size_t ln = std::strlen(n);
+        for (size_t pos = sel.find(n); pos != std::string::npos && !on; pos = sel.find(n, pos + 1))
+            on = (pos == 0 || sel[pos - 1] == ',') && (pos + ln == sel.size() || sel[pos + ln] == ',');
+    }
     if (on) { e0 = qd_get_event(c); e1 = qd_get_event(c); hipEventRecord(e0, c->stream); }
 }
 QdScope::~QdScope() {
@@ -285,6 +291,7 @@ extern "C" int qd_destroy(qd_handle c) {
     if (c->k4_atm) hipFree(c->k4_atm); if (c->k4_ocn) hipFree(c->k4_ocn);
     if (c->red_partial) hipFree(c->red_partial); if (c->dscal) hipFree(c->dscal);
     if (c->dcount) hipFree(c->dcount); if (c->hist) hipFree(c->hist); if (c->sel_state) hipFree(c->sel_state);
+    if (c->zonal_tw) hipFree(c->zonal_tw);
     if (c->sel_cand) hipFree(c->sel_cand); if (c->sel_ccount) hipFree(c->sel_ccount);
     if (c->hpin) hipHostFree(c->hpin);
     if (c->stage) hipHostFree(c->stage);
@@ -543,6 +550,14 @@ static int seam_divvort(qd_ctx* c, const double* u, const double* v, double* out
     if (seam_in(c, c->scratch[10], u) || seam_in(c, c->scratch[11], v)) return -1;
     qd_launch_divvort(c, c->scratch[10], c->scratch[11], c->scratch[12], vort, 0);
     return seam_out(c, c->scratch[12], out);
+}
+extern "C" int qd_op_zonal_filter(qd_handle c, const double* F, double cutoff, double damp, double* out) {
+    if (!c || !F || !out) return -1;
+    hipSetDevice(c->desc.device);
+    if (seam_in(c, c->scratch[10], F)) return -1;
+    double* fl[1] = {c->scratch[10]};
+    if (qd_zonal_filter_fields(c, fl, 1, cutoff, damp, 0)) return -1;
+    return seam_out(c, c->scratch[10], out);
 }
 extern "C" int qd_op_divergence(qd_handle c, const double* u, const double* v, double* out) { return seam_divvort(c, u, v, out, 0); }
 extern "C" int qd_op_vorticity(qd_handle c, const double* u, const double* v, double* out) { return seam_divvort(c, u, v, out, 1); }

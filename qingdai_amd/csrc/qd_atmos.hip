@@ -315,8 +315,6 @@ int qd_atmos_step_impl(qd_ctx* c, double dt, int has_albedo) {
     const QdGeom& G0 = c->geo;
     const dim3 blk(QD_BLOCK);
     double** F = c->f;
-    if (p.spec_every > 0 && (p.filter_type == 0 || p.filter_type == 3))
-        return qd_fail(c, "zonal-FFT filter (QD_SPEC_EVERY>0) is not available on the device path yet");
     QdColP P = qd_make_colp(c, dt);
     const int R = qd_adv_reach(c, dt, 250.0);      // lat reach of the gather for |v| <= 250 m/s
 
@@ -435,6 +433,14 @@ int qd_atmos_step_impl(qd_ctx* c, double dt, int has_albedo) {
             const int mc = qd_plan(c, {QD_IN(F[QD_F_CLOUD], n1)}); if (mc < 0) return -1;
             double* g1[1] = {F[QD_F_CLOUD]}; qd_shapiro_fields(c, g1, 1, n1, mc); F[QD_F_CLOUD] = g1[0];
         }
+    }
+    // zonal spectral filter (dynamics.py:627-637): spectral and combo
+    if ((ft == 0 || ft == 3) && p.spec_every > 0 && (sc_ % p.spec_every == 0)) {
+        QdScope sc(c, "zonal_filter");
+        const int m = qd_plan(c, {QD_IN(F[QD_F_U], 0), QD_IN(F[QD_F_V], 0), QD_IN(F[QD_F_H], 0)});
+        if (m < 0) return -1;
+        double* fl[3] = {F[QD_F_U], F[QD_F_V], F[QD_F_H]};
+        if (qd_zonal_filter_fields(c, fl, 3, p.spec_cutoff, p.spec_damp, m)) return -1;
     }
     // cloud gather + decay + damp + scrub (dynamics.py:642-667)
     {

@@ -147,6 +147,7 @@ struct qd_ctx {
     unsigned long long* dcount = nullptr;  // device counters
     unsigned int* hist = nullptr;  // [2][QD_HIST_BINS]
     unsigned long long* sel_state = nullptr; // radix-select state
+    double* zonal_tw = nullptr;      // [2][nlon] cos / sin(2 pi m / nlon) of the zonal spectral filter
     double* sel_cand = nullptr;      // [2][cells] candidates of the two middle ranks after two radix passes (whole-globe handles)
     unsigned int* sel_ccount = nullptr; // [2] candidate counts
     double* hpin = nullptr;        // pinned host scalars
@@ -238,6 +239,7 @@ void qd_launch_divvort(qd_ctx* c, const double* u, const double* v, double* out,
 int  qd_gaussian(qd_ctx* c, const double* in, double* out, double* tmp, double sigma, int mode_wrap, int m_out, int clip01 = 0);
 int  qd_gaussian_swap(qd_ctx* c, double*& field, double*& tmp, double sigma, int mode_wrap, int m_out, int clip01 = 0);
 int  qd_gauss_radius(double sigma);
+int  qd_zonal_filter_fields(qd_ctx* c, double** fields, int nf, double cutoff, double damp, int m);
 int  qd_adv_reach(const qd_ctx* c, double dt, double vmax);
 
 // qd_reduce.hip

@@ -332,3 +332,90 @@ int qd_gaussian_swap(qd_ctx* c, double*& field, double*& tmp, double sigma, int 
     }
     return qd_gaussian(c, field, field, tmp, sigma, mode_wrap, m_out, clip01);
 }
+
+
+__global__ void __launch_bounds__(QD_BLOCK) k_scrub_field(QdGeom G, double* __restrict__ x) {
+    const QdTile tl = qd_tile();
+    const int j = tl.seg * QD_BLOCK + threadIdx.x;
+    if (j >= G.nlon) return;
+    const size_t o = (size_t)qd_lrow(G, G.row0 + tl.row) * G.nlon + j;
+    x[o] = qd_nn(x[o]);
+}
+
+// ------------------------------------------------------------------ zonal spectral filter (O4): dynamics.py:233-258
+// F' = nan_to_num(irfft(rfft(nan_to_num(F)) * factor)), factor = s = max(0, 1 - min(1, damp)) for bins >= kcut, else 1.
+// The filter is linear and row-local:  F' = F - (1 - s) * high,  high = irfft(X restricted to bins kcut..kN).
+// Only the damped bins (a quarter of the spectrum at the default cutoff 0.75) are transformed, with a direct DFT
+// per row: one workgroup per (row, field), the row and the twiddle table cos/sin(2 pi m / n) staged in LDS,
+// phase 1 one damped bin per thread, phase 2 one output column per thread.  Differs from pocketfft only by
+// summation order (rounding, ~1e-15 of the row's max-norm).
+__global__ void __launch_bounds__(QD_BLOCK)
+k_zonal_filter(QdGeom G, QdFieldList fl, const double* __restrict__ tw, int kcut, int kN, double one_minus_s) {
+    extern __shared__ double zs[];
+    const int n = G.nlon, nb = kN - kcut + 1;
+    double* x = zs;                 // [n]   nan_to_num(row)
+    double* tc = x + n;             // [n]   cos(2 pi m / n)
+    double* ts = tc + n;            // [n]   sin(2 pi m / n)
+    double* Xr = ts + n;            // [nb]
+    double* Xi = Xr + nb;           // [nb]
+    const int i = G.row0 + blockIdx.y, f = blockIdx.z;
+    double* Frow = fl.out[f] + (size_t)qd_lrow(G, i) * n;
+    for (int j = threadIdx.x; j < n; j += QD_BLOCK) { x[j] = qd_nn(Frow[j]); tc[j] = tw[j]; ts[j] = tw[n + j]; }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nb; b += QD_BLOCK) {
+        const int k = kcut + b;
+        double ar = 0.0, ai = 0.0;
+        int idx = 0;
+        for (int j = 0; j < n; ++j) {
+            const double v = x[j];
+            ar += v * tc[idx];
+            ai -= v * ts[idx];
+            idx += k; if (idx >= n) idx -= n;
+        }
+        Xr[b] = ar; Xi[b] = ai;
+    }
+    __syncthreads();
+    const bool even = (n & 1) == 0;
+    const double inv_n = 1.0 / (double)n;
+    for (int j = threadIdx.x; j < n; j += QD_BLOCK) {
+        double hp = 0.0;
+        int idx = (int)(((long long)j * kcut) % n);
+        for (int b = 0; b < nb; ++b) {
+            const bool nyq = even && (kcut + b == kN);            // irfft uses only the real part of the Nyquist bin, weight 1
+            const double t = Xr[b] * tc[idx] - (nyq ? 0.0 : Xi[b] * ts[idx]);
+            hp += nyq ? t : 2.0 * t;
+            idx += j; if (idx >= n) idx -= n;
+        }
+        Frow[j] = qd_nn(x[j] - one_minus_s * (hp * inv_n));
+    }
+}
+
+int qd_zonal_filter_fields(qd_ctx* c, double** fields, int nf, double cutoff, double damp, int m) {
+    const int n = c->geo.nlon;
+    if (!(damp > 0.0) || !(cutoff > 0.0) || n / 2 + 1 <= 1) {
+        // the reference still scrubs: nan_to_num(F)
+        for (int f = 0; f < nf; ++f)
+            QD_ROWS(c, m, G, hipLaunchKernelGGL(k_scrub_field, qd_grid2d(G), dim3(QD_BLOCK), 0, c->stream, G, fields[f]));
+        return 0;
+    }
+    const int kN = n / 2;                                         // rfft bins - 1
+    const int kcut = std::max(1, std::min(kN, (int)(cutoff * (double)kN)));
+    const double s = std::max(0.0, 1.0 - std::min(1.0, damp));
+    if (!c->zonal_tw) {
+        std::vector<double> tw(2 * (size_t)n);
+        for (int k = 0; k < n; ++k) { const double a = 2.0 * M_PI * (double)k / (double)n; tw[k] = std::cos(a); tw[n + k] = std::sin(a); }
+        if (hipMalloc(&c->zonal_tw, tw.size() * sizeof(double)) != hipSuccess) return qd_fail(c, "hipMalloc zonal twiddles");
+        QD_HIP(c, hipMemcpy(c->zonal_tw, tw.data(), tw.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    const int nb = kN - kcut + 1;
+    const size_t lds = sizeof(double) * (3 * (size_t)n + 2 * (size_t)nb);
+    if (lds > 150 * 1024) return qd_fail(c, "zonal filter: row too long for the LDS-staged DFT");
+    static bool once = false;
+    if (!once) { hipFuncSetAttribute((const void*)k_zonal_filter, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); once = true; }
+    QdFieldList fl{}; fl.n = nf;
+    for (int f = 0; f < nf; ++f) { fl.in[f] = fields[f]; fl.out[f] = fields[f]; }
+    QD_ROWS(c, m, G, hipLaunchKernelGGL(k_zonal_filter, dim3(1, G.nrows, nf), dim3(QD_BLOCK), lds, c->stream, G, fl, c->zonal_tw,
+                                        kcut, kN, 1.0 - s));
+    qd_mark(c, {fields[0], nf > 1 ? fields[1] : fields[0], nf > 2 ? fields[2] : fields[0]}, m);
+    return 0;
+}

@@ -211,6 +211,12 @@ class Device:
         self._chk(self.lib.qd_op_shapiro(self.h, a.ctypes.data, int(n), out.ctypes.data), "qd_op_shapiro")
         return out
 
+    def op_zonal_filter(self, Fh, cutoff=0.75, damp=0.5):
+        """SpectralModel._spectral_zonal_filter (dynamics.py:233-258)."""
+        a, out = _c(Fh), self._out()
+        self._chk(self.lib.qd_op_zonal_filter(self.h, a.ctypes.data, float(cutoff), float(damp), out.ctypes.data), "qd_op_zonal_filter")
+        return out
+
     def op_divvort(self, u, v, vort=False):
         uu, vv, out = _c(u), _c(v), self._out()
         fn = self.lib.qd_op_vorticity if vort else self.lib.qd_op_divergence

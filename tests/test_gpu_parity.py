@@ -18,7 +18,6 @@ from util import GOLD, STATE, DIAG, load_golden, relerr, surface, run_device_tim
 pytestmark = pytest.mark.gpu
 
 TS_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "ts_*.npz")))
-TS_CASES = [c for c in TS_CASES if "spectral" not in c]
 OC_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "ocean_*.npz")))
 OP_TOL = 1e-13
 STEP_TOL = 1e-9
@@ -35,7 +34,7 @@ def test_operators_vs_reference(gpu, shape):
         lap_atm=dev.op_laplacian(Fh), lap_ocn=dev.op_laplacian(Fh, ocean=True),
         hyper_atm=dev.op_hyperdiffuse(Fh, k4, dt, 1), hyper_atm_nsub2=dev.op_hyperdiffuse(Fh, 0.5 * k4, dt, 2),
         hyper_scalar=dev.op_hyperdiffuse(Fh, 1.0e14, dt, 1),
-        shapiro2=dev.op_shapiro(Fh, 2), shapiro1=dev.op_shapiro(Fh, 1),
+        shapiro2=dev.op_shapiro(Fh, 2), shapiro1=dev.op_shapiro(Fh, 1), spectral=dev.op_zonal_filter(Fh, 0.75, 0.5),
         div=dev.op_divvort(u, v), vort=dev.op_divvort(u, v, vort=True),
         gauss1=dev.op_gaussian(Fh, 1.0), gauss02_wrap=dev.op_gaussian(T, 0.2, "wrap"),
         advect_atm=dev.op_advect(T, u, v, dt), advect_ocn=dev.op_advect(T, 0.02 * u, 0.02 * v, dt, ocean=True),
