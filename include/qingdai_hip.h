@@ -91,6 +91,12 @@ typedef struct qd_params {
     double runoff_tau_days, wland_cap_mm, snow_thresh_K, snow_melt_rate_mm_day, snow_t_band_K;
     double snow_ddf_mm_per_k_day, snow_melt_tref_K, swe_ref_mm, swe_max_mm, snow_albedo_fresh;
     double lapse_k_kpm, land_elev_max_m, polar_ice_thick_max_m, polar_lat_thresh, rho_snow, glacier_frac, glacier_swe_mm;
+    /* orographic precipitation factor: physics.py:116-161, run_simulation.py:1612-1613,1769-1775 */
+    double orog_k;
+    /* the driver's own EnergyParams copy, nudged by autotune_greenhouse_params (energy.py:544-579,
+     * run_simulation.py:1245-1257,2242-2246); NaN = same as lw_eps0 / lw_kc.  Only the coupling block (Q_net,
+     * energy diagnostics) reads them, never time_step. */
+    double qnet_lw_eps0, qnet_lw_kc;
     /* integer switches */
     int32_t seaice_enabled, cloud_couple, lw_v2, gh_lock, polar_freeze_fix_s, polar_freeze_fix_n;
     int32_t mom_scheme;        /* 0 geos, 1 primitive (QD_MOM_SCHEME) */
@@ -102,6 +108,7 @@ typedef struct qd_params {
     int32_t p_hybrid_fallback, cloud_advect, use_topo_albedo, has_csmap;
     int32_t snow_melt_mode;    /* 0 degree_day, 1 constant (QD_SNOW_MELT_MODE) */
     int32_t swe_enable, lapse_enable;
+    int32_t orog_enable;       /* QD_OROG; takes effect once an ELEVATION field has been uploaded */
 } qd_params;
 
 /* ---- lifetime ------------------------------------------------------------------ */
@@ -163,6 +170,10 @@ int qd_op_gaussian(qd_handle h, const double* F, double sigma, int mode_wrap, do
 int qd_op_median_positive(qd_handle h, const double* x, double dflt, double* out);  /* dynamics.py:344-348 */
 
 /* ---- reductions for diagnostics (energy.py:494-538, ocean.py:535-561) -------------- */
+/* compute_energy_diagnostics (energy.py:494-538) from the resident state, with the flux formulas of the driver's
+ * coupling block (run_simulation.py:2199-2239): out[10] = cos-weighted global means of
+ * TOA_net, SFC_net, ATM_net, I, R, OLR, SW_sfc, LW_sfc, SH, LH. */
+int qd_energy_diagnostics(qd_handle h, double out[10]);
 enum qd_reduce_op { QD_R_SUM = 0, QD_R_COSWEIGHTED_MEAN = 1, QD_R_MAX = 2, QD_R_MIN = 3, QD_R_MAXABS = 4 };
 int qd_reduce(qd_handle h, int field, int op, double* out);
 

@@ -366,6 +366,42 @@ def case_physics(nlat, nlon, seed):
          Pc_wet=Pc_wet, base_albedo=alb, **{"ref_" + k: v for k, v in out.items()})
 
 
+def case_orography(nlat, nlon, seed):
+    """compute_orographic_factor (physics.py:116-161) and the hybrid precipitation with that factor
+    (run_simulation.py:1769-1781), from the REFERENCE's functions on a seeded elevation map."""
+    from types import SimpleNamespace
+    from pygcm import physics as rph
+    from qingdai_amd.topography import generate_elevation_map
+    g, mask, alb, fric = surface(nlat, nlon)
+    st = perturbed_state((nlat, nlon), seed, cloudy=True, icy=False)
+    r = np.random.default_rng(seed + 100)
+    elev = np.maximum(generate_elevation_map(g, seed=seed), 0.0) * (mask == 1)
+    Pc = np.abs(r.normal(3e-5, 2e-5, (nlat, nlon)))
+    with ref_env({}):
+        fac = rph.compute_orographic_factor(g, elev, st["u"], st["v"], k_orog=7e-4)
+        ns = SimpleNamespace(u=st["u"], v=st["v"], T_s=st["T_s"], cloud_cover=st["cloud_cover"], P_cond_flux_last=Pc)
+        pr = rph.diagnose_precipitation_hybrid(ns, g, D_crit=-1e-7, k_precip=1e5, orog_factor=fac, smooth_sigma=1.0,
+                                               beta_div=0.4, renorm=True)
+    P = qo.defaults(orog_enable=1)
+    og = qo.Grid(nlat, nlon)
+    ofac = oph.compute_orographic_factor(og, elev, st["u"], st["v"], k_orog=7e-4)
+    opr = oph.diagnose_precipitation_hybrid(ns, og, P, orog_factor=ofac)
+    print(f"    orog_factor        oracle-vs-ref maxrel {maxrel(ofac, fac):.2e}   (max factor {fac.max():.3f})")
+    print(f"    precip_orog        oracle-vs-ref maxrel {maxrel(opr, pr):.2e}")
+    # a strong QD_OROG_K so the cap (2.0) and the [1, 3] clip inside the precipitation are exercised
+    K2 = 0.08
+    with ref_env({}):
+        fac2 = rph.compute_orographic_factor(g, elev, st["u"], st["v"], k_orog=K2)
+        pr2 = rph.diagnose_precipitation_hybrid(ns, g, D_crit=-1e-7, k_precip=1e5, orog_factor=fac2, smooth_sigma=1.0,
+                                                beta_div=0.4, renorm=True)
+    ofac2 = oph.compute_orographic_factor(og, elev, st["u"], st["v"], k_orog=K2)
+    opr2 = oph.diagnose_precipitation_hybrid(ns, og, P, orog_factor=ofac2)
+    print(f"    strong k: factor maxrel {maxrel(ofac2, fac2):.2e} (max {fac2.max():.3f}); precip maxrel {maxrel(opr2, pr2):.2e}")
+    save(f"orog_{nlat}x{nlon}", dict(kind="orography", nlat=nlat, nlon=nlon, seed=seed, k_orog=7e-4, k_orog_strong=K2),
+         u=st["u"], v=st["v"], elevation=elev, Pc=Pc, T_s=st["T_s"], cloud_cover=st["cloud_cover"],
+         ref_orog_factor=fac, ref_precip_orog=pr, ref_orog_factor_strong=fac2, ref_precip_orog_strong=pr2)
+
+
 def case_driver_physics(nlat, nlon, seed, nsteps=3):
     """run_simulation.py:1766-1934 + 2063-2146 composed from the REFERENCE's functions
     (physics.*, scripts.run_simulation._advect_scalar_periodic, scipy gaussian_filter), interleaved
@@ -477,6 +513,10 @@ def main():
         for (a, b, sd) in ((19, 36, 41), (37, 72, 42)):
             print(f"[driver physics {a}x{b}]")
             case_driver_physics(a, b, sd)
+    if want("orog"):
+        for (a, b, s) in ((19, 36, 51), (37, 72, 52)):
+            print(f"[orography {a}x{b}]")
+            case_orography(a, b, s)
     if want("physics"):
         for (a, b, s) in ((19, 36, 31), (37, 72, 32)):
             print(f"[physics {a}x{b}]")

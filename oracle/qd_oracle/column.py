@@ -205,3 +205,10 @@ def energy_diagnostics(lat_mesh, I, R, OLR, SW_sfc, LW_sfc, SH, LH):
     return {"TOA_net": wm(TOA), "SFC_net": wm(SFC), "ATM_net": wm(ATM), "I_mean": wm(I),
             "R_mean": wm(R), "OLR_mean": wm(OLR), "SW_sfc_mean": wm(SW_sfc),
             "LW_sfc_mean": wm(LW_sfc), "SH_mean": wm(SH), "LH_mean": wm(LH)}
+
+
+def autotune_greenhouse(eps0, kc, diag, rate_eps=5e-5, rate_kc=2e-5, bounds_eps=(0.30, 0.98), bounds_kc=(0.0, 0.80)):
+    """energy.py:544-579: proportional nudge of (lw_eps0, lw_kc) by TOA_net; returns the new pair."""
+    err = float(diag.get("TOA_net", 0.0))
+    return (float(np.clip(eps0 - rate_eps * err, bounds_eps[0], bounds_eps[1])),
+            float(np.clip(kc - rate_kc * err, bounds_kc[0], bounds_kc[1])))

@@ -17,9 +17,17 @@ from .atmos import advect_semilag
 from .params import is_set
 
 
-def driver_physics_step(m, grid, P, base_albedo, land_mask, dt):
+def orog_factor_of(m, grid, P, elevation):
+    """run_simulation.py:1769-1775: only with QD_OROG=1 and an elevation map."""
+    if int(getattr(P, "orog_enable", 0)) == 1 and elevation is not None:
+        return ph.compute_orographic_factor(grid, elevation, m.u, m.v, k_orog=float(P.orog_k))
+    return None
+
+
+def driver_physics_step(m, grid, P, base_albedo, land_mask, dt, elevation=None):
     """Mutates m.cloud_cover; returns (precip, albedo).  `m` is an AtmosOracle."""
-    precip = ph.diagnose_precipitation_hybrid(m, grid, P, orog_factor=None, smooth_sigma=1.0, renorm=True)
+    precip = ph.diagnose_precipitation_hybrid(m, grid, P, orog_factor=orog_factor_of(m, grid, P, elevation),
+                                              smooth_sigma=1.0, renorm=True)
     # run_simulation.py:1866-1881
     if np.any(precip > 0):
         if is_set(P.pref) and P.pref != 0.0:
@@ -126,7 +134,8 @@ class DriverOracle:
         P, m, g = self.P, self.atm, self.grid
         land = (self.land_mask == 1)
         # --- precipitation + clouds (everything of driver_physics_step up to the cloud tracer)
-        precip = ph.diagnose_precipitation_hybrid(m, g, P, orog_factor=None, smooth_sigma=1.0, renorm=True)
+        precip = ph.diagnose_precipitation_hybrid(m, g, P, orog_factor=orog_factor_of(m, g, P, self.elevation),
+                                                  smooth_sigma=1.0, renorm=True)
         if np.any(precip > 0):
             P_ref = float(P.pref) if (is_set(P.pref) and P.pref != 0.0) else nx.median_positive(precip, 1e-6)
         else:

@@ -75,6 +75,8 @@ def defaults(**over):
         rho_snow=300.0, glacier_frac=0.60, glacier_swe_mm=50.0,
         snow_melt_mode=0,      # 0 = degree_day, 1 = constant
         swe_enable=1, lapse_enable=1,
+        orog_enable=0, orog_k=7e-4,   # run_simulation.py:1612-1613
+        qnet_lw_eps0=NAN, qnet_lw_kc=NAN,   # the driver's autotuned EnergyParams copy (run_simulation.py:2242-2246)
     )
     for k, v in over.items():
         if not hasattr(p, k):

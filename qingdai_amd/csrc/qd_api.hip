@@ -335,6 +335,7 @@ extern "C" int qd_upload(qd_handle c, int field, const void* host, size_t bytes)
         if (band_copy_in(c, c->f[field], host, sizeof(double))) return qd_fail(c, "qd_upload: copy failed");
         qd_mark(c, {c->f[field]}, c->geo.halo);
         if (field == QD_F_CLOUD_EFF) c->cloud_eff_valid = 1;
+        if (field == QD_F_ELEVATION) c->has_elevation = 1;
     }
     QD_HIP(c, hipStreamSynchronize(c->stream));    // host buffer is only borrowed for the call
     if (field == QD_F_LAND_MASK) {
@@ -591,6 +592,12 @@ extern "C" int qd_reduce(qd_handle c, int field, int op, double* out) {
     if (op == QD_R_COSWEIGHTED_MEAN) v = v / (c->wsum_all + 1e-15);
     *out = v;
     return 0;
+}
+
+extern "C" int qd_energy_diagnostics(qd_handle c, double* out) {
+    if (!c || !out) return -1;
+    hipSetDevice(c->desc.device);
+    return qd_energy_diag_impl(c, out);
 }
 
 // ------------------------------------------------------------------ timing

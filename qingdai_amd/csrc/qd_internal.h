@@ -147,6 +147,7 @@ struct qd_ctx {
     unsigned long long* dcount = nullptr;  // device counters
     unsigned int* hist = nullptr;  // [2][QD_HIST_BINS]
     unsigned long long* sel_state = nullptr; // radix-select state
+    int has_elevation = 0;           // an ELEVATION map has been uploaded (orographic factor needs one)
     double* zonal_tw = nullptr;      // [2][nlon] cos / sin(2 pi m / nlon) of the zonal spectral filter
     double* sel_cand = nullptr;      // [2][cells] candidates of the two middle ranks after two radix passes (whole-globe handles)
     unsigned int* sel_ccount = nullptr; // [2] candidate counts
@@ -181,7 +182,8 @@ struct qd_ctx {
 
 // device scalar slots
 enum { QD_S_PREF = 0, QD_S_ETA_MEAN, QD_S_MED_OUT, QD_S_PSCALE, QD_S_RENORM, QD_S_PQMEAN, QD_S_TMP0, QD_S_TMP1,
-       QD_S_COUNT = 16 };
+       QD_S_DIAG0 = 16,          // ten energy-budget means (qd_energy_diagnostics)
+       QD_S_COUNT = 32 };
 
 extern thread_local std::string g_qd_create_err;
 
@@ -239,6 +241,7 @@ void qd_launch_divvort(qd_ctx* c, const double* u, const double* v, double* out,
 int  qd_gaussian(qd_ctx* c, const double* in, double* out, double* tmp, double sigma, int mode_wrap, int m_out, int clip01 = 0);
 int  qd_gaussian_swap(qd_ctx* c, double*& field, double*& tmp, double sigma, int mode_wrap, int m_out, int clip01 = 0);
 int  qd_gauss_radius(double sigma);
+int  qd_energy_diag_impl(qd_ctx* c, double* host_out);    // qd_ocean.hip
 int  qd_zonal_filter_fields(qd_ctx* c, double** fields, int nf, double cutoff, double damp, int m);
 int  qd_adv_reach(const qd_ctx* c, double dt, double vmax);
 

@@ -38,6 +38,86 @@ k_qnet(QdGeom G, QdColP P, const double* __restrict__ isr, const double* __restr
     icemask[o] = (hi > 0.0) ? 1 : 0;
 }
 
+__device__ __forceinline__ double qd_wave_sum_d(double x);
+
+// ------------------------------------------------------------------ energy budget means (energy.py:494-538)
+// cos-weighted row sums of the ten budget terms, from the same flux function as k_qnet:
+//   0 TOA_net = I - R - OLR   1 SFC_net = SW_sfc - LW_sfc - SH - LH   2 ATM_net = TOA - SFC
+//   3 I  4 R  5 OLR  6 SW_sfc  7 LW_sfc  8 SH  9 LH
+#define QD_NDIAG 10
+__global__ void __launch_bounds__(QD_BLOCK)
+k_energy_diag(QdGeom G, QdTabs T, QdColP P, const double* __restrict__ isr, const double* __restrict__ albedo,
+              const double* __restrict__ cloud, const double* __restrict__ Ts, const double* __restrict__ h,
+              const double* __restrict__ u, const double* __restrict__ v, const uint8_t* __restrict__ land,
+              const double* __restrict__ hice, const double* __restrict__ LH, double* __restrict__ partial) {
+    __shared__ double sm[QD_NDIAG][QD_BLOCK / 64];
+    const int i = G.row0 + blockIdx.y;
+    const size_t b = (size_t)qd_lrow(G, i) * G.nlon;
+    const double w = T.warea[i];
+    double acc[QD_NDIAG];
+#pragma unroll
+    for (int k = 0; k < QD_NDIAG; ++k) acc[k] = 0.0;
+    for (int j = threadIdx.x; j < G.nlon; j += QD_BLOCK) {
+        const size_t o = b + j;
+        const double T_a = 288.0 + P.ga * h[o];
+        const double I = isr[o], lh = LH[o];
+        const QdFlux F = qd_surface_fluxes(P, I, albedo[o], cloud[o], Ts[o], T_a, u[o], v[o], land[o] == 1, hice[o]);
+        const double toa = I - F.R - F.OLR, sfc = F.SW_sfc - F.LW_sfc - F.SH - lh;
+        const double t[QD_NDIAG] = {toa, sfc, toa - sfc, I, F.R, F.OLR, F.SW_sfc, F.LW_sfc, F.SH, lh};
+#pragma unroll
+        for (int k = 0; k < QD_NDIAG; ++k) acc[k] += t[k] * w;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < QD_NDIAG; ++k) { const double s = qd_wave_sum_d(acc[k]); if (lane == 0) sm[k][wv] = s; }
+    __syncthreads();
+    if (threadIdx.x < QD_NDIAG) {
+        double r = sm[threadIdx.x][0];
+        for (int k = 1; k < QD_BLOCK / 64; ++k) r += sm[threadIdx.x][k];
+        partial[(size_t)threadIdx.x * gridDim.y + blockIdx.y] = r;
+    }
+}
+__global__ void __launch_bounds__(QD_BLOCK)
+k_energy_diag_finish(const double* __restrict__ partial, int nrows, double* __restrict__ out) {
+    __shared__ double sm[QD_BLOCK / 64];
+    for (int q = 0; q < QD_NDIAG; ++q) {
+        double a = 0.0;
+        for (int k = threadIdx.x; k < nrows; k += QD_BLOCK) a += partial[(size_t)q * nrows + k];
+        a = qd_wave_sum_d(a);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = a;
+        __syncthreads();
+        if (threadIdx.x == 0) { double r = sm[0]; for (int k = 1; k < QD_BLOCK / 64; ++k) r += sm[k]; out[q] = r; }
+    }
+}
+
+// the driver's coupling block works on its own EnergyParams copy (the one autotune nudges)
+static QdColP qd_make_colp_driver(const qd_ctx* c, double dt) {
+    QdColP P = qd_make_colp(c, dt);
+    if (c->p.qnet_lw_eps0 == c->p.qnet_lw_eps0) { P.lw_eps0 = c->p.qnet_lw_eps0; P.eps_clear = std::min(std::max(c->p.qnet_lw_eps0, 0.0), 1.0); }
+    if (c->p.qnet_lw_kc == c->p.qnet_lw_kc) P.lw_kc = c->p.qnet_lw_kc;
+    return P;
+}
+
+int qd_energy_diag_impl(qd_ctx* c, double* host_out) {
+    double** F = c->f;
+    QdColP P = qd_make_colp_driver(c, 0.0);
+    double*& cl = c->cloud_eff_valid ? F[QD_F_CLOUD_EFF] : F[QD_F_CLOUD];
+    const int m = qd_plan(c, {QD_IN(F[QD_F_ISR], 0), QD_IN(F[QD_F_ALBEDO], 0), QD_IN(cl, 0), QD_IN(F[QD_F_TS], 0), QD_IN(F[QD_F_H], 0),
+                              QD_IN(F[QD_F_U], 0), QD_IN(F[QD_F_V], 0), QD_IN(F[QD_F_HICE], 0), QD_IN(F[QD_F_LH], 0)});
+    if (m < 0) return -1;
+    const QdGeom G = qd_segments(c, 0).g[0];                 // owned rows only
+    if ((size_t)QD_NDIAG * G.nrows > (size_t)c->red_blocks) return qd_fail(c, "qd_energy_diagnostics: partial buffer too small");
+    hipLaunchKernelGGL(k_energy_diag, dim3(1, G.nrows), dim3(QD_BLOCK), 0, c->stream, G, c->tabs, P, F[QD_F_ISR], F[QD_F_ALBEDO], cl,
+                       F[QD_F_TS], F[QD_F_H], F[QD_F_U], F[QD_F_V], c->land, F[QD_F_HICE], F[QD_F_LH], c->red_partial);
+    hipLaunchKernelGGL(k_energy_diag_finish, dim3(1), dim3(QD_BLOCK), 0, c->stream, c->red_partial, G.nrows, c->dscal + QD_S_DIAG0);
+    if (qd_allreduce_f64(c, c->dscal + QD_S_DIAG0, QD_NDIAG, 0)) return -1;
+    QD_HIP(c, hipMemcpyAsync(c->hpin, c->dscal + QD_S_DIAG0, QD_NDIAG * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    QD_HIP(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < QD_NDIAG; ++k) host_out[k] = c->hpin[k] / (c->wsum_all + 1e-15);
+    return 0;
+}
+
 // ------------------------------------------------------------------ wind stress + CFL maxima
 __device__ __forceinline__ double qd_wave_max_d(double x) {
 #pragma unroll
@@ -443,7 +523,7 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
 
     if (compute_qnet) {
         QdScope sc(c, "ocean_qnet");
-        QdColP P = qd_make_colp(c, dt);
+        QdColP P = qd_make_colp_driver(c, dt);
         // cloud optical field: cloud_eff_last when time_step produced one, else cloud_cover
         double*& cl = c->cloud_eff_valid ? F[QD_F_CLOUD_EFF] : F[QD_F_CLOUD];
         const int m = qd_plan(c, {QD_IN(F[QD_F_ISR], 0), QD_IN(F[QD_F_ALBEDO], 0), QD_IN(cl, 0), QD_IN(F[QD_F_TS], 0),

@@ -26,7 +26,8 @@ __global__ void __launch_bounds__(QD_BLOCK)
 k_precip_raw(QdGeom G, QdTabs T, const double* __restrict__ u, const double* __restrict__ v,
              const double* __restrict__ pcond, double a, double dlat, double dlon, double D_crit, double beta,
              const double* __restrict__ scale_p, const unsigned long long* __restrict__ sel_state,
-             double* __restrict__ praw, double* __restrict__ pos_out, double* __restrict__ partial) {
+             double* __restrict__ praw, double* __restrict__ pos_out, double* __restrict__ partial,
+             const double* __restrict__ orog) {
     __shared__ double sm[2][QD_BLOCK / 64];
     const int i = G.row0 + blockIdx.y;
     const size_t b = (size_t)qd_lrow(G, i) * G.nlon;
@@ -39,7 +40,8 @@ k_precip_raw(QdGeom G, QdTabs T, const double* __restrict__ u, const double* __r
         const double pos = qd_max(0.0, -(div - D_crit));
         const double F_div = anypos ? qd_clip(pos / scale, 0.0, 5.0) : 0.0;
         const double Pq = qd_max(0.0, pcond[b + j]);
-        const double F = (1.0 + beta * F_div) * 1.0;          // F_orog = 1.0 (QD_OROG off)
+        const double F_orog = orog ? qd_clip(orog[b + j], 1.0, 3.0) : 1.0;     // physics.py:309-312
+        const double F = (1.0 + beta * F_div) * F_orog;
         const double pr = Pq * F;
         praw[b + j] = pr;
         pos_out[b + j] = pos;
@@ -55,6 +57,28 @@ k_precip_raw(QdGeom G, QdTabs T, const double* __restrict__ u, const double* __r
         partial[blockIdx.y] = s_num;
         partial[gridDim.y + blockIdx.y] = s_den;
     }
+}
+
+// compute_orographic_factor before its blur (physics.py:116-158): upslope wind on the elevation gradient
+// (np.roll on both axes, pole rows of dH/dy zeroed)
+__global__ void __launch_bounds__(QD_BLOCK)
+k_orog_factor(QdGeom G, QdTabs T, const double* __restrict__ elev, const double* __restrict__ u, const double* __restrict__ v,
+              double a, double dlat, double dlon, double k_orog, double cap, double* __restrict__ out) {
+    const QdTile tl = qd_tile();
+    const int j = tl.seg * QD_BLOCK + threadIdx.x;
+    if (j >= G.nlon) return;
+    const int i = G.row0 + tl.row, n = G.nlat;
+    const size_t b = (size_t)qd_lrow(G, i) * G.nlon;
+    const int jp = qd_wrapc(j + 1, G.nlon), jm = qd_wrapc(j - 1, G.nlon);
+    const double dx = a * T.cos6[i] * dlon, dy = a * dlat;
+    const double dHdx = (elev[b + jp] - elev[b + jm]) / (2.0 * dx);
+    double dHdy = 0.0;
+    if (i != 0 && i != n - 1)
+        dHdy = (elev[(size_t)qd_lrow(G, i + 1) * G.nlon + j] - elev[(size_t)qd_lrow(G, i - 1) * G.nlon + j]) / (2.0 * dy);
+    const double gn = sqrt(dHdx * dHdx + dHdy * dHdy);
+    const double nxh = gn > 1e-12 ? dHdx / (gn + 1e-12) : 0.0;
+    const double nyh = gn > 1e-12 ? dHdy / (gn + 1e-12) : 0.0;
+    out[b + j] = qd_clip(1.0 + k_orog * qd_max(0.0, u[b + j] * nxh + v[b + j] * nyh), 1.0, cap);
 }
 
 // s = num/den (renorm), Pq_mean = num / wsum; out[0] = s, out[1] = blend weight of the legacy field
@@ -333,6 +357,22 @@ int qd_driver_physics_impl(qd_ctx* c, double dt) {
         if (m < 0) return -1;
         qd_launch_divvort(c, F[QD_F_U], F[QD_F_V], tmp, 0, m);
         if (qd_median_positive_dev(c, tmp, 1e-12, QD_S_PSCALE, 1, p.D_crit)) return -1;
+        // orographic enhancement (run_simulation.py:1769-1775): only with QD_OROG=1 and an elevation map
+        const double* orog = nullptr;
+        if (p.orog_enable && c->has_elevation) {
+            double*& of = c->scratch[8];
+            const int mo = qd_plan(c, {QD_IN(F[QD_F_U], 0), QD_IN(F[QD_F_V], 0), QD_IN(F[QD_F_ELEVATION], 1)});
+            if (mo < 0) return -1;
+            QD_ROWS(c, mo, G, hipLaunchKernelGGL(k_orog_factor, qd_grid2d(G), blk, 0, c->stream, G, c->tabs, F[QD_F_ELEVATION],
+                                                 F[QD_F_U], F[QD_F_V], p.a, c->dlat, c->dlon, p.orog_k, 2.0, of));
+            qd_mark(c, {of}, mo);
+            const int mb = qd_plan(c, {QD_IN(of, R1)});
+            if (mb < 0) return -1;
+            if (qd_gaussian_swap(c, of, tmp, 1.0, 0, mb)) return -1;
+            orog = of;
+            m = qd_plan(c, {QD_IN(F[QD_F_U], 1), QD_IN(F[QD_F_V], 1), QD_IN(F[QD_F_PCOND], 0), QD_IN(c->scratch[8], 0)});
+            if (m < 0) return -1;
+        }
         // P_raw / pos on the margin; the two weighted sums over owned rows only
         if (band && m > 0) {
             QdSegs S = qd_segments(c, m);
@@ -344,7 +384,7 @@ int qd_driver_physics_impl(qd_ctx* c, double dt) {
                     QdGeom g2 = G; g2.row0 = r0; g2.nrows = r1 - r0;
                     hipLaunchKernelGGL(k_precip_raw, dim3(1, g2.nrows), blk, 0, c->stream, g2, c->tabs, F[QD_F_U], F[QD_F_V],
                                        F[QD_F_PCOND], p.a, c->dlat, c->dlon, p.D_crit, p.p_betadiv, c->dscal + QD_S_PSCALE,
-                                       c->dcount, praw, pos, c->red_partial + (size_t)2 * G0.lrows());
+                                       c->dcount, praw, pos, c->red_partial + (size_t)2 * G0.lrows(), orog);
                 };
                 const int a0 = G.row0, a1 = G.row0 + G.nrows;
                 if (a1 <= own0 || a0 >= own1) run(a0, a1);
@@ -353,7 +393,7 @@ int qd_driver_physics_impl(qd_ctx* c, double dt) {
         }
         hipLaunchKernelGGL(k_precip_raw, dim3(1, Gown.nrows), blk, 0, c->stream, Gown, c->tabs, F[QD_F_U], F[QD_F_V],
                            F[QD_F_PCOND], p.a, c->dlat, c->dlon, p.D_crit, p.p_betadiv, c->dscal + QD_S_PSCALE, c->dcount, praw,
-                           pos, c->red_partial);
+                           pos, c->red_partial, orog);
         qd_mark(c, {praw, pos}, m);
         if (band) {
             hipLaunchKernelGGL(k_precip_rawsums, dim3(1), blk, 0, c->stream, c->red_partial, Gown.nrows, c->dscal + QD_S_TMP0);

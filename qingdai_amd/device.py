@@ -211,6 +211,16 @@ class Device:
         self._chk(self.lib.qd_op_shapiro(self.h, a.ctypes.data, int(n), out.ctypes.data), "qd_op_shapiro")
         return out
 
+    ENERGY_DIAG_KEYS = ("TOA_net", "SFC_net", "ATM_net", "I_mean", "R_mean", "OLR_mean", "SW_sfc_mean", "LW_sfc_mean",
+                        "SH_mean", "LH_mean")
+
+    def energy_diagnostics(self):
+        """energy.compute_energy_diagnostics (energy.py:494-538) of the resident state -> dict of global means."""
+        self.flush()
+        out = (ctypes.c_double * 10)()
+        self._chk(self.lib.qd_energy_diagnostics(self.h, out), "qd_energy_diagnostics")
+        return dict(zip(self.ENERGY_DIAG_KEYS, [float(x) for x in out]))
+
     def op_zonal_filter(self, Fh, cutoff=0.75, damp=0.5):
         """SpectralModel._spectral_zonal_filter (dynamics.py:233-258)."""
         a, out = _c(Fh), self._out()

@@ -39,67 +39,58 @@ RESTART_VARS = {  # restart name -> device field (run_simulation.py:63-124)
 
 
 # ------------------------------------------------------------------------------------- NetCDF I/O
+from . import ncio  # noqa: E402
+
+
 def _nc_backend():
-    try:
-        import netCDF4  # noqa: F401
-        return "netCDF4"
-    except Exception:
-        return "scipy"
+    return ncio.backend()
 
 
 def save_restart(path, grid, dev, t_seconds, land_mask):
-    """run_simulation.py:63-124: dims lat/lon, f4 state variables, scalar t_seconds (f8), format=v1.
-    netCDF4 when importable, else NetCDF-3 classic through scipy.io (which has no u1: land_mask is i1)."""
-    os.makedirs(os.path.dirname(os.path.abspath(path)) or ".", exist_ok=True)
-    fields = {name: dev.get(fid).astype(np.float32) for name, fid in RESTART_VARS.items()}
-    if _nc_backend() == "netCDF4":
-        from netCDF4 import Dataset
-        with Dataset(path, "w") as ds:
-            ds.createDimension("lat", grid.n_lat)
-            ds.createDimension("lon", grid.n_lon)
-            ds.createVariable("lat", "f4", ("lat",))[:] = grid.lat
-            ds.createVariable("lon", "f4", ("lon",))[:] = grid.lon
-            for name, arr in fields.items():
-                ds.createVariable(name, "f4", ("lat", "lon"))[:] = arr
-            ds.createVariable("land_mask", "u1", ("lat", "lon"))[:] = land_mask.astype(np.uint8)
-            ds.createVariable("t_seconds", "f8", ())[...] = float(t_seconds)
-            ds.title = "Qingdai GCM Restart"
-            ds.creator = "qingdai_amd"
-            ds.format = "v1"
-    else:
-        from scipy.io import netcdf_file
-        with netcdf_file(path, "w", version=2) as ds:
-            ds.createDimension("lat", grid.n_lat)
-            ds.createDimension("lon", grid.n_lon)
-            v = ds.createVariable("lat", "f4", ("lat",)); v[:] = grid.lat.astype(np.float32)
-            v = ds.createVariable("lon", "f4", ("lon",)); v[:] = grid.lon.astype(np.float32)
-            for name, arr in fields.items():
-                v = ds.createVariable(name, "f4", ("lat", "lon")); v[:] = arr
-            v = ds.createVariable("land_mask", "i1", ("lat", "lon")); v[:] = land_mask.astype(np.int8)
-            v = ds.createVariable("t_seconds", "f8", ()); v[()] = float(t_seconds)
-            ds.title = b"Qingdai GCM Restart"
-            ds.creator = b"qingdai_amd"
-            ds.format = b"v1"
+    """run_simulation.py:63-124: dims lat/lon, f4 state variables, land_mask u1, scalar t_seconds (f8), format=v1.
+    netCDF4 when importable, else NetCDF-3 through scipy.io (no u1 there: land_mask is i1)."""
+    v = {"lat": ("f4", ("lat",), np.asarray(grid.lat, np.float32)), "lon": ("f4", ("lon",), np.asarray(grid.lon, np.float32))}
+    for name, fid in RESTART_VARS.items():
+        v[name] = ("f4", ("lat", "lon"), dev.get(fid).astype(np.float32))
+    v["land_mask"] = ("u1", ("lat", "lon"), np.asarray(land_mask, np.uint8))
+    v["t_seconds"] = ("f8", (), float(t_seconds))
+    ncio.write_nc(path, {"lat": grid.n_lat, "lon": grid.n_lon}, v,
+                  {"title": "Qingdai GCM Restart", "creator": "qingdai_amd", "format": "v1"})
 
 
 def load_restart(path):
-    """run_simulation.py:126-183: returns {name: float32 array} + t_seconds (arrays come back f4)."""
-    out = {}
-    if _nc_backend() == "netCDF4":
-        from netCDF4 import Dataset
-        with Dataset(path, "r") as ds:
-            for name in list(RESTART_VARS) + ["land_mask"]:
-                if name in ds.variables:
-                    out[name] = np.array(ds.variables[name][:])
-            out["t_seconds"] = float(ds.variables["t_seconds"][...]) if "t_seconds" in ds.variables else 0.0
-    else:
-        from scipy.io import netcdf_file
-        with netcdf_file(path, "r", mmap=False) as ds:
-            for name in list(RESTART_VARS) + ["land_mask"]:
-                if name in ds.variables:
-                    a = np.array(ds.variables[name][:])
-                    out[name] = a.astype(a.dtype.newbyteorder("="))       # classic NetCDF is big-endian on disk
-            out["t_seconds"] = float(ds.variables["t_seconds"].getValue()) if "t_seconds" in ds.variables else 0.0
+    """run_simulation.py:161-183: returns {name: float32 array} + t_seconds (arrays come back f4)."""
+    v, _ = ncio.read_nc(path, list(RESTART_VARS) + ["land_mask", "t_seconds"])
+    out = {k: a for k, a in v.items() if k != "t_seconds"}
+    out["t_seconds"] = float(v["t_seconds"]) if "t_seconds" in v else 0.0
+    return out
+
+
+def save_ocean(path, grid, dev, day_value=None):
+    """data/ocean.nc (run_simulation.py:185-220): uo, vo, eta, Ts as f4, attribute `day`.  Never raises."""
+    try:
+        v = {"lat": ("f4", ("lat",), np.asarray(grid.lat, np.float32)), "lon": ("f4", ("lon",), np.asarray(grid.lon, np.float32))}
+        for name, fid in (("uo", "UO"), ("vo", "VO"), ("eta", "ETA"), ("Ts", "SST")):
+            v[name] = ("f4", ("lat", "lon"), dev.get(fid).astype(np.float32))
+        attrs = {"title": "Qingdai Ocean State", "source": "qingdai_amd"}
+        if day_value is not None:
+            attrs["day"] = float(day_value)
+        ncio.write_nc(path, {"lat": grid.n_lat, "lon": grid.n_lon}, v, attrs)
+        return True
+    except Exception as e:                                  # the reference logs and carries on
+        print(f"[Ocean] Save failed: {e}")
+        return False
+
+
+def load_ocean(path):
+    """run_simulation.py:222-246: {uo, vo, eta, Ts, day}; missing entries are None.  Never raises."""
+    out = {"uo": None, "vo": None, "eta": None, "Ts": None, "day": None}
+    try:
+        v, attrs = ncio.read_nc(path, ["uo", "vo", "eta", "Ts"])
+        out.update({k: v.get(k) for k in ("uo", "vo", "eta", "Ts")})
+        out["day"] = float(attrs["day"]) if "day" in attrs else None
+    except Exception as e:
+        print(f"[Ocean] Load failed '{path}': {e}")
     return out
 
 
@@ -113,12 +104,25 @@ class Simulation:
         n_lon = int(n_lon if n_lon is not None else env.get("QD_N_LON", "240"))
         self.quiet = quiet
         self.grid = SphericalGrid(n_lat, n_lon)
-        self.land_mask, self.elevation = topo.create_land_sea_mask(self.grid, return_elevation=True)
-        self.base_albedo, self.friction = topo.generate_base_properties(self.land_mask)
-        if not quiet:
-            w = np.cos(np.deg2rad(self.grid.lat_mesh))
-            frac = float((w * (self.land_mask == 1)).sum() / (w.sum() + 1e-15))
-            print(f"[Topo] Procedural topography (seed 42). Land fraction: {frac:.3f}")
+        # run_simulation.py:1198-1215: external topography (QD_TOPO_NC) or the procedural seed-42 planet, for
+        # which the reference driver has NO elevation map (orography / lapse then see a flat bed)
+        topo_nc = env.get("QD_TOPO_NC")
+        self.elevation = None
+        loaded = False
+        if topo_nc and os.path.exists(topo_nc):
+            try:
+                self.elevation, self.land_mask, self.base_albedo, self.friction = topo.load_topography_from_netcdf(
+                    topo_nc, self.grid, quiet=quiet)
+                loaded = True
+            except Exception as e:
+                print(f"[Topo] Failed to load '{topo_nc}': {e}\nFalling back to procedural generation.")
+        if not loaded:
+            self.land_mask = topo.create_land_sea_mask(self.grid)
+            self.base_albedo, self.friction = topo.generate_base_properties(self.land_mask)
+            if not quiet:
+                w = np.cos(np.deg2rad(self.grid.lat_mesh))
+                frac = float((w * (self.land_mask == 1)).sum() / (w.sum() + 1e-15))
+                print(f"[Topo] Procedural topography (seed 42). Land fraction: {frac:.3f}")
         rho_w = float(env.get("QD_RHO_W", "1000"))
         cp_w = float(env.get("QD_CP_W", "4200"))
         H_mld = float(env.get("QD_MLD_M", "50"))
@@ -133,6 +137,8 @@ class Simulation:
                                  params=p, device=device)
         self.dev = self.gcm._dev
         self.dev.upload_now("BASE_ALBEDO", self.base_albedo)
+        if self.elevation is not None:
+            self.dev.upload_now("ELEVATION", np.nan_to_num(self.elevation))
         use_ocean = (int(env.get("QD_USE_OCEAN", "1")) == 1) if use_ocean is None else bool(use_ocean)
         self.ocean = None
         if use_ocean:
@@ -141,6 +147,7 @@ class Simulation:
                                              init_Ts=np.where(self.land_mask == 0, 288.0, 288.0))
         self.forcing = ThermalForcing(self.grid, OrbitalSystem())
         self.t = 0.0
+        self._step_index = 0
         self.dt = int(env.get("QD_DT_SECONDS", "300"))
         # banded initial surface temperature (run_simulation.py:310-328)
         if int(env.get("QD_INIT_BANDED", "0")) == 1:
@@ -166,16 +173,45 @@ class Simulation:
     def save(self, path):
         save_restart(path, self.grid, self.dev, self.t, self.land_mask)
 
+    def save_autosave(self, data_dir="data"):
+        """run_simulation.py:248-270 + 126-159 + 185-220: data/atmosphere.nc (the restart layout with the epoch
+        in t_seconds), data/ocean.nc, data/topography.nc.  Ecology / genes files are outside this path."""
+        day = self.t / (2 * np.pi / PLANET_OMEGA)
+        save_restart(os.path.join(data_dir, "atmosphere.nc"), self.grid, self.dev, self.t, self.land_mask)
+        if self.ocean is not None:
+            save_ocean(os.path.join(data_dir, "ocean.nc"), self.grid, self.dev, day_value=day)
+        topo.export_topography_to_netcdf(os.path.join(data_dir, "topography.nc"), self.grid, self.land_mask, self.base_albedo,
+                                         self.friction, elevation=self.elevation)
+
     # -- the loop
     def run_steps(self, n):
-        """n iterations of run_simulation.py:1760-2340, one resident qd_step_n call."""
+        """n iterations of run_simulation.py:1760-2340, one resident qd_step_n call (chunks of QD_ENERGY_TUNE_EVERY
+        steps when the greenhouse autotuner is on)."""
         if n <= 0:
             return
+        p = self.dev.params
+        autotune = (int(p.gh_lock) == 0) and int(os.environ.get("QD_ENERGY_AUTOTUNE", "0")) == 1 and self.ocean is not None
+        if autotune:                                           # run_simulation.py:1256-1257, 2242-2246
+            from . import energy as _energy
+            every = max(1, int(os.environ.get("QD_ENERGY_TUNE_EVERY", "50")))
+            left = n
+            while left > 0:
+                if self._step_index % every == 0:
+                    _energy.autotune_greenhouse_params(p, _energy.compute_energy_diagnostics(self.dev))
+                    self.dev.push_params()
+                k = min(left, every - (self._step_index % every))
+                self._run_chunk(k)
+                left -= k
+            return
+        self._run_chunk(n)
+
+    def _run_chunk(self, n):
         times = self.t + self.dt * np.arange(n)
         stars = self.forcing.star_table(times)
         self.dev.step_n(stars, float(self.dt), with_ocean=self.ocean is not None, with_physics=True, pass_albedo=False,
                         with_hydrology=True)
         self.t = float(times[-1] + self.dt)
+        self._step_index += n
 
     def diagnostics(self):
         d = self.dev
@@ -225,8 +261,11 @@ def main(argv=None):
         if state["saved"] or not autosave_on:
             return
         try:
-            sim.save(restart_out)
-            print(f"[Autosave] ({reason}) wrote {restart_out} at t={sim.t:.1f} s")
+            # run_simulation.py:1669-1687: data/atmosphere.nc (+ data/ocean.nc, data/topography.nc); QD_RESTART_OUT on top
+            sim.save_autosave(env.get("QD_DATA_DIR", "data"))
+            if env.get("QD_RESTART_OUT"):
+                sim.save(restart_out)
+            print(f"[Autosave] ({reason}) core state saved to 'data/atmosphere.nc' at t={sim.t:.1f} s")
         except Exception as e:     # noqa: BLE001  (the reference never lets I/O kill the run)
             print(f"[Autosave] skipped: {e}")
         state["saved"] = True

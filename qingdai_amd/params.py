@@ -65,6 +65,8 @@ _DOUBLES = [
     ("lapse_k_kpm", "QD_LAPSE_K_KPM", 6.5), ("land_elev_max_m", "QD_LAND_ELEV_MAX_M", 10000.0),
     ("polar_ice_thick_max_m", "QD_POLAR_ICE_THICK_MAX_M", 4500.0), ("polar_lat_thresh", "QD_POLAR_LAT_THRESH", 60.0),
     ("rho_snow", "QD_RHO_SNOW", 300.0), ("glacier_frac", "QD_GLACIER_FRAC", 0.60), ("glacier_swe_mm", "QD_GLACIER_SWE_MM", 50.0),
+    ("orog_k", "QD_OROG_K", 7e-4),
+    ("qnet_lw_eps0", None, NAN), ("qnet_lw_kc", None, NAN),
 ]
 # (field, env var, default) -- int32 switches
 _INTS = [
@@ -82,6 +84,7 @@ _INTS = [
     ("p_hybrid_fallback", "QD_P_HYBRID_FALLBACK", 1), ("cloud_advect", "QD_CLOUD_ADVECT", 1),
     ("use_topo_albedo", "QD_USE_TOPO_ALBEDO", 1), ("has_csmap", None, 0),
     ("snow_melt_mode", "QD_SNOW_MELT_MODE", 0), ("swe_enable", "QD_SWE_ENABLE", 1), ("lapse_enable", "QD_LAPSE_ENABLE", 1),
+    ("orog_enable", "QD_OROG", 0),
 ]
 
 

@@ -101,3 +101,80 @@ def generate_base_properties(mask):
     albedo = np.clip(np.where(mask == 1, 0.28, 0.08), 0.05, 0.85)
     friction = np.clip(np.where(mask == 1, 1.0e-5, 1.0e-6), 5e-7, 3e-5)
     return albedo, friction
+
+
+# ------------------------------------------------------------------------------------- topography files
+def export_topography_to_netcdf(path, grid, land_mask, base_albedo, friction, elevation=None, title="Qingdai Topography"):
+    """data/topography.nc (run_simulation.py:126-159; pygcm/topography.py:349-426): lat, lon (f4),
+    land_mask (u1), base_albedo, friction (f4), optional elevation (f4)."""
+    from . import ncio
+    v = {"lat": ("f4", ("lat",), np.asarray(grid.lat, np.float32)), "lon": ("f4", ("lon",), np.asarray(grid.lon, np.float32)),
+         "land_mask": ("u1", ("lat", "lon"), np.asarray(land_mask, np.uint8)),
+         "base_albedo": ("f4", ("lat", "lon"), np.asarray(base_albedo, np.float32)),
+         "friction": ("f4", ("lat", "lon"), np.asarray(friction, np.float32))}
+    if elevation is not None:
+        v["elevation"] = ("f4", ("lat", "lon"), np.asarray(elevation, np.float32))
+    ncio.write_nc(path, {"lat": grid.n_lat, "lon": grid.n_lon}, v, {"title": title, "source": "qingdai_amd", "format": "v1"})
+
+
+def _regrid(src_lat, src_lon, field, grid, nearest):
+    """Bilinear (nearest for the mask) onto the model grid, cyclic in longitude, latitudes clamped to the
+    source range; non-finite bilinear results fall back to nearest (pygcm/topography.py:485-520)."""
+    from scipy.interpolate import RegularGridInterpolator
+    lon3 = np.concatenate([src_lon - 360.0, src_lon, src_lon + 360.0])
+    f3 = np.concatenate([field, field, field], axis=1).astype(float)
+    pts = np.stack([np.clip(grid.lat_mesh.ravel(), src_lat.min(), src_lat.max()), grid.lon_mesh.ravel()], axis=-1)
+
+    def run(method):
+        return RegularGridInterpolator((src_lat, lon3), f3, bounds_error=False, fill_value=None, method=method)(pts).reshape(
+            grid.lat_mesh.shape)
+    if nearest:
+        return np.where(run("nearest") >= 0.5, 1, 0).astype(np.uint8)
+    vals = run("linear")
+    bad = ~np.isfinite(vals)
+    if bad.any():
+        vals = np.where(bad, run("nearest"), vals)
+    return vals
+
+
+def load_topography_from_netcdf(path, grid, regrid="auto", quiet=False):
+    """-> (elevation | None, land_mask u8, base_albedo, friction) on `grid` (pygcm/topography.py:428-575).
+    Source longitudes are brought to [0, 360) and sorted, descending latitudes flipped, a duplicated 0/360
+    seam column dropped; an exact grid match is taken as is, anything else is regridded unless regrid="never"."""
+    from . import ncio
+    v, _ = ncio.read_nc(path, ["lat", "lon", "elevation", "land_mask", "base_albedo", "friction"])
+    lat, lon = np.asarray(v["lat"], float), np.asarray(v["lon"], float)
+    if np.nanmin(lon) < 0.0 or np.nanmax(lon) <= 180.0:
+        lon = np.mod(lon, 360.0)
+    flip = not np.all(np.diff(lat) > 0)
+    if flip:
+        lat = lat[::-1]
+    order = np.argsort(lon)
+    lon = lon[order]
+
+    def field(name):
+        if name not in v:
+            return None
+        a = np.asarray(v[name])
+        a = a[::-1, :] if flip else a
+        return a[:, order]
+    F = {k: field(k) for k in ("elevation", "land_mask", "base_albedo", "friction")}
+    if lon.size >= 2 and np.isclose(lon[0], 0.0) and np.isclose(lon[-1], 360.0):
+        lon = lon[:-1]
+        F = {k: (a[:, :-1] if a is not None else None) for k, a in F.items()}
+    exact = F["land_mask"].shape == (grid.n_lat, grid.n_lon) and (
+        regrid == "never" or (np.allclose(lat, grid.lat, atol=1e-6) and np.allclose(lon, grid.lon, atol=1e-6)))
+    if exact:
+        elev = None if F["elevation"] is None else F["elevation"].astype(float)
+        mask, alb, fric = F["land_mask"].astype(np.uint8), F["base_albedo"].astype(float), F["friction"].astype(float)
+    else:
+        if regrid == "never":
+            raise ValueError(f"topography grid mismatch: source {F['land_mask'].shape} vs target {(grid.n_lat, grid.n_lon)}")
+        elev = None if F["elevation"] is None else _regrid(lat, lon, F["elevation"], grid, False)
+        mask = _regrid(lat, lon, F["land_mask"], grid, True)
+        alb, fric = _regrid(lat, lon, F["base_albedo"], grid, False), _regrid(lat, lon, F["friction"], grid, False)
+    if not quiet:
+        w = np.cos(np.deg2rad(grid.lat_mesh))
+        print(f"[Topo] Loaded: {path}")
+        print(f"[Topo] Land fraction (achieved): {float((w * (mask == 1)).sum() / (w.sum() + 1e-15)):.3f}")
+    return elev, mask, alb, fric

@@ -30,3 +30,89 @@ def test_restart_roundtrip(tmp_path):
     for name, fid in RESTART_VARS.items():
         assert rst[name].dtype == np.float32                       # the reference stores f4
         assert np.array_equal(rst[name], dev.get(fid).astype(np.float32)), name
+
+
+def test_ocean_file_roundtrip(tmp_path):
+    """data/ocean.nc (run_simulation.py:185-246): four f4 fields + the `day` attribute; loaders never raise."""
+    from qingdai_amd.driver import save_ocean, load_ocean
+    from qingdai_amd.grid import SphericalGrid
+    g = SphericalGrid(19, 36)
+    dev = _FakeDev((19, 36))
+    path = str(tmp_path / "data" / "ocean.nc")
+    assert save_ocean(path, g, dev, day_value=12.25)
+    oc = load_ocean(path)
+    assert oc["day"] == 12.25
+    for name, fid in (("uo", "UO"), ("vo", "VO"), ("eta", "ETA"), ("Ts", "SST")):
+        assert oc[name].dtype == np.float32 and np.array_equal(oc[name], dev.get(fid).astype(np.float32))
+    missing = load_ocean(str(tmp_path / "nope.nc"))
+    assert all(v is None for v in missing.values())
+
+
+def test_topography_file_roundtrip_and_regrid(tmp_path):
+    """data/topography.nc (run_simulation.py:126-159, pygcm/topography.py:349-575): exact-grid read returns the
+    stored maps; a coarser source is regridded bilinearly (nearest for the mask), cyclic in longitude; a source
+    with longitudes in [-180, 180) and descending latitudes is normalised first."""
+    from qingdai_amd import topography as topo
+    from qingdai_amd.grid import SphericalGrid
+    g = SphericalGrid(19, 36)
+    mask, elev = topo.create_land_sea_mask(g, return_elevation=True)
+    alb, fric = topo.generate_base_properties(mask)
+    p = str(tmp_path / "topography.nc")
+    topo.export_topography_to_netcdf(p, g, mask, alb, fric, elevation=elev)
+    e2, m2, a2, f2 = topo.load_topography_from_netcdf(p, g, quiet=True)
+    # the model grid's longitudes run 0..360 inclusive (SphericalGrid: linspace(0, 360, n_lon)): like the reference
+    # loader, the duplicated seam column is dropped and the file is regridded -- nodes coincide (to the f4 rounding
+    # of the stored coordinates), the last column becomes the cyclic image of the first
+    assert m2.dtype == np.uint8 and np.array_equal(m2[:, :-1], mask[:, :-1]) and np.array_equal(m2[:, -1], m2[:, 0])
+    assert np.allclose(e2[:, :-1], elev[:, :-1], rtol=1e-4, atol=1e-3 * np.abs(elev).max())
+    assert np.allclose(a2[:, :-1], alb[:, :-1], atol=1e-5) and np.allclose(f2[:, :-1], fric[:, :-1], rtol=1e-4)
+    # no elevation variable -> None (the procedural planet of the reference driver has none)
+    p2 = str(tmp_path / "noelev.nc")
+    topo.export_topography_to_netcdf(p2, g, mask, alb, fric)
+    assert topo.load_topography_from_netcdf(p2, g, quiet=True)[0] is None
+    # regrid: a smooth analytic field on a different grid comes back within the bilinear error
+    src = SphericalGrid(37, 72)
+    f = 1000.0 * np.cos(np.deg2rad(src.lat_mesh)) * (1.0 + 0.3 * np.sin(np.deg2rad(src.lon_mesh)))
+    msk = (src.lat_mesh > 10).astype(np.uint8)
+    p3 = str(tmp_path / "coarse.nc")
+    topo.export_topography_to_netcdf(p3, src, msk, np.full(src.lat_mesh.shape, 0.2), np.full(src.lat_mesh.shape, 1e-5), elevation=f)
+    e3, m3, a3, _ = topo.load_topography_from_netcdf(p3, g, quiet=True)
+    want = 1000.0 * np.cos(np.deg2rad(g.lat_mesh)) * (1.0 + 0.3 * np.sin(np.deg2rad(g.lon_mesh)))
+    assert np.max(np.abs(e3 - want)) < 5.0 and np.allclose(a3, 0.2, atol=1e-6)
+    assert np.array_equal(m3, (g.lat_mesh > 10).astype(np.uint8))
+    with np.testing.assert_raises(ValueError):
+        topo.load_topography_from_netcdf(p3, g, regrid="never", quiet=True)
+    # [-180, 180) longitudes + descending latitudes
+    from qingdai_amd import ncio
+    lat_d = np.linspace(90.0, -90.0, 37)
+    lon_w = np.linspace(-180.0, 175.0, 72)
+    LON, LAT = np.meshgrid(np.mod(lon_w, 360.0), lat_d)
+    fw = 1000.0 * np.cos(np.deg2rad(LAT)) * (1.0 + 0.3 * np.sin(np.deg2rad(LON)))
+    ncio.write_nc(str(tmp_path / "w.nc"), {"lat": 37, "lon": 72},
+                  {"lat": ("f4", ("lat",), lat_d.astype(np.float32)), "lon": ("f4", ("lon",), lon_w.astype(np.float32)),
+                   "land_mask": ("u1", ("lat", "lon"), (LAT > 10).astype(np.uint8)),
+                   "base_albedo": ("f4", ("lat", "lon"), np.full((37, 72), 0.2)),
+                   "friction": ("f4", ("lat", "lon"), np.full((37, 72), 1e-5)), "elevation": ("f4", ("lat", "lon"), fw)})
+    e4, m4, _, _ = topo.load_topography_from_netcdf(str(tmp_path / "w.nc"), g, quiet=True)
+    assert np.max(np.abs(e4 - want)) < 5.0 and np.array_equal(m4, (g.lat_mesh > 10).astype(np.uint8))
+
+
+def test_greenhouse_autotune_matches_oracle():
+    """energy.autotune_greenhouse_params (energy.py:544-579): proportional nudge, bounds, and that it moves the DRIVER's
+    copy (qnet_lw_*) and leaves the model's lw_eps0 / lw_kc alone (run_simulation.py:2242-2246)."""
+    import math
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    from qd_oracle import column as col
+    import qingdai_amd as qa
+    from qingdai_amd import energy
+    p = qa.QdParams()
+    e0, k0 = p.lw_eps0, p.lw_kc
+    assert math.isnan(p.qnet_lw_eps0) and math.isnan(p.qnet_lw_kc)
+    eps, kc = e0, k0
+    for toa in (12.5, -3.0, 4000.0, -9000.0, -9000.0, 0.0):
+        energy.autotune_greenhouse_params(p, {"TOA_net": toa}, verbose=False)
+        eps, kc = col.autotune_greenhouse(eps, kc, {"TOA_net": toa})
+        assert (p.qnet_lw_eps0, p.qnet_lw_kc) == (eps, kc)
+        assert 0.30 <= eps <= 0.98 and 0.0 <= kc <= 0.80
+    assert (p.lw_eps0, p.lw_kc) == (e0, k0)

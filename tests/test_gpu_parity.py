@@ -173,6 +173,81 @@ def test_driver_physics_vs_reference(gpu, shape):
         assert e < STEP_TOL, (k, e)
 
 
+@pytest.mark.parametrize("shape", [(19, 36), (37, 72)])
+def test_orographic_precipitation_vs_reference(gpu, shape):
+    """QD_OROG=1 with an uploaded ELEVATION map: compute_orographic_factor (physics.py:116-161) feeding the
+    hybrid precipitation (run_simulation.py:1769-1781), against the reference's own output."""
+    import qingdai_amd as qa
+    from qingdai_amd.device import Device
+    meta, d = load_golden(f"orog_{shape[0]}x{shape[1]}")
+    nlat, nlon = shape
+    _, mask, alb, fric = surface(nlat, nlon)
+    for tag, k in (("", meta["k_orog"]), ("_strong", meta["k_orog_strong"])):
+        p = qa.QdParams(orog_enable=1, orog_k=k)
+        p.has_csmap = 0
+        dev = Device(qa.SphericalGrid(nlat, nlon), p)
+        for name, arr in (("LAND_MASK", mask), ("BASE_ALBEDO", alb), ("FRICTION", fric), ("ELEVATION", d["elevation"]),
+                          ("U", d["u"]), ("V", d["v"]), ("TS", d["T_s"]), ("CLOUD", d["cloud_cover"]), ("PCOND", d["Pc"])):
+            dev.upload_now(name, arr)
+        dev.driver_physics(300.0)
+        e = relerr(dev.get("PRECIP"), d["ref_precip_orog" + tag])
+        print(tag or "default", e)
+        assert e < 1e-11, (tag, e)
+        # without an elevation map the switch has no effect (run_simulation.py:1770: `elevation is not None`)
+        dev.close()
+    p = qa.QdParams(orog_enable=1, orog_k=meta["k_orog_strong"]); p.has_csmap = 0
+    dev = Device(qa.SphericalGrid(nlat, nlon), p)
+    for name, arr in (("LAND_MASK", mask), ("BASE_ALBEDO", alb), ("FRICTION", fric), ("U", d["u"]), ("V", d["v"]),
+                      ("TS", d["T_s"]), ("CLOUD", d["cloud_cover"]), ("PCOND", d["Pc"])):
+        dev.upload_now(name, arr)
+    dev.driver_physics(300.0)
+    assert relerr(dev.get("PRECIP"), d["ref_precip_orog_strong"]) > 1e-3
+    dev.close()
+
+
+@pytest.mark.parametrize("over", [{}, {"gh_lock": 0}, {"gh_lock": 0, "lw_v2": 0, "qnet_lw_eps0": 0.61, "qnet_lw_kc": 0.12}])
+def test_energy_diagnostics_vs_oracle(gpu, over):
+    """qd_energy_diagnostics = compute_energy_diagnostics (energy.py:494-538) on the fluxes of the driver's coupling block
+    (run_simulation.py:2199-2239), incl. the driver's own autotuned (qnet_lw_*) EnergyParams copy."""
+    import qd_oracle as qo
+    from qd_oracle import column as col
+    import qingdai_amd as qa
+    from qingdai_amd.device import Device
+    meta, d = load_golden("physics_37x72")
+    nlat, nlon = 37, 72
+    _, mask, alb, fric = surface(nlat, nlon)
+    p = qa.QdParams(**over); p.has_csmap = 0
+    dev = Device(qa.SphericalGrid(nlat, nlon), p)
+    r = np.random.default_rng(11)
+    h = 8000.0 + 300.0 * r.normal(0, 1, (nlat, nlon))
+    isr = np.maximum(0.0, 600.0 * np.cos(np.deg2rad(np.linspace(-90, 90, nlat)))[:, None] + r.normal(0, 20, (nlat, nlon)))
+    LH = np.abs(r.normal(40, 20, (nlat, nlon)))
+    for name, arr in (("LAND_MASK", mask), ("U", d["u"]), ("V", d["v"]), ("TS", d["T_s"]), ("CLOUD", d["cloud_cover"]),
+                      ("HICE", d["h_ice"]), ("H", h), ("ISR", isr), ("ALBEDO", d["ref_albedo"]), ("LH", LH)):
+        dev.upload_now(name, arr)
+    got = dev.energy_diagnostics()
+    okw = {k: v for k, v in over.items() if not k.startswith("qnet_")}
+    P = qo.defaults(**okw)
+    if "qnet_lw_eps0" in over:
+        P.lw_eps0, P.lw_kc = over["qnet_lw_eps0"], over["qnet_lw_kc"]
+    g = qo.Grid(nlat, nlon)
+    T_a = 288.0 + (9.81 / 1004.0) * h
+    SW_atm, SW_sfc, R = col.shortwave(isr, d["ref_albedo"], d["cloud_cover"], P)
+    ice_frac = 1.0 - np.exp(-np.maximum(d["h_ice"], 0.0) / 0.5)
+    if int(P.lw_v2):
+        eps_sfc = col.surface_emissivity_map(mask, ice_frac, P)
+        LW_atm, LW_sfc, OLR, DLR, eps = col.longwave_v2(d["T_s"], T_a, d["cloud_cover"], eps_sfc, P)
+    else:
+        LW_atm, LW_sfc, OLR, DLR, eps = col.longwave_v1(d["T_s"], T_a, d["cloud_cover"], P)
+    SH = col.sensible_heat(d["T_s"], T_a, d["u"], d["v"], P)
+    want = col.energy_diagnostics(g.lat_mesh, isr, R, OLR, SW_sfc, LW_sfc, SH, LH)
+    errs = {k: abs(got[k] - want[k]) / (abs(want[k]) + 1.0) for k in want}
+    print(over, errs)
+    for k, e in errs.items():
+        assert e < 1e-12, (k, e, got[k], want[k])
+    dev.close()
+
+
 @pytest.mark.parametrize("use_ocean", [1, 0])
 def test_driver_loop_vs_oracle(gpu, use_ocean):
     """The whole driver iteration (run_simulation.py:1760-2340: precipitation, clouds, P019 snow, albedo,

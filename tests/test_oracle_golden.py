@@ -99,6 +99,21 @@ def test_physics_and_forcing_match_reference(shape):
         assert np.array_equal(f.equilibrium_temp(t, albedo), d[f"ref_Teq_{j}"])
 
 
+@pytest.mark.parametrize("shape", [(19, 36), (37, 72)])
+def test_orographic_factor_matches_reference(shape):
+    """compute_orographic_factor (physics.py:116-161) and the hybrid precipitation it multiplies
+    (run_simulation.py:1769-1781), default and strong QD_OROG_K."""
+    meta, d = load_golden(f"orog_{shape[0]}x{shape[1]}")
+    g, _, _, _ = surface(*shape)
+    ns = SimpleNamespace(u=d["u"], v=d["v"], T_s=d["T_s"], cloud_cover=d["cloud_cover"], P_cond_flux_last=d["Pc"])
+    for tag, k in (("", meta["k_orog"]), ("_strong", meta["k_orog_strong"])):
+        fac = oph.compute_orographic_factor(g, d["elevation"], d["u"], d["v"], k_orog=k)
+        assert np.array_equal(fac, d["ref_orog_factor" + tag])
+        pr = oph.diagnose_precipitation_hybrid(ns, g, qo.defaults(orog_enable=1, orog_k=k), orog_factor=fac)
+        assert np.array_equal(pr, d["ref_precip_orog" + tag])
+    assert d["ref_orog_factor_strong"].max() > 1.5          # the enhancement really is exercised
+
+
 def test_known_answers_appendix_a3():
     """19x36, defaults, albedo passed, 12 steps of the benchmark loop."""
     meta, d = load_golden("ts_19x36_default_alb")
