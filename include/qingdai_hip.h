@@ -113,6 +113,7 @@ typedef struct qd_params {
 
 /* ---- lifetime ------------------------------------------------------------------ */
 int qd_abi_version(void);
+int qd_device_count(void);   /* visible HIP devices (0 when none): what jax_compat.is_enabled() asks of its backend */
 /* SpectralModel.__init__ / WindDrivenSlabOcean.__init__ (dynamics.py:22-88, ocean.py:28-97):
  * allocates every field on `desc->device`, fills the reference's initial state
  * (u=v=0, h=H+300 sin^2, T_s=288, q=RH0*q_sat(T_s), ocean at rest, SST=288). */

@@ -27,7 +27,7 @@ R_SUM, R_COSMEAN, R_MAX, R_MIN, R_MAXABS = 0, 1, 2, 3, 4
 
 # every symbol include/qingdai_hip.h declares
 SYMBOLS = [
-    "qd_abi_version", "qd_create", "qd_destroy", "qd_last_error", "qd_upload", "qd_download", "qd_set_params",
+    "qd_abi_version", "qd_device_count", "qd_create", "qd_destroy", "qd_last_error", "qd_upload", "qd_download", "qd_set_params",
     "qd_get_step_counter", "qd_set_step_counter", "qd_forcing", "qd_simple_albedo", "qd_atmos_step",
     "qd_ocean_step", "qd_driver_physics", "qd_hydrology_commit", "qd_step_n", "qd_last_ocean_nsub", "qd_sync",
     "qd_op_laplacian", "qd_op_hyperdiffuse", "qd_op_advect", "qd_op_shapiro", "qd_op_zonal_filter", "qd_op_divergence",
@@ -60,6 +60,7 @@ def load():
     vp, dp, i32, i64, dbl, sz = (ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int64,
                                  ctypes.c_double, ctypes.c_size_t)
     lib.qd_abi_version.restype = i32
+    lib.qd_device_count.restype = i32
     lib.qd_create.argtypes = [ctypes.POINTER(qd_grid_desc), ctypes.POINTER(qd_params), dbl, ctypes.POINTER(vp)]
     lib.qd_destroy.argtypes = [vp]
     lib.qd_last_error.argtypes = [vp]

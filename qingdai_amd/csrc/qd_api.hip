@@ -213,6 +213,7 @@ static double host_qsat(double T, double p0) {
 
 // ------------------------------------------------------------------ lifetime
 extern "C" int qd_abi_version(void) { return QD_ABI_VERSION; }
+extern "C" int qd_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
 
 extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double q_init_rh, qd_handle* out) {
     if (!d || !params || !out) return qd_fail(nullptr, "qd_create: null argument");

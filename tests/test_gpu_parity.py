@@ -49,6 +49,40 @@ def test_operators_vs_reference(gpu, shape):
     assert relerr(storm, d["ref_advect_storm"]) < 1e-10     # pole rows fold 1e4-1e5 cells
 
 
+@pytest.mark.parametrize("shape", [(19, 36), (37, 72)])
+def test_hip_compat_seam_matches_reference(gpu, shape):
+    """qingdai_amd.hip_compat: the three operators of pygcm/jax_compat.py:111-216 with the reference's own argument
+    lists (floored cos maps, dlat/dlon, a), against the reference outputs in the golden file."""
+    import qingdai_amd as qa
+    from qingdai_amd import hip_compat as hc
+    meta, d = load_golden(f"ops_{shape[0]}x{shape[1]}")
+    g = qa.SphericalGrid(*shape)
+    a = 6.371e6 if "a" not in meta else meta["a"]
+    a = qa.QdParams().a
+    cos = np.cos(np.deg2rad(g.lat_mesh))
+    c02, c05, c6 = np.maximum(cos, 0.2), np.maximum(cos, 0.5), np.maximum(cos, 1e-6)
+    assert hc.is_enabled() and hc.backend() == "hip"
+    Fh, T, u, v, k4, dt = d["F"], d["T"], d["u"], d["v"], d["k4"], meta["dt"]
+    got = {
+        "lap_atm": hc.laplacian_sphere(Fh, g.dlat_rad, g.dlon_rad, c02, a),
+        "lap_ocn": hc.laplacian_sphere(Fh, g.dlat_rad, g.dlon_rad, c05, a),
+        "hyper_atm": hc.hyperdiffuse(Fh, k4, dt, 1, g.dlat_rad, g.dlon_rad, c02, a),
+        "hyper_atm_nsub2": hc.hyperdiffuse(Fh, 0.5 * k4, dt, 2, g.dlat_rad, g.dlon_rad, c02, a),
+        "hyper_scalar": hc.hyperdiffuse(Fh, 1.0e14, dt, 1, g.dlat_rad, g.dlon_rad, c02, a),
+        "advect_atm": hc.advect_semilag(T, u, v, dt, a, g.dlat_rad, g.dlon_rad, c6),
+        "advect_ocn": hc.advect_semilag(T, 0.02 * u, 0.02 * v, dt, a, g.dlat_rad, g.dlon_rad, c05),
+    }
+    for k, val in got.items():
+        assert isinstance(val, np.ndarray) and val.flags.writeable
+        assert relerr(val, d["ref_" + k]) < OP_TOL, k
+    assert np.array_equal(hc.hyperdiffuse(Fh, 0.0, dt, 1, g.dlat_rad, g.dlon_rad, c02, a), np.nan_to_num(Fh))   # k4 <= 0 early-out
+    with pytest.raises(ValueError):
+        hc.laplacian_sphere(Fh, g.dlat_rad, g.dlon_rad, np.maximum(cos, 0.3), a)      # unknown floor: refuse, never guess
+    with pytest.raises(ValueError):
+        hc.laplacian_sphere(Fh, 2 * g.dlat_rad, g.dlon_rad, c02, a)
+    assert isinstance(hc.to_numpy(np.arange(3)), np.ndarray)
+
+
 def test_median_exact(gpu):
     import qingdai_amd as qa
     grid = qa.SphericalGrid(37, 72)
