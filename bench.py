@@ -192,6 +192,21 @@ def main():
         out["roofline_ocean_substep"] = {"bound": "hbm", "kernel": also, "achieved": a2, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                          "frac": a2 / HBM_PEAK_GBS, "traffic": None, "bytes_per_cell": BYTES_PER_CELL[also],
                                          "cells": cells, "avg_kernel_ms": also_ms, "launches": also_n}
+    # HBM-side traffic per launch: PMC counters cannot be collected from inside this process; the committed summary of
+    # the separate rocprofv3 --pmc passes of this same command (profiles/, corrected as MI355X_MICROARCH.md prescribes)
+    # is reported when it covers this kernel and grid, else null
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_final_pmc_traffic.json")) as fh:
+            pmc = json.load(fh)["kernels"]
+        if args.gpus == 1 and (args.nlat, args.nlon) == (721, 1440):
+            for key, val in pmc.items():
+                if args.profile_kernel in key:
+                    out["roofline"]["traffic"] = val["traffic_bytes"]
+                    out["roofline"]["traffic_source"] = "profiles/r01_final_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+                if also and also in key and "roofline_ocean_substep" in out:
+                    out["roofline_ocean_substep"]["traffic"] = val["traffic_bytes"]
+    except Exception:
+        pass
     if not args.no_cpu_baseline and rank == 0 and args.gpus == 1:
         out["cpu_baseline"] = cpu_baseline(args.nlat, args.nlon, with_ocean, args.cpu_budget)
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
