@@ -25,6 +25,10 @@ struct QdOcnArgs {
     int skip[3];
     double a, g, dlat, dlon, sub_dt, rhoH, r_bot;
     double inv_2dlon, inv_2dlat, inv_a, inv_rhoH;
+    // deferred end of the previous sub-step (ocean.py:375,436-443): eta <- clip(nan_to_num(eta - *eta_mean), -cap, cap) applied on
+    // load instead of in a pass of its own; nullptr = eta is already final
+    const double* eta_mean;
+    double eta_cap;
     int fast;
     QdTileShape ts;
 };

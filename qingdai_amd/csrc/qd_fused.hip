@@ -330,6 +330,11 @@ __device__ __forceinline__ void qd_ocn_exact(const QdGeom& G, const QdTabs& T, c
         ae[k] = P.eta[oe]; ru[k] = P.uo[o]; rv[k] = P.vo[o]; rtx[k] = P.taux[o]; rty[k] = P.tauy[o];
         rl[k] = (int)P.land[o];
     }
+    if (P.eta_mean) {                                       // deferred end of the previous sub-step (see QdOcnArgs)
+        const double em = *P.eta_mean;
+#pragma unroll
+        for (int k = 0; k < K; ++k) ae[k] = qd_clip(qd_nn(ae[k] - em), -P.eta_cap, P.eta_cap);
+    }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int rho = wv + QD_NW * k;
@@ -656,6 +661,17 @@ __device__ __forceinline__ bool qd_ocn_fast(const QdGeom& G, const QdTabs& T, co
         if (g0 == 0) wrap_s = P.eta[(unsigned)qd_lrow(G, n - 1) * (unsigned)mlon + (unsigned)j];
         if (g0 + K == n) wrap_n = P.eta[(unsigned)qd_lrow(G, 0) * (unsigned)mlon + (unsigned)j];
     }
+    bool bad = false;
+    if (P.eta_mean) {                                       // deferred eta -= mean; nan_to_num; clip of the previous sub-step
+        const double em = *P.eta_mean, cap = P.eta_cap;
+#pragma unroll
+        for (int k = 0; k < K; ++k) { const double e = ae[k] - em; bad |= qd_nonfinite(e); ae[k] = fmin(fmax(e, -cap), cap); }
+        if (POLE) {
+            const double es_ = wrap_s - em, en_ = wrap_n - em;
+            bad |= qd_nonfinite(es_) | qd_nonfinite(en_);
+            wrap_s = fmin(fmax(es_, -cap), cap); wrap_n = fmin(fmax(en_, -cap), cap);
+        }
+    }
     double sA[K + 2], sP[K], sQ[K], sF[K], sI[K], sX[K];
 #pragma unroll
     for (int k = 0; k < K + 2; ++k) sA[k] = qd_sload(T.lapA[1], POLE ? qd_clampi(g0 - 1 + k, 0, n - 1) : g0 - 1 + k);
@@ -670,7 +686,6 @@ __device__ __forceinline__ bool qd_ocn_fast(const QdGeom& G, const QdTabs& T, co
     double es_edge = Ap[qd_clampi(rho0 - 1, 0, RA - 1) * S + lane];
     double en_edge = Ap[qd_clampi(rho0 + K, 0, RA - 1) * S + lane];
     if (POLE) { if (g0 == 0) es_edge = wrap_s; if (g0 + K == n) en_edge = wrap_n; }
-    bool bad = false;
     // ocean.py:306-336
 #pragma unroll
     for (int k = 0; k < K; ++k) {

@@ -11,6 +11,7 @@
 //                   k_sst_diffuse_heat                            ocean.py:385-406,440
 //                   k_outlier                                     ocean.py:409-444
 // After:            k_polar_fill (2 workgroups), clamp + SST write-back   ocean.py:519-533
+#include <cstdlib>
 #include "qd_internal.h"
 #include "qd_device.h"
 
@@ -401,7 +402,24 @@ k_sst_outlier_fused(QdGeom G, QdTabs T, double dlat, double dlon, double a, QdHe
                     const uint8_t* __restrict__ land, const uint8_t* __restrict__ ice,
                     const double* __restrict__ uo, const double* __restrict__ vo, double* __restrict__ uo_out,
                     double* __restrict__ vo_out, double* __restrict__ eta, double cap, double eta_cap, int mean4,
-                    const double* __restrict__ eta_mean) {
+                    const double* __restrict__ eta_mean, const double* __restrict__ partial, int pcount, double wsum,
+                    double* __restrict__ mean_out) {
+    // deferred-mean mode (mean_out != nullptr): eta is not touched here -- the next momentum kernel applies
+    // eta - mean, nan_to_num and the clip on load -- and workgroup 0 turns the continuity kernel's partial sums into
+    // the mean on the side (same summation order as k_eta_mean)
+    if (mean_out && blockIdx.x == 0 && blockIdx.y == 0) {
+        __shared__ double smm[QD_BLOCK / 64];
+        double acc = 0.0;
+        for (int k = threadIdx.x; k < pcount; k += QD_BLOCK) acc += partial[k];
+        acc = qd_wave_sum_d(acc);
+        if ((threadIdx.x & 63) == 0) smm[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double r = smm[0];
+            for (int k = 1; k < QD_BLOCK / 64; ++k) r += smm[k];
+            *mean_out = r / (wsum + 1e-15);
+        }
+    }
     const QdTile tl = qd_tile();
     const int j = tl.seg * QD_BLOCK + threadIdx.x;
     if (j >= G.nlon) return;
@@ -438,8 +456,19 @@ k_sst_outlier_fused(QdGeom G, QdTabs T, double dlat, double dlon, double a, QdHe
     }
     uo_out[o] = u; vo_out[o] = v;
     // eta -= area-weighted ocean mean (ocean.py:375), then nan_to_num + clip (ocean.py:436-443)
+    if (mean_out) return;
     const double e = eta_mean ? eta[o] - *eta_mean : eta[o];
     eta[o] = qd_clip(qd_nn(e), -eta_cap, eta_cap);
+}
+
+// the deferred eta update of the LAST sub-step of a call (nobody loads eta through the momentum kernel afterwards)
+__global__ void __launch_bounds__(QD_BLOCK)
+k_eta_finalize(QdGeom G, double* __restrict__ eta, const double* __restrict__ eta_mean, double eta_cap) {
+    const QdTile tl = qd_tile();
+    const int j = tl.seg * QD_BLOCK + threadIdx.x;
+    if (j >= G.nlon) return;
+    const size_t o = (size_t)qd_lrow(G, G.row0 + tl.row) * G.nlon + j;
+    eta[o] = qd_clip(qd_nn(eta[o] - *eta_mean), -eta_cap, eta_cap);
 }
 
 // ------------------------------------------------------------------ polar ring fills: ocean.py:197-262
@@ -584,6 +613,10 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
     const double ov[3] = {p.ocean_k4_u, p.ocean_k4_v, p.ocean_k4_eta};
     const int Ro = qd_adv_reach(c, sub_dt, 4.0);           // currents are capped at QD_OCEAN_MAX_U (3 m/s)
 
+    // whole-globe handles on the fused path defer "eta -= mean; nan_to_num; clip" of a sub-step to the load of the next
+    // momentum kernel (and to k_eta_finalize after the last one): no k_eta_mean launch, no eta pass in the SST kernel
+    static const bool defer_env = !(std::getenv("QD_DEFER_ETA") && std::getenv("QD_DEFER_ETA")[0] == '0');     // tuning aid
+    const bool defer_eta = defer_env && !band && do_diff && c->use_fused && p.ocean_k4_nsub == 1 && !do_shap && c->wsum_ocean > 0.0;
     for (int s = 0; s < n_sub; ++s) {
         if (do_diff && c->use_fused && p.ocean_k4_nsub == 1) {
             const int m = qd_plan(c, {QD_IN(F[QD_F_ETA], 5), QD_IN(F[QD_F_UO], 4), QD_IN(F[QD_F_VO], 4), QD_IN(taux, 4),
@@ -600,6 +633,8 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
             }
             O.a = p.a; O.g = p.g_ocean; O.dlat = c->dlat; O.dlon = c->dlon; O.sub_dt = sub_dt; O.rhoH = p.rho_w * H; O.r_bot = p.r_bot;
             O.inv_2dlon = 1.0 / (2.0 * c->dlon); O.inv_2dlat = 1.0 / (2.0 * c->dlat); O.inv_a = 1.0 / p.a; O.inv_rhoH = 1.0 / (p.rho_w * H);
+            O.eta_mean = (defer_eta && s > 0) ? c->dscal + QD_S_ETA_MEAN : nullptr;
+            O.eta_cap = p.eta_cap;
             if (qd_launch_ocn_hyper(c, O, m)) return -1;
             qd_mark(c, {O.uo_out, O.vo_out, O.eta_out}, m);
             qd_swap(c, QD_F_UO, 0); qd_swap(c, QD_F_VO, 1); qd_swap(c, QD_F_ETA, 2);
@@ -647,8 +682,9 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
                 hipLaunchKernelGGL(k_cont_sstadv, g2, blk, 0, c->stream, Gown, c->tabs, p.a, c->dlat, c->dlon, -sub_dt * H, sub_dt,
                                    p.ocean_adv_alpha, F[QD_F_UO], F[QD_F_VO], c->land, F[QD_F_ETA], F[QD_F_SST], T1, own0, own1,
                                    c->red_partial, (unsigned long long*)nullptr, 0.0, (double*)nullptr);
-                hipLaunchKernelGGL(k_eta_mean, dim3(1), blk, 0, c->stream, c->red_partial, (int)(g2.x * g2.y), c->wsum_ocean,
-                                   c->dscal + QD_S_ETA_MEAN);
+                if (!defer_eta)
+                    hipLaunchKernelGGL(k_eta_mean, dim3(1), blk, 0, c->stream, c->red_partial, (int)(g2.x * g2.y), c->wsum_ocean,
+                                       c->dscal + QD_S_ETA_MEAN);
             } else {
                 // halo segments first (their partials are zero-weighted), the owned rows' partials are summed below
                 QdSegs S = qd_segments(c, m);
@@ -675,7 +711,9 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
                                                  c->dlon, p.a, HP, c->scratch[0], T2, F[QD_F_QNET], c->land, c->icemask,
                                                  F[QD_F_UO], F[QD_F_VO], u2, v2, F[QD_F_ETA], p.ocean_max_u, p.eta_cap,
                                                  p.ocean_outlier == 0 ? 1 : 0,
-                                                 has_ocean ? c->dscal + QD_S_ETA_MEAN : (const double*)nullptr));
+                                                 has_ocean ? c->dscal + QD_S_ETA_MEAN : (const double*)nullptr,
+                                                 c->red_partial, (int)(qd_grid2d(Gown).x * qd_grid2d(Gown).y), c->wsum_ocean,
+                                                 defer_eta ? c->dscal + QD_S_ETA_MEAN : (double*)nullptr));
             qd_mark(c, {T2, u2, v2, F[QD_F_ETA]}, m2);
             qd_swap(c, QD_F_SST, 1); qd_swap(c, QD_F_UO, 2); qd_swap(c, QD_F_VO, 3);
         } else {
@@ -735,7 +773,8 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
                 QD_ROWS(c, m2, G, hipLaunchKernelGGL(k_sst_outlier_fused, qd_grid2d(G), blk, 0, c->stream, G, c->tabs, c->dlat,
                                                      c->dlon, p.a, HP, c->scratch[0], T2, F[QD_F_QNET], c->land, c->icemask,
                                                      F[QD_F_UO], F[QD_F_VO], u2, v2, F[QD_F_ETA], p.ocean_max_u, p.eta_cap,
-                                                     p.ocean_outlier == 0 ? 1 : 0, (const double*)nullptr));
+                                                     p.ocean_outlier == 0 ? 1 : 0, (const double*)nullptr, (const double*)nullptr, 0,
+                                                     0.0, (double*)nullptr));
                 qd_mark(c, {T2, u2, v2, F[QD_F_ETA]}, m2);
                 qd_swap(c, QD_F_SST, 1); qd_swap(c, QD_F_UO, 2); qd_swap(c, QD_F_VO, 3);
             } else {
@@ -760,6 +799,8 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
             qd_swap(c, QD_F_UO, 2); qd_swap(c, QD_F_VO, 3);
         }
     }
+    if (defer_eta && n_sub > 0)
+        hipLaunchKernelGGL(k_eta_finalize, qd_grid2d(Gown), blk, 0, c->stream, Gown, F[QD_F_ETA], c->dscal + QD_S_ETA_MEAN, p.eta_cap);
     {
         QdScope sc(c, "ocean_finish");
         if (p.ocean_polar_fix) {
