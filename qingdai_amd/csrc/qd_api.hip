@@ -267,6 +267,7 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
         hipMemsetAsync(c->sel_ccount, 0, 2 * sizeof(unsigned int), c->stream);
     }
     if ((e = hipHostMalloc((void**)&c->hpin, 64 * sizeof(double))) != hipSuccess) return bail("hipHostMalloc", e);
+    if ((e = hipHostMalloc((void**)&c->hpin_rows, (size_t)2 * c->geo.lrows() * sizeof(double))) != hipSuccess) return bail("hipHostMalloc", e);
     // reference initial state
     const double q0 = std::min(std::max(q_init_rh, 0.0), 1.0) * host_qsat(288.0, params->p0);
     hipLaunchKernelGGL(k_init_state, dim3((d->n_lon + QD_BLOCK - 1) / QD_BLOCK, c->geo.lrows()), dim3(QD_BLOCK), 0,
@@ -295,6 +296,7 @@ extern "C" int qd_destroy(qd_handle c) {
     if (c->zonal_tw) hipFree(c->zonal_tw);
     if (c->sel_cand) hipFree(c->sel_cand); if (c->sel_ccount) hipFree(c->sel_ccount);
     if (c->hpin) hipHostFree(c->hpin);
+    if (c->hpin_rows) hipHostFree(c->hpin_rows);
     if (c->stage) hipHostFree(c->stage);
     qd_resolve_timers(c);
     for (hipEvent_t e : c->ev_free) hipEventDestroy(e);

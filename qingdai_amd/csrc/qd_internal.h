@@ -152,6 +152,7 @@ struct qd_ctx {
     double* sel_cand = nullptr;      // [2][cells] candidates of the two middle ranks after two radix passes (whole-globe handles)
     unsigned int* sel_ccount = nullptr; // [2] candidate counts
     double* hpin = nullptr;        // pinned host scalars
+    double* hpin_rows = nullptr;   // pinned, 2 x slab rows: per-row partial maxima read back in one copy
     double wsum_ocean = 0, wsum_all = 0;
     int64_t atm_counter = 0, ocn_counter = 0;
     QdTileShape tile{0, 0, 0, 0};   // fused-kernel tile (qd_pick_tile)
@@ -238,8 +239,11 @@ int  qd_shapiro_fields(qd_ctx* c, double** fields, int n, int npass, int m_out);
 void qd_launch_advect(qd_ctx* c, const double* u, const double* v, const double* coslat, double dt,
                       const double* f0, double* o0, const double* f1, double* o1, double alpha, int clipq, int m);
 void qd_launch_divvort(qd_ctx* c, const double* u, const double* v, double* out, int vort, int m);
-int  qd_gaussian(qd_ctx* c, const double* in, double* out, double* tmp, double sigma, int mode_wrap, int m_out, int clip01 = 0);
-int  qd_gaussian_swap(qd_ctx* c, double*& field, double*& tmp, double sigma, int mode_wrap, int m_out, int clip01 = 0);
+int  qd_gaussian(qd_ctx* c, const double* in, double* out, double* tmp, double sigma, int mode_wrap, int m_out, int clip01 = 0,
+                 const double* scale_p = nullptr, double scale_k = 1.0);
+int  qd_gaussian_swap(qd_ctx* c, double*& field, double*& tmp, double sigma, int mode_wrap, int m_out, int clip01 = 0,
+                      const double* scale_p = nullptr, double scale_k = 1.0);
+bool qd_gauss_can_fuse(const qd_ctx* c, double sigma);
 int  qd_gauss_radius(double sigma);
 int  qd_energy_diag_impl(qd_ctx* c, double* host_out);    // qd_ocean.hip
 int  qd_zonal_filter_fields(qd_ctx* c, double** fields, int nf, double cutoff, double damp, int m);

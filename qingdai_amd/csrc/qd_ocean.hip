@@ -523,11 +523,13 @@ k_polar_fill(QdGeom G, QdTabs T, const uint8_t* __restrict__ land, double* __res
 __global__ void __launch_bounds__(QD_BLOCK)
 k_sst_clamp_inject(QdGeom G, double* __restrict__ sst, double tmin, double tmax, int inject,
                    const uint8_t* __restrict__ land, const uint8_t* __restrict__ ice, int has_ice,
-                   double* __restrict__ Ts_atm) {
+                   double* __restrict__ Ts_atm, double* __restrict__ eta, const double* __restrict__ eta_mean, double eta_cap) {
     const QdTile tl = qd_tile();
     const int j = tl.seg * QD_BLOCK + threadIdx.x;
     if (j >= G.nlon) return;
     const size_t o = (size_t)qd_lrow(G, G.row0 + tl.row) * G.nlon + j;
+    // the deferred eta update of the LAST sub-step (nobody loads eta through the momentum kernel afterwards)
+    if (eta) eta[o] = qd_clip(qd_nn(eta[o] - *eta_mean), -eta_cap, eta_cap);
     const double t = qd_clip(sst[o], tmin, tmax);
     sst[o] = t;
     // gcm.T_s = where(ocean & ~ice, ocean.Ts, gcm.T_s)    run_simulation.py:2252-2253
@@ -575,6 +577,17 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
         const int m = qd_plan(c, {QD_IN(F[QD_F_U], 0), QD_IN(F[QD_F_V], 0), QD_IN(F[QD_F_UO], 0), QD_IN(F[QD_F_VO], 0)});
         if (m < 0) return -1;
         QdSegs S = qd_segments(c, m);
+        double maxVa = 0.0, maxUo = 0.0;
+        if (!band) {
+            // whole globe: one launch, the 2 x n_lat row maxima come back in the same copy the host has to wait for anyway
+            const QdGeom& G = S.g[0];
+            hipLaunchKernelGGL(k_stress_max, dim3(1, G.nrows), blk, 0, c->stream, G, F[QD_F_U], F[QD_F_V], F[QD_F_UO],
+                               F[QD_F_VO], p.vcap, p.rho_a_ocean * p.CD, p.tau_scale, taux, tauy, c->red_partial);
+            qd_mark(c, {taux, tauy}, m);
+            QD_HIP(c, hipMemcpyAsync(c->hpin_rows, c->red_partial, (size_t)2 * G.nrows * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            QD_HIP(c, hipStreamSynchronize(c->stream));
+            for (int k = 0; k < G.nrows; ++k) { maxVa = std::max(maxVa, c->hpin_rows[k]); maxUo = std::max(maxUo, c->hpin_rows[G.nrows + k]); }
+        } else {
         QD_HIP(c, hipMemsetAsync(c->dscal + QD_S_TMP0, 0, 6 * sizeof(double), c->stream));
         for (int k = 0; k < S.n; ++k) {
             const QdGeom& G = S.g[k];
@@ -590,8 +603,8 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
         if (qd_allreduce_f64(c, c->dscal + QD_S_TMP0, 6, 1)) return -1;
         QD_HIP(c, hipMemcpyAsync(c->hpin, c->dscal + QD_S_TMP0, 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         QD_HIP(c, hipStreamSynchronize(c->stream));
-        double maxVa = 0.0, maxUo = 0.0;
         for (int k = 0; k < 3; ++k) { maxVa = std::max(maxVa, c->hpin[2 * k]); maxUo = std::max(maxUo, c->hpin[2 * k + 1]); }
+        }
         // ocean.py:293-303
         const double dx_lat = p.a * c->dlat;
         const double min_cos = 0.5;                       // min of max(cos, 0.5) on a pole-to-pole grid
@@ -799,8 +812,6 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
             qd_swap(c, QD_F_UO, 2); qd_swap(c, QD_F_VO, 3);
         }
     }
-    if (defer_eta && n_sub > 0)
-        hipLaunchKernelGGL(k_eta_finalize, qd_grid2d(Gown), blk, 0, c->stream, Gown, F[QD_F_ETA], c->dscal + QD_S_ETA_MEAN, p.eta_cap);
     {
         QdScope sc(c, "ocean_finish");
         if (p.ocean_polar_fix) {
@@ -813,7 +824,8 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
         const int m = qd_plan(c, {QD_IN(F[QD_F_SST], 0), QD_IN(F[QD_F_TS], 0), QD_IN8(c->icemask, 0)});
         if (m < 0) return -1;
         QD_ROWS(c, m, G, hipLaunchKernelGGL(k_sst_clamp_inject, qd_grid2d(G), blk, 0, c->stream, G, F[QD_F_SST], p.ts_min, p.ts_max,
-                                            inject_sst, c->land, c->icemask, use_ice_mask ? 1 : 0, F[QD_F_TS]));
+                                            inject_sst, c->land, c->icemask, use_ice_mask ? 1 : 0, F[QD_F_TS],
+                                            (defer_eta && n_sub > 0) ? F[QD_F_ETA] : (double*)nullptr, c->dscal + QD_S_ETA_MEAN, p.eta_cap));
         qd_mark(c, {F[QD_F_SST]}, m);
         if (inject_sst) qd_mark(c, {F[QD_F_TS]}, m);
     }

@@ -404,7 +404,16 @@ int qd_driver_physics_impl(qd_ctx* c, double dt) {
             hipLaunchKernelGGL(k_precip_scalars, dim3(1), blk, 0, c->stream, c->red_partial, Gown.nrows, c->wsum_all, p.pq_min,
                                p.p_blend, p.p_hybrid_fallback, c->dscal + QD_S_RENORM);
         }
-        // P = gaussian(P_raw * s); P_dyn = gaussian(k_precip * pos)
+        // P = gaussian(P_raw * s); P_dyn = gaussian(k_precip * pos): the two scalings ride on the blur's loads
+        if (qd_gauss_can_fuse(c, 1.0)) {
+            const int mg = qd_plan(c, {QD_IN(praw, R1), QD_IN(pos, R1)});
+            if (mg < 0) return -1;
+            if (qd_gaussian_swap(c, praw, tmp, 1.0, 0, mg, 0, c->dscal + QD_S_RENORM)) return -1;
+            if (qd_gaussian(c, pos, pdyn, nullptr, 1.0, 0, mg, 0, nullptr, p.k_precip)) return -1;
+            QD_ROWS(c, mg, G, hipLaunchKernelGGL(k_precip_blend, qd_grid2d(G), blk, 0, c->stream, G, praw, pdyn,
+                                                 c->dscal + QD_S_RENORM, F[QD_F_PRECIP]));
+            qd_mark(c, {F[QD_F_PRECIP]}, mg);
+        } else {
         QD_ROWS(c, m, G, hipLaunchKernelGGL(k_scale_field, qd_grid2d(G), blk, 0, c->stream, G, praw, c->dscal + QD_S_RENORM, 0.0, praw));
         QD_ROWS(c, m, G, hipLaunchKernelGGL(k_scale_field, qd_grid2d(G), blk, 0, c->stream, G, pos, (const double*)nullptr,
                                             p.k_precip, pdyn));
@@ -416,6 +425,7 @@ int qd_driver_physics_impl(qd_ctx* c, double dt) {
         QD_ROWS(c, mg, G, hipLaunchKernelGGL(k_precip_blend, qd_grid2d(G), blk, 0, c->stream, G, praw, pdyn,
                                              c->dscal + QD_S_RENORM, F[QD_F_PRECIP]));
         qd_mark(c, {F[QD_F_PRECIP]}, mg);
+        }
     }
     {
         QdScope sc(c, "phys_cloud");

@@ -247,7 +247,8 @@ __global__ void __launch_bounds__(QD_BLOCK) k_clip01_field(QdGeom G, double* __r
 // goes to LDS and the axis-1 pass reads it from there -- same arithmetic in the same order as the two-kernel form,
 // without the round trip of the intermediate field through memory.  out must not alias in.
 __global__ void __launch_bounds__(QD_BLOCK)
-k_gauss_fused(QdGeom G, const double* __restrict__ in, double* __restrict__ out, QdGaussW W, int mode_wrap, int clip01) {
+k_gauss_fused(QdGeom G, const double* __restrict__ in, double* __restrict__ out, QdGaussW W, int mode_wrap, int clip01,
+              const double* __restrict__ scale_p, double scale_k) {
     __shared__ double sm[QD_BLOCK + 2 * QD_GAUSS_MAXR];
     const QdTile tl = qd_tile();
     const int i = G.row0 + tl.row;
@@ -257,10 +258,12 @@ k_gauss_fused(QdGeom G, const double* __restrict__ in, double* __restrict__ out,
         const int jj = jbase - r + s;
         if (jj >= G.nlon + r) break;
         const int j = qd_ext(jj, G.nlon, mode_wrap);
-        double tmp = in[(size_t)qd_lrow(G, i) * G.nlon + j] * W.w[0];
+        // optional pre-scaling of the input (the caller's `field * s` pass folded in; one rounding per element, as there)
+        const double sc = scale_p ? *scale_p : scale_k;
+        double tmp = (in[(size_t)qd_lrow(G, i) * G.nlon + j] * sc) * W.w[0];
         for (int k = r; k >= 1; --k) {
-            const double lo = in[(size_t)qd_lrow(G, qd_ext(i - k, G.nlat, mode_wrap)) * G.nlon + j];
-            const double hi = in[(size_t)qd_lrow(G, qd_ext(i + k, G.nlat, mode_wrap)) * G.nlon + j];
+            const double lo = in[(size_t)qd_lrow(G, qd_ext(i - k, G.nlat, mode_wrap)) * G.nlon + j] * sc;
+            const double hi = in[(size_t)qd_lrow(G, qd_ext(i + k, G.nlat, mode_wrap)) * G.nlon + j] * sc;
             tmp += (lo + hi) * W.w[k];
         }
         sm[s] = tmp;
@@ -276,7 +279,11 @@ k_gauss_fused(QdGeom G, const double* __restrict__ in, double* __restrict__ out,
 }
 
 // gaussian_filter(in, sigma, mode): axis 0 then axis 1.  out may alias in; tmp is a distinct slab.
-int qd_gaussian(qd_ctx* c, const double* in, double* out, double* tmp, double sigma, int mode_wrap, int m_out, int clip01) {
+int qd_gaussian(qd_ctx* c, const double* in, double* out, double* tmp, double sigma, int mode_wrap, int m_out, int clip01,
+                const double* scale_p, double scale_k) {
+    const bool scaled = scale_p != nullptr || scale_k != 1.0;
+    if (scaled && !(c->use_fused && out != in && sigma > 1e-15 && c->geo.nlon > 2 * qd_gauss_radius(sigma)))
+        return qd_fail(c, "qd_gaussian: input scaling needs the fused blur");
     if (!(sigma > 1e-15)) {
         if (out != in) hipMemcpyAsync(out, in, c->geo.cells() * sizeof(double), hipMemcpyDeviceToDevice, c->stream);
         qd_mark(c, {out}, m_out);
@@ -306,7 +313,7 @@ int qd_gaussian(qd_ctx* c, const double* in, double* out, double* tmp, double si
     for (int k = 0; k <= r; ++k) W.w[k] = phi[r + k] / tot;
     // axis 0 reaches r rows; axis 1 is row-local.  Both passes run on the output margin.
     if (c->use_fused && out != in && c->geo.nlon > 2 * r) {
-        QD_ROWS(c, m_out, G, hipLaunchKernelGGL(k_gauss_fused, qd_grid2d(G), dim3(QD_BLOCK), 0, c->stream, G, in, out, W, mode_wrap, clip01));
+        QD_ROWS(c, m_out, G, hipLaunchKernelGGL(k_gauss_fused, qd_grid2d(G), dim3(QD_BLOCK), 0, c->stream, G, in, out, W, mode_wrap, clip01, scale_p, scale_k));
         qd_mark(c, {out}, m_out);
         return 0;
     }
@@ -319,17 +326,21 @@ int qd_gaussian(qd_ctx* c, const double* in, double* out, double* tmp, double si
     return 0;
 }
 
+bool qd_gauss_can_fuse(const qd_ctx* c, double sigma) { return c->use_fused && sigma > 1e-15 && c->geo.nlon > 2 * qd_gauss_radius(sigma); }
+
 // in-place form for fields held in context slots: blur `field` into `tmp`, then exchange the two slots
-int qd_gaussian_swap(qd_ctx* c, double*& field, double*& tmp, double sigma, int mode_wrap, int m_out, int clip01) {
+int qd_gaussian_swap(qd_ctx* c, double*& field, double*& tmp, double sigma, int mode_wrap, int m_out, int clip01,
+                     const double* scale_p, double scale_k) {
     if (!(sigma > 1e-15)) {
         if (clip01) QD_ROWS(c, m_out, G, hipLaunchKernelGGL(k_clip01_field, qd_grid2d(G), dim3(QD_BLOCK), 0, c->stream, G, field));
         return 0;
     }
     if (c->use_fused && c->geo.nlon > 2 * qd_gauss_radius(sigma)) {
-        if (qd_gaussian(c, field, tmp, nullptr, sigma, mode_wrap, m_out, clip01)) return -1;
+        if (qd_gaussian(c, field, tmp, nullptr, sigma, mode_wrap, m_out, clip01, scale_p, scale_k)) return -1;
         std::swap(field, tmp);
         return 0;
     }
+    if (scale_p != nullptr || scale_k != 1.0) return qd_fail(c, "qd_gaussian_swap: input scaling needs the fused blur");
     return qd_gaussian(c, field, field, tmp, sigma, mode_wrap, m_out, clip01);
 }
 
