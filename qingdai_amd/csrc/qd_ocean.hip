@@ -461,15 +461,6 @@ k_sst_outlier_fused(QdGeom G, QdTabs T, double dlat, double dlon, double a, QdHe
     eta[o] = qd_clip(qd_nn(e), -eta_cap, eta_cap);
 }
 
-// the deferred eta update of the LAST sub-step of a call (nobody loads eta through the momentum kernel afterwards)
-__global__ void __launch_bounds__(QD_BLOCK)
-k_eta_finalize(QdGeom G, double* __restrict__ eta, const double* __restrict__ eta_mean, double eta_cap) {
-    const QdTile tl = qd_tile();
-    const int j = tl.seg * QD_BLOCK + threadIdx.x;
-    if (j >= G.nlon) return;
-    const size_t o = (size_t)qd_lrow(G, G.row0 + tl.row) * G.nlon + j;
-    eta[o] = qd_clip(qd_nn(eta[o] - *eta_mean), -eta_cap, eta_cap);
-}
 
 // ------------------------------------------------------------------ polar ring fills: ocean.py:197-262
 // one workgroup per pole row; fixed-order tree sums (deterministic)
@@ -628,8 +619,7 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
 
     // whole-globe handles on the fused path defer "eta -= mean; nan_to_num; clip" of a sub-step to the load of the next
     // momentum kernel (and to k_eta_finalize after the last one): no k_eta_mean launch, no eta pass in the SST kernel
-    static const bool defer_env = !(std::getenv("QD_DEFER_ETA") && std::getenv("QD_DEFER_ETA")[0] == '0');     // tuning aid
-    const bool defer_eta = defer_env && !band && do_diff && c->use_fused && p.ocean_k4_nsub == 1 && !do_shap && c->wsum_ocean > 0.0;
+    const bool defer_eta = !band && do_diff && c->use_fused && p.ocean_k4_nsub == 1 && !do_shap && c->wsum_ocean > 0.0;
     for (int s = 0; s < n_sub; ++s) {
         if (do_diff && c->use_fused && p.ocean_k4_nsub == 1) {
             const int m = qd_plan(c, {QD_IN(F[QD_F_ETA], 5), QD_IN(F[QD_F_UO], 4), QD_IN(F[QD_F_VO], 4), QD_IN(taux, 4),

@@ -109,18 +109,16 @@ __device__ __forceinline__ double qd_med_value(double x, int transform, double t
 // sel_state: [0] count of positives, [1] prefix_lo, [2] rank_lo, [3] prefix_hi, [4] rank_hi, [6] ticket
 __global__ void __launch_bounds__(QD_BLOCK)
 k_sel_pass(QdGeom G, const double* __restrict__ x, int transform, double tparam, unsigned long long* st,
-           unsigned int* hist, int shift, int width, int first, int mode, int dbg) {
+           unsigned int* hist, int shift, int width, int first, int mode) {
     // mode 0: histogram + scan by the last workgroup (single GPU)
     // mode 1: histogram only   mode 2: scan only (one workgroup) -- latitude bands all-reduce the
     //         histogram between the two
     __shared__ unsigned int sh[2 * QD_HIST_BINS];
-    __shared__ unsigned int csum[2][QD_BLOCK];
     __shared__ unsigned long long s_st[8];
     __shared__ int s_last;
     const int t = threadIdx.x;
     const unsigned long long n0 = __hip_atomic_load(&st[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!first && n0 == 0ull) return;                        // no positive entry: nothing to refine
-    if (dbg & 16) return;
     if (mode != 2) {
     for (int k = t; k < 2 * QD_HIST_BINS; k += QD_BLOCK) sh[k] = 0u;
     const unsigned long long plo = __hip_atomic_load(&st[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -130,7 +128,7 @@ k_sel_pass(QdGeom G, const double* __restrict__ x, int transform, double tparam,
     const int jstep = gridDim.x * QD_BLOCK;
     // few, fat workgroups: each walks several rows so its LDS histogram is dense (fewer global atomics,
     // fewer tickets on the single counter word)
-    for (int i = G.row0 + (int)blockIdx.y; i < G.row0 + ((dbg & 32) ? 0 : G.nrows); i += (int)gridDim.y) {
+    for (int i = G.row0 + (int)blockIdx.y; i < G.row0 + G.nrows; i += (int)gridDim.y) {
     const size_t b = (size_t)qd_lrow(G, i) * G.nlon;
     for (int jb = blockIdx.x * QD_BLOCK; jb < G.nlon; jb += 8 * jstep) {
     // issue up to 8 independent loads per thread before touching the (wave-synchronising) histogram code:
@@ -153,20 +151,8 @@ k_sel_pass(QdGeom G, const double* __restrict__ x, int transform, double tparam,
         const unsigned int digit = (unsigned int)((bits >> shift) & ((1u << width) - 1u));
         const bool in_lo = pos && (first || hi_bits == (plo >> up));
         const bool in_hi = pos && !first && plo != phi && hi_bits == (phi >> up);
-        // Digits of the leading passes (sign + exponent bits) are shared by most of a wavefront: peel up to
-        // four wave-wide groups with one LDS atomic each before falling back to per-lane atomics, which
-        // would otherwise serialise 64-deep on one bank.
-        bool todo = in_lo;
-        if (dbg & 2) todo = false;
-        for (int it = 0; it < ((dbg & 1) ? 4 : 0); ++it) {
-            const unsigned long long act = __ballot(todo);
-            if (!act) break;
-            const int leader = __ffsll((long long)act) - 1;
-            const unsigned int d0 = (unsigned int)__shfl((int)digit, leader, 64);
-            const unsigned long long same = __ballot(todo && digit == d0);
-            if ((int)(threadIdx.x & 63) == leader) atomicAdd(&sh[d0], (unsigned int)__popcll(same));
-            if (todo && digit == d0) todo = false;
-        }
+        // (wave-level pre-aggregation of equal digits was measured slower than plain LDS atomics here: 41 vs 25 us)
+        const bool todo = in_lo;
         if (todo) atomicAdd(&sh[digit], 1u);
         if (in_hi) atomicAdd(&sh[QD_HIST_BINS + digit], 1u);
     }
@@ -176,12 +162,10 @@ k_sel_pass(QdGeom G, const double* __restrict__ x, int transform, double tparam,
     // fire-and-forget device-scope atomics, all in flight at once; vmcnt(0) drains them (a write leaves the
     // counter when it has reached L2), so the ticket below is ordered after this workgroup's counts without
     // a cache flush and without paying one round trip per bin
-    if (!(dbg & 4)) for (int k = t; k < 2 * QD_HIST_BINS; k += QD_BLOCK) if (sh[k]) atomicAdd(&hist[k], sh[k]);
+    for (int k = t; k < 2 * QD_HIST_BINS; k += QD_BLOCK) if (sh[k]) atomicAdd(&hist[k], sh[k]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (dbg & 8) return;
     if (mode == 1) return;
     __syncthreads();
-    if (dbg & 64) return;
     if (t == 0) {
         const unsigned long long ticket = atomicAdd(&st[6], 1ull);
         s_last = (ticket == (unsigned long long)(gridDim.x * gridDim.y) - 1ull) ? 1 : 0;
@@ -396,14 +380,13 @@ int qd_median_positive_dev(qd_ctx* c, const double* x, double dflt, int slot, in
     // digits from the top: bits 63..53, 52..42, 41..31, 30..20 (11 wide), 19..10, 9..0 (10 wide)
     const int shifts[6] = {53, 42, 31, 20, 10, 0};
     const int widths[6] = {11, 11, 11, 11, 10, 10};
-    static const int dbg = std::getenv("QD_SEL_DBG") ? std::atoi(std::getenv("QD_SEL_DBG")) : 0;
-    static const int nblk = std::getenv("QD_SEL_BLOCKS") ? std::atoi(std::getenv("QD_SEL_BLOCKS")) : 128;
+    const int nblk = 128;         // few, fat workgroups (measured: 64..256 within 10 %; thousands of tiny ones 2x slower)
     dim3 grid(1, std::min(G.nrows, nblk));
     if (c->geo.full && c->sel_cand) {
         // two histogram passes, one collecting pass, one finishing workgroup
         for (int p = 0; p < 2; ++p)
             hipLaunchKernelGGL(k_sel_pass, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, c->sel_state,
-                               c->hist, shifts[p], widths[p], p == 0 ? 1 : 0, 0, dbg);
+                               c->hist, shifts[p], widths[p], p == 0 ? 1 : 0, 0);
         hipLaunchKernelGGL(k_sel_collect, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, c->sel_state,
                            c->sel_cand, c->sel_ccount, (unsigned long long)c->geo.cells(), 22);
         hipLaunchKernelGGL(k_sel_final, dim3(1), dim3(QD_FIN_BLOCK), 0, c->stream, c->sel_state, c->sel_cand, c->sel_ccount,
@@ -413,13 +396,13 @@ int qd_median_positive_dev(qd_ctx* c, const double* x, double dflt, int slot, in
     for (int p = 0; p < 6; ++p) {
         if (c->geo.full) {
             hipLaunchKernelGGL(k_sel_pass, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, c->sel_state,
-                               c->hist, shifts[p], widths[p], p == 0 ? 1 : 0, 0, dbg);
+                               c->hist, shifts[p], widths[p], p == 0 ? 1 : 0, 0);
         } else {
             hipLaunchKernelGGL(k_sel_pass, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, c->sel_state,
-                               c->hist, shifts[p], widths[p], p == 0 ? 1 : 0, 1, dbg);
+                               c->hist, shifts[p], widths[p], p == 0 ? 1 : 0, 1);
             if (qd_allreduce_u32(c, c->hist, 2 * QD_HIST_BINS)) return -1;
             hipLaunchKernelGGL(k_sel_pass, dim3(1, 1), dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, c->sel_state,
-                               c->hist, shifts[p], widths[p], p == 0 ? 1 : 0, 2, dbg);
+                               c->hist, shifts[p], widths[p], p == 0 ? 1 : 0, 2);
         }
     }
     hipLaunchKernelGGL(k_sel_finish, dim3(1), dim3(64), 0, c->stream, c->sel_state, dflt, c->dscal + slot, c->dcount);
