@@ -278,6 +278,63 @@ k_gauss_fused(QdGeom G, const double* __restrict__ in, double* __restrict__ out,
     out[(size_t)qd_lrow(G, i) * G.nlon + j] = acc;
 }
 
+// Row-blocked form of the same blur for small compile-time radii: a workgroup owns QD_GB consecutive rows of a
+// 256-column segment; a thread loads its column's QD_GB + 2R input rows ONCE into registers (instead of 2R+1 rows
+// per output row), forms the axis-0 result of all QD_GB rows from them, and the axis-1 pass reads those from LDS.
+// Identical arithmetic and tap order to k_gauss_fused / the two-kernel form.
+#define QD_GB 8
+template <int RR>
+__global__ void __launch_bounds__(QD_BLOCK)
+k_gauss_rows(QdGeom G, const double* __restrict__ in, double* __restrict__ out, QdGaussW W, int mode_wrap, int clip01,
+             const double* __restrict__ scale_p, double scale_k) {
+    __shared__ double sm[QD_GB][QD_BLOCK + 2 * RR];
+    const int i0 = G.row0 + (int)blockIdx.y * QD_GB;
+    const int nvalid = min(QD_GB, G.row0 + G.nrows - i0);                  // rows of this block inside the launch
+    const int jbase = (int)blockIdx.x * QD_BLOCK;
+    const double sc = scale_p ? *scale_p : scale_k;
+    double w[RR + 1];
+#pragma unroll
+    for (int k = 0; k <= RR; ++k) w[k] = W.w[k];
+    for (int s = threadIdx.x; s < QD_BLOCK + 2 * RR; s += QD_BLOCK) {
+        const int jj = jbase - RR + s;
+        if (jj >= G.nlon + RR) break;
+        const int j = qd_ext(jj, G.nlon, mode_wrap);
+        double x[QD_GB + 2 * RR];
+#pragma unroll
+        for (int q = 0; q < QD_GB + 2 * RR; ++q) {
+            const int qq = q < nvalid + 2 * RR ? q : nvalid + 2 * RR - 1;   // never beyond the rows the valid outputs need
+            x[q] = in[(size_t)qd_lrow(G, qd_ext(i0 - RR + qq, G.nlat, mode_wrap)) * G.nlon + j] * sc;
+        }
+#pragma unroll
+        for (int k = 0; k < QD_GB; ++k) {
+            double tmp = x[k + RR] * w[0];
+#pragma unroll
+            for (int q = RR; q >= 1; --q) tmp += (x[k + RR - q] + x[k + RR + q]) * w[q];
+            sm[k][s] = tmp;
+        }
+    }
+    __syncthreads();
+    const int j = jbase + threadIdx.x;
+    if (j >= G.nlon) return;
+    const int c0 = threadIdx.x + RR;
+#pragma unroll
+    for (int k = 0; k < QD_GB; ++k) {
+        if (k >= nvalid) break;
+        double acc = sm[k][c0] * w[0];
+#pragma unroll
+        for (int q = RR; q >= 1; --q) acc += (sm[k][c0 - q] + sm[k][c0 + q]) * w[q];
+        if (clip01) acc = qd_clip(acc, 0.0, 1.0);
+        out[(size_t)qd_lrow(G, i0 + k) * G.nlon + j] = acc;
+    }
+}
+
+template <int RR>
+static void qd_launch_gauss_rows(qd_ctx* c, const double* in, double* out, const QdGaussW& W, int mode_wrap, int clip01,
+                                 const double* scale_p, double scale_k, int m_out) {
+    QD_ROWS(c, m_out, G, hipLaunchKernelGGL(k_gauss_rows<RR>, dim3((G.nlon + QD_BLOCK - 1) / QD_BLOCK, (G.nrows + QD_GB - 1) / QD_GB),
+                                            dim3(QD_BLOCK), 0, c->stream, G, in, out, W, mode_wrap, clip01, scale_p, scale_k));
+}
+
 // gaussian_filter(in, sigma, mode): axis 0 then axis 1.  out may alias in; tmp is a distinct slab.
 int qd_gaussian(qd_ctx* c, const double* in, double* out, double* tmp, double sigma, int mode_wrap, int m_out, int clip01,
                 const double* scale_p, double scale_k) {
@@ -312,6 +369,13 @@ int qd_gaussian(qd_ctx* c, const double* in, double* out, double* tmp, double si
     }
     for (int k = 0; k <= r; ++k) W.w[k] = phi[r + k] / tot;
     // axis 0 reaches r rows; axis 1 is row-local.  Both passes run on the output margin.
+    if (c->use_fused && out != in && c->geo.nlon > 2 * r && (r == 1 || r == 2 || r == 4)) {
+        if (r == 1) qd_launch_gauss_rows<1>(c, in, out, W, mode_wrap, clip01, scale_p, scale_k, m_out);
+        else if (r == 2) qd_launch_gauss_rows<2>(c, in, out, W, mode_wrap, clip01, scale_p, scale_k, m_out);
+        else qd_launch_gauss_rows<4>(c, in, out, W, mode_wrap, clip01, scale_p, scale_k, m_out);
+        qd_mark(c, {out}, m_out);
+        return 0;
+    }
     if (c->use_fused && out != in && c->geo.nlon > 2 * r) {
         QD_ROWS(c, m_out, G, hipLaunchKernelGGL(k_gauss_fused, qd_grid2d(G), dim3(QD_BLOCK), 0, c->stream, G, in, out, W, mode_wrap, clip01, scale_p, scale_k));
         qd_mark(c, {out}, m_out);
