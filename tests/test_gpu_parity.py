@@ -13,7 +13,7 @@ import os
 import numpy as np
 import pytest
 
-from util import GOLD, STATE, DIAG, load_golden, relerr, surface, run_device_time_step, run_oracle_time_step
+from util import GOLD, STATE, DIAG, load_golden, relerr, surface, run_device_time_step, run_oracle_time_step, oracle_params
 
 pytestmark = pytest.mark.gpu
 
@@ -127,6 +127,27 @@ def test_time_step_vs_reference_and_oracle(gpu, case):
     print(case, {k: f"{a:.1e}/{b:.1e}" for k, (a, b) in errs.items()})
     for k, (a, b) in errs.items():
         assert a < STEP_TOL and b < STEP_TOL, (case, k, a, b)
+
+
+def test_config1_240_steps_181x360_hyper4(gpu):
+    """BASELINE configs[1] / SURVEY 8(d) whole-run bound: 181x360, QD_FILTER_TYPE=hyper4, time_step(Teq, dt) without
+    albedo, ocean off, 240 steps (one planet-day) from the reference's initial state: max-norm relative <= 1e-9 on
+    u, v, h, T_s, q, cloud against the oracle (itself <= 1e-12 from the reference on whole time_step runs)."""
+    import qd_oracle as qo
+    nlat, nlon = 181, 360
+    g, mask, alb, fric = surface(nlat, nlon)
+    over = {"filter_type": "hyper4"}
+    P = oracle_params(over)
+    m0 = qo.AtmosOracle(g, fric, mask, P, C_s_map=np.where(mask == 1, 3e6, P.Cs_ocean).astype(float))
+    d = {"init_" + k: np.array(getattr(m0, k), dtype=float, copy=True) for k in STATE}
+    meta = dict(nlat=nlat, nlon=nlon, over=over, dt=300.0, nsteps=240, with_albedo=False)
+    want = run_oracle_time_step(meta, d)
+    got = run_device_time_step(meta, d)
+    errs = {k: relerr(getattr(got, k), getattr(want, k)) for k in STATE}
+    print(errs)
+    assert float(np.max(np.abs(want.u))) > 1.0            # the run did spin up winds
+    for k, e in errs.items():
+        assert e < STEP_TOL, (k, e)
 
 
 def test_time_step_host_arrays_path(gpu):
