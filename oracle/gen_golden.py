@@ -402,6 +402,39 @@ def case_orography(nlat, nlon, seed):
          ref_orog_factor=fac, ref_precip_orog=pr, ref_orog_factor_strong=fac2, ref_precip_orog_strong=pr2)
 
 
+def case_phyto(nlat, nlon, seed):
+    """PhytoManager.advect_diffuse (pygcm/ecology/phyto.py:496-547) run as the REFERENCE's own method, bound to a
+    minimal stand-in object carrying exactly the attributes the method reads."""
+    import types
+    from types import SimpleNamespace
+    from pygcm.ecology.phyto import PhytoManager
+    from qd_oracle import phyto as ophy
+    g, mask, alb, fric = surface(nlat, nlon)
+    r = np.random.default_rng(seed)
+    S = 3
+    lat = np.deg2rad(g.lat_mesh)
+    C = np.abs(r.normal(0.3, 0.2, (S, nlat, nlon))) * (mask == 0) * (0.5 + np.cos(lat) ** 2)
+    uo = 0.4 * np.cos(lat) * np.sin(2 * np.deg2rad(g.lon_mesh)) + r.normal(0, 0.05, (nlat, nlon))
+    vo = 0.2 * np.sin(2 * lat) * np.cos(3 * np.deg2rad(g.lon_mesh)) + r.normal(0, 0.05, (nlat, nlon))
+    dt = 300.0
+    fake = SimpleNamespace(S=S, land_mask=mask, C_phyto_s=C.copy(), K_h=5.0e3, NL=nlat, NM=nlon, a=6.371e6 if False else None,
+                           dlat=g.dlat_rad, dlon=g.dlon_rad, coslat=np.maximum(np.cos(lat), 0.5))
+    from pygcm import constants as rconst
+    fake.a = rconst.PLANET_RADIUS
+    fake._advect_scalar = types.MethodType(PhytoManager._advect_scalar, fake)
+    fake._laplacian_sphere = types.MethodType(PhytoManager._laplacian_sphere, fake)
+    with ref_env({}):
+        for _ in range(3):
+            PhytoManager.advect_diffuse(fake, uo, vo, dt)
+    out = C.copy()
+    og = qo.Grid(nlat, nlon)
+    for _ in range(3):
+        out = ophy.advect_diffuse(out, uo, vo, dt, og, mask, K_h=5.0e3, adv_alpha=0.7)
+    print(f"    phyto C after 3 steps   oracle-vs-ref maxrel {maxrel(out, fake.C_phyto_s):.2e}")
+    save(f"phyto_{nlat}x{nlon}", dict(kind="phyto", nlat=nlat, nlon=nlon, seed=seed, dt=dt, nsteps=3, K_h=5.0e3, adv_alpha=0.7),
+         C0=C, uo=uo, vo=vo, ref_C=fake.C_phyto_s)
+
+
 def case_driver_physics(nlat, nlon, seed, nsteps=3):
     """run_simulation.py:1766-1934 + 2063-2146 composed from the REFERENCE's functions
     (physics.*, scripts.run_simulation._advect_scalar_periodic, scipy gaussian_filter), interleaved
@@ -513,6 +546,10 @@ def main():
         for (a, b, sd) in ((19, 36, 41), (37, 72, 42)):
             print(f"[driver physics {a}x{b}]")
             case_driver_physics(a, b, sd)
+    if want("phyto"):
+        for (a, b, s) in ((19, 36, 61), (37, 72, 62)):
+            print(f"[phyto transport {a}x{b}]")
+            case_phyto(a, b, s)
     if want("orog"):
         for (a, b, s) in ((19, 36, 51), (37, 72, 52)):
             print(f"[orography {a}x{b}]")

@@ -83,6 +83,23 @@ def test_hip_compat_seam_matches_reference(gpu, shape):
     assert isinstance(hc.to_numpy(np.arange(3)), np.ndarray)
 
 
+@pytest.mark.parametrize("shape", [(19, 36), (37, 72)])
+def test_phyto_transport_vs_reference(gpu, shape):
+    """qingdai_amd.phyto.advect_diffuse (phyto.py:496-547 over qd_op_advect / qd_op_laplacian, ocean cos floor)."""
+    import qingdai_amd as qa
+    from qingdai_amd import phyto
+    meta, d = load_golden(f"phyto_{shape[0]}x{shape[1]}")
+    _, mask, _, _ = surface(*shape)
+    dev = qa.SphericalGrid(*shape)._ops()
+    C = d["C0"]
+    for _ in range(meta["nsteps"]):
+        C = phyto.advect_diffuse(dev, C, d["uo"], d["vo"], meta["dt"], mask, K_h=meta["K_h"], adv_alpha=meta["adv_alpha"])
+    e = relerr(C, d["ref_C"])
+    print(e)
+    assert e < 1e-12
+    assert np.all(C[:, mask == 1] == 0.0) and np.all(C >= 0.0)
+
+
 def test_median_exact(gpu):
     import qingdai_amd as qa
     grid = qa.SphericalGrid(37, 72)

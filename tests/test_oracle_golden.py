@@ -114,6 +114,20 @@ def test_orographic_factor_matches_reference(shape):
     assert d["ref_orog_factor_strong"].max() > 1.5          # the enhancement really is exercised
 
 
+@pytest.mark.parametrize("shape", [(19, 36), (37, 72)])
+def test_phyto_transport_matches_reference(shape):
+    """PhytoManager.advect_diffuse (pygcm/ecology/phyto.py:496-547), three steps, against the reference's own method
+    (<= 1 ulp: the bilinear gather on folded pole rows, see numerics.bilinear_wrap)."""
+    from qd_oracle import phyto as ophy
+    meta, d = load_golden(f"phyto_{shape[0]}x{shape[1]}")
+    g, mask, _, _ = surface(*shape)
+    C = d["C0"]
+    for _ in range(meta["nsteps"]):
+        C = ophy.advect_diffuse(C, d["uo"], d["vo"], meta["dt"], g, mask, K_h=meta["K_h"], adv_alpha=meta["adv_alpha"])
+    assert relerr(C, d["ref_C"]) < 1e-15
+    assert np.all(C[:, mask == 1] == 0.0) and np.all(C >= 0.0)
+
+
 def test_known_answers_appendix_a3():
     """19x36, defaults, albedo passed, 12 steps of the benchmark loop."""
     meta, d = load_golden("ts_19x36_default_alb")
