@@ -148,7 +148,7 @@ int qd_driver_physics(qd_handle h, double dt);
 int qd_hydrology_commit(qd_handle h, double dt);
 /* benchmark_jax.py:124-158 as one resident loop of n steps: forcing -> albedo -> time_step [-> ocean
  * coupling] [-> hydrology commit].  flags bit0 = with_ocean, bit1 = with_driver_physics (else the simple
- * ocean/land albedo of benchmark_jax.py:129), bit2 = pass albedo to time_step, bit3 = hydrology commit.  `stars` holds n rows of 7 host scalars
+ * ocean/land albedo of benchmark_jax.py:129), bit2 = pass albedo to time_step, bit3 = hydrology commit, bit4 = energy diagnostics on the first step (qd_energy_diagnostics_last).  `stars` holds n rows of 7 host scalars
  * (flux_A, decl_A, ra_A, flux_B, decl_B, ra_B, theta), evaluated by the caller as forcing.py:85-125 does. */
 int qd_step_n(qd_handle h, int n, double dt, int flags, const double* stars);
 int qd_last_ocean_nsub(qd_handle h, int* n_sub);
@@ -175,6 +175,9 @@ int qd_op_median_positive(qd_handle h, const double* x, double dflt, double* out
  * coupling block (run_simulation.py:2199-2239): out[10] = cos-weighted global means of
  * TOA_net, SFC_net, ATM_net, I, R, OLR, SW_sfc, LW_sfc, SH, LH. */
 int qd_energy_diagnostics(qd_handle h, double out[10]);
+/* the same ten means as taken INSIDE the last qd_step_n call that had flags bit4 set: on its first step, after time_step and
+ * before the ocean step, i.e. exactly where run_simulation.py:2242-2246 evaluates them for the autotuner */
+int qd_energy_diagnostics_last(qd_handle h, double out[10]);
 enum qd_reduce_op { QD_R_SUM = 0, QD_R_COSWEIGHTED_MEAN = 1, QD_R_MAX = 2, QD_R_MIN = 3, QD_R_MAXABS = 4 };
 int qd_reduce(qd_handle h, int field, int op, double* out);
 

@@ -251,7 +251,7 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
     if (build_tables(c)) return bail("table allocation", hipErrorOutOfMemory);
     if ((e = hipMalloc(&c->k4_atm, (size_t)5 * d->n_lat * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc(&c->k4_ocn, (size_t)3 * d->n_lat * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
-    c->red_blocks = (8 + (d->n_lon + QD_BLOCK - 1) / QD_BLOCK) * c->geo.lrows() + 64;
+    c->red_blocks = (12 + (d->n_lon + QD_BLOCK - 1) / QD_BLOCK) * c->geo.lrows() + 64;   // >= 10 x rows: qd_energy_diagnostics
     if ((e = hipMalloc(&c->red_partial, (size_t)c->red_blocks * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc(&c->dscal, QD_S_COUNT * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc(&c->dcount, 8 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
@@ -459,7 +459,7 @@ extern "C" int qd_hydrology_commit(qd_handle c, double dt) {
 extern "C" int qd_step_n(qd_handle c, int n, double dt, int flags, const double* stars) {
     if (!c || !stars) return -1;
     hipSetDevice(c->desc.device);
-    const int with_ocean = flags & 1, with_phys = flags & 2, pass_alb = flags & 4, with_hydro = flags & 8;
+    const int with_ocean = flags & 1, with_phys = flags & 2, pass_alb = flags & 4, with_hydro = flags & 8, want_diag = flags & 16;
     for (int s = 0; s < n; ++s) {
         const double* st = stars + (size_t)7 * s;
         int rc;
@@ -467,6 +467,9 @@ extern "C" int qd_step_n(qd_handle c, int n, double dt, int flags, const double*
         else if ((rc = qd_simple_albedo_impl(c, 0.08))) return rc;
         if ((rc = qd_forcing_impl(c, st, st + 3, st[6], 1))) return rc;
         if ((rc = qd_atmos_step_impl(c, dt, pass_alb ? 1 : 0))) return rc;
+        // bit4: energy-budget means of the FIRST step, taken where the reference driver takes them -- after time_step, on the
+        // fluxes of the coupling block (run_simulation.py:2199-2246) -- and kept for qd_energy_diagnostics_last
+        if (with_ocean && want_diag && s == 0 && (rc = qd_energy_diag_impl(c, c->last_diag))) return rc;
         if (with_ocean && (rc = qd_ocean_step_impl(c, dt, 1, 1, 1))) return rc;
         if (with_hydro && (rc = qd_hydrology_commit_impl(c, dt))) return rc;
     }
@@ -597,6 +600,11 @@ extern "C" int qd_reduce(qd_handle c, int field, int op, double* out) {
     return 0;
 }
 
+extern "C" int qd_energy_diagnostics_last(qd_handle c, double* out) {
+    if (!c || !out) return -1;
+    for (int k = 0; k < 10; ++k) out[k] = c->last_diag[k];
+    return 0;
+}
 extern "C" int qd_energy_diagnostics(qd_handle c, double* out) {
     if (!c || !out) return -1;
     hipSetDevice(c->desc.device);

@@ -147,6 +147,7 @@ struct qd_ctx {
     unsigned long long* dcount = nullptr;  // device counters
     unsigned int* hist = nullptr;  // [2][QD_HIST_BINS]
     unsigned long long* sel_state = nullptr; // radix-select state
+    double last_diag[10] = {0};      // energy-budget means taken inside qd_step_n (flags bit 4)
     int has_elevation = 0;           // an ELEVATION map has been uploaded (orographic factor needs one)
     double* zonal_tw = nullptr;      // [2][nlon] cos / sin(2 pi m / nlon) of the zonal spectral filter
     double* sel_cand = nullptr;      // [2][cells] candidates of the two middle ranks after two radix passes (whole-globe handles)

@@ -192,24 +192,29 @@ class Simulation:
         p = self.dev.params
         autotune = (int(p.gh_lock) == 0) and int(os.environ.get("QD_ENERGY_AUTOTUNE", "0")) == 1 and self.ocean is not None
         if autotune:                                           # run_simulation.py:1256-1257, 2242-2246
+            # the reference evaluates the budget inside step i (i % every == 0), after time_step, and the nudged
+            # parameters first act on step i+1: run that step on its own with the in-step diagnostics, then the rest
             from . import energy as _energy
             every = max(1, int(os.environ.get("QD_ENERGY_TUNE_EVERY", "50")))
             left = n
             while left > 0:
                 if self._step_index % every == 0:
-                    _energy.autotune_greenhouse_params(p, _energy.compute_energy_diagnostics(self.dev))
+                    self._run_chunk(1, energy_diag=True)
+                    _energy.autotune_greenhouse_params(p, self.dev.energy_diagnostics_last())
                     self.dev.push_params()
+                    left -= 1
+                    continue
                 k = min(left, every - (self._step_index % every))
                 self._run_chunk(k)
                 left -= k
             return
         self._run_chunk(n)
 
-    def _run_chunk(self, n):
+    def _run_chunk(self, n, energy_diag=False):
         times = self.t + self.dt * np.arange(n)
         stars = self.forcing.star_table(times)
         self.dev.step_n(stars, float(self.dt), with_ocean=self.ocean is not None, with_physics=True, pass_albedo=False,
-                        with_hydrology=True)
+                        with_hydrology=True, energy_diag=energy_diag)
         self.t = float(times[-1] + self.dt)
         self._step_index += n
 
@@ -296,7 +301,6 @@ def main(argv=None):
     if env.get("QD_RESTART_OUT"):
         sim.save(env["QD_RESTART_OUT"])
         print(f"[Restart] wrote {env['QD_RESTART_OUT']}")
-        state["saved"] = True
     print("--- Simulation Finished ---")
     return 0
 
