@@ -649,28 +649,18 @@ __device__ __forceinline__ bool qd_ocn_fast(const QdGeom& G, const QdTabs& T, co
     const int j = jraw < 0 ? jraw + mlon : (jraw >= mlon ? jraw - mlon : jraw);
     const unsigned o0 = (unsigned)qd_lrow(G, g0) * (unsigned)mlon + (unsigned)j;
     double ae[K], ru[K], rv[K], rtx[K], rty[K];
-    int rl[K];
+    unsigned lmask = 0u;                                    // land flags of the K cells, one bit each
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const unsigned o = o0 + (unsigned)k * (unsigned)mlon;
-        ae[k] = P.eta[o]; ru[k] = P.uo[o]; rv[k] = P.vo[o]; rtx[k] = P.taux[o]; rty[k] = P.tauy[o]; rl[k] = (int)P.land[o];
-    }
-    // eta rows wrap across the poles (np.roll(axis=0), ocean.py:308): the row beyond a pole is the other pole's row
-    double wrap_s = 0.0, wrap_n = 0.0;
-    if (POLE) {
-        if (g0 == 0) wrap_s = P.eta[(unsigned)qd_lrow(G, n - 1) * (unsigned)mlon + (unsigned)j];
-        if (g0 + K == n) wrap_n = P.eta[(unsigned)qd_lrow(G, 0) * (unsigned)mlon + (unsigned)j];
+        ae[k] = P.eta[o]; ru[k] = P.uo[o]; rv[k] = P.vo[o]; rtx[k] = P.taux[o]; rty[k] = P.tauy[o];
+        lmask |= (P.land[o] == 1 ? 1u : 0u) << k;
     }
     bool bad = false;
     if (P.eta_mean) {                                       // deferred eta -= mean; nan_to_num; clip of the previous sub-step
         const double em = *P.eta_mean, cap = P.eta_cap;
 #pragma unroll
         for (int k = 0; k < K; ++k) { const double e = ae[k] - em; bad |= qd_nonfinite(e); ae[k] = fmin(fmax(e, -cap), cap); }
-        if (POLE) {
-            const double es_ = wrap_s - em, en_ = wrap_n - em;
-            bad |= qd_nonfinite(es_) | qd_nonfinite(en_);
-            wrap_s = fmin(fmax(es_, -cap), cap); wrap_n = fmin(fmax(en_, -cap), cap);
-        }
     }
     double sA[K + 2], sP[K], sQ[K], sF[K], sI[K], sX[K];
 #pragma unroll
@@ -685,7 +675,13 @@ __device__ __forceinline__ bool qd_ocn_fast(const QdGeom& G, const QdTabs& T, co
     __syncthreads();
     double es_edge = Ap[qd_clampi(rho0 - 1, 0, RA - 1) * S + lane];
     double en_edge = Ap[qd_clampi(rho0 + K, 0, RA - 1) * S + lane];
-    if (POLE) { if (g0 == 0) es_edge = wrap_s; if (g0 + K == n) en_edge = wrap_n; }
+    if (POLE && (g0 == 0 || g0 + K == n)) {
+        // eta rows wrap across the poles (np.roll(axis=0), ocean.py:308): the row beyond a pole is the other pole's row
+        // (loaded here, by the one wave that needs it, rather than carried in registers from the top of the kernel)
+        double wr = P.eta[(unsigned)qd_lrow(G, g0 == 0 ? n - 1 : 0) * (unsigned)mlon + (unsigned)j];
+        if (P.eta_mean) { const double e = wr - *P.eta_mean; bad |= qd_nonfinite(e); wr = fmin(fmax(e, -P.eta_cap), P.eta_cap); }
+        if (g0 == 0) es_edge = wr; else en_edge = wr;
+    }
     // ocean.py:306-336
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -698,7 +694,7 @@ __device__ __forceinline__ bool qd_ocn_fast(const QdGeom& G, const QdTabs& T, co
         const double du = (f * v0 - P.g * gx + rtx[k] * P.inv_rhoH - P.r_bot * u0);
         const double dv = (-f * u0 - P.g * gy + rty[k] * P.inv_rhoH - P.r_bot * v0);
         double un = u0 + P.sub_dt * du, vn = v0 + P.sub_dt * dv;
-        if (rl[k] == 1) { un = 0.0; vn = 0.0; }
+        if ((lmask >> k) & 1u) { un = 0.0; vn = 0.0; }
         const double sx = P.sub_dt * sX[k];
         ru[k] = un - sx * un;
         rv[k] = vn - sx * vn;
