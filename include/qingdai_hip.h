@@ -170,6 +170,11 @@ int qd_op_vorticity(qd_handle h, const double* u, const double* v, double* out);
 int qd_op_gaussian(qd_handle h, const double* F, double sigma, int mode_wrap, double* out); /* physics.py:44 */
 int qd_op_median_positive(qd_handle h, const double* x, double dflt, double* out);  /* dynamics.py:344-348 */
 
+/* ---- ecology spectral sub-step, first stage (pygcm/ecology/spectral.py:304-426) --------------------
+ * dual_star_insolation_to_bands on the resident ISR_A / ISR_B: specA/specB/tray are the NB host-computed band weights of the
+ * two stars and the Rayleigh factor; the result [nb][n_lat][n_lon] f64 stays resident and is also copied to `out_host_or_null`. */
+int qd_band_insolation(qd_handle h, int nb, const double* specA, const double* specB, const double* tray, double* out_host_or_null);
+
 /* ---- reductions for diagnostics (energy.py:494-538, ocean.py:535-561) -------------- */
 /* compute_energy_diagnostics (energy.py:494-538) from the resident state, with the flux formulas of the driver's
  * coupling block (run_simulation.py:2199-2239): out[10] = cos-weighted global means of

@@ -435,6 +435,34 @@ def case_phyto(nlat, nlon, seed):
          C0=C, uo=uo, vo=vo, ref_C=fake.C_phyto_s)
 
 
+def case_spectral_bands(nlat, nlon):
+    """dual_star_insolation_to_bands (pygcm/ecology/spectral.py:304-426) from the REFERENCE, NB = 16 (default mode) and NB = 8
+    in Rayleigh mode, on the reference's own two-star insolation at two times."""
+    from pygcm.ecology import spectral as rsp
+    from pygcm.forcing import ThermalForcing
+    from pygcm.orbital import OrbitalSystem
+    from qd_oracle import spectral as osp
+    g, mask, alb, fric = surface(nlat, nlon)
+    out = {}
+    with ref_env({}):
+        forcing = ThermalForcing(g, OrbitalSystem())
+        for ti, t in enumerate((0.0, 4.1e6)):
+            insA, insB = forcing.calculate_insolation_components(t)
+            out[f"insA_{ti}"], out[f"insB_{ti}"] = insA, insB
+            out[f"ref_bands16_{ti}"] = rsp.dual_star_insolation_to_bands(insA, insB, rsp.make_bands(16, 380.0, 780.0))
+        os.environ["QD_ECO_TOA_TO_SURF_MODE"] = "rayleigh"
+        out["ref_bands8_rayleigh_1"] = rsp.dual_star_insolation_to_bands(out["insA_1"], out["insB_1"], rsp.make_bands(8, 400.0, 700.0))
+        b16 = rsp.make_bands(16, 380.0, 780.0)
+        out["ref_specA16"] = rsp.blackbody_band_weights(rsp.estimate_teff_from_LM(0.7, 0.914, j=0.8), b16)
+        out["ref_specB16"] = rsp.blackbody_band_weights(rsp.estimate_teff_from_LM(0.410, 0.8, j=0.8), b16)
+    for ti in (0, 1):
+        o = osp.dual_star_insolation_to_bands(out[f"insA_{ti}"], out[f"insB_{ti}"], osp.make_bands(16, 380.0, 780.0))
+        print(f"    bands16 t{ti}          oracle-vs-ref maxrel {maxrel(o, out[f'ref_bands16_{ti}']):.2e}")
+    o = osp.dual_star_insolation_to_bands(out["insA_1"], out["insB_1"], osp.make_bands(8, 400.0, 700.0), rayleigh=dict(mode="rayleigh"))
+    print(f"    bands8 rayleigh      oracle-vs-ref maxrel {maxrel(o, out['ref_bands8_rayleigh_1']):.2e}")
+    save(f"spectral_{nlat}x{nlon}", dict(kind="spectral", nlat=nlat, nlon=nlon, times=[0.0, 4.1e6]), **out)
+
+
 def case_driver_physics(nlat, nlon, seed, nsteps=3):
     """run_simulation.py:1766-1934 + 2063-2146 composed from the REFERENCE's functions
     (physics.*, scripts.run_simulation._advect_scalar_periodic, scipy gaussian_filter), interleaved
@@ -546,6 +574,9 @@ def main():
         for (a, b, sd) in ((19, 36, 41), (37, 72, 42)):
             print(f"[driver physics {a}x{b}]")
             case_driver_physics(a, b, sd)
+    if want("bands"):
+        print("[spectral bands 19x36]")
+        case_spectral_bands(19, 36)
     if want("phyto"):
         for (a, b, s) in ((19, 36, 61), (37, 72, 62)):
             print(f"[phyto transport {a}x{b}]")

@@ -23,6 +23,6 @@ from .ocean import WindDrivenSlabOcean                 # noqa: F401
 from .forcing import OrbitalSystem, ThermalForcing     # noqa: F401
 from . import topography                               # noqa: F401
 from .double_buffer import DoubleBufferingArray       # noqa: F401
-from . import hip_compat, energy, ncio, phyto          # noqa: F401
+from . import hip_compat, energy, ncio, phyto, spectral  # noqa: F401
 
 __version__ = "0.1.0"

@@ -294,6 +294,7 @@ extern "C" int qd_destroy(qd_handle c) {
     if (c->red_partial) hipFree(c->red_partial); if (c->dscal) hipFree(c->dscal);
     if (c->dcount) hipFree(c->dcount); if (c->hist) hipFree(c->hist); if (c->sel_state) hipFree(c->sel_state);
     if (c->zonal_tw) hipFree(c->zonal_tw);
+    if (c->bands) hipFree(c->bands);
     if (c->sel_cand) hipFree(c->sel_cand); if (c->sel_ccount) hipFree(c->sel_ccount);
     if (c->hpin) hipHostFree(c->hpin);
     if (c->hpin_rows) hipHostFree(c->hpin_rows);
@@ -600,6 +601,11 @@ extern "C" int qd_reduce(qd_handle c, int field, int op, double* out) {
     return 0;
 }
 
+extern "C" int qd_band_insolation(qd_handle c, int nb, const double* specA, const double* specB, const double* tray, double* out_host) {
+    if (!c || !specA || !specB || !tray) return -1;
+    hipSetDevice(c->desc.device);
+    return qd_band_insolation_impl(c, nb, specA, specB, tray, out_host);
+}
 extern "C" int qd_energy_diagnostics_last(qd_handle c, double* out) {
     if (!c || !out) return -1;
     for (int k = 0; k < 10; ++k) out[k] = c->last_diag[k];

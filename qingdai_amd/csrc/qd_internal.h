@@ -147,6 +147,8 @@ struct qd_ctx {
     unsigned long long* dcount = nullptr;  // device counters
     unsigned int* hist = nullptr;  // [2][QD_HIST_BINS]
     unsigned long long* sel_state = nullptr; // radix-select state
+    double* bands = nullptr;         // [bands_nb][cells] band insolation planes (qd_band_insolation), allocated on first use
+    int bands_nb = 0;
     double last_diag[10] = {0};      // energy-budget means taken inside qd_step_n (flags bit 4)
     int has_elevation = 0;           // an ELEVATION map has been uploaded (orographic factor needs one)
     double* zonal_tw = nullptr;      // [2][nlon] cos / sin(2 pi m / nlon) of the zonal spectral filter
@@ -247,6 +249,7 @@ int  qd_gaussian_swap(qd_ctx* c, double*& field, double*& tmp, double sigma, int
 bool qd_gauss_can_fuse(const qd_ctx* c, double sigma);
 int  qd_gauss_radius(double sigma);
 int  qd_energy_diag_impl(qd_ctx* c, double* host_out);    // qd_ocean.hip
+int  qd_band_insolation_impl(qd_ctx* c, int nb, const double* specA, const double* specB, const double* tray, double* out_host);   // qd_physics.hip
 int  qd_zonal_filter_fields(qd_ctx* c, double** fields, int nf, double cutoff, double damp, int m);
 int  qd_adv_reach(const qd_ctx* c, double dt, double vmax);
 

@@ -503,3 +503,64 @@ int qd_driver_physics_impl(qd_ctx* c, double dt) {
     }
     return 0;
 }
+
+
+// ------------------------------------------------------------------ ecology spectral sub-step, stage 1
+// dual_star_insolation_to_bands (pygcm/ecology/spectral.py:397-426): per cell S_b = (specA_b insA + specB_b insB) T_ray_b,
+// S_sum = sum_b S_b (in band order, like np.sum(axis=0)), I_b = S_b / S_sum * (insA + insB) where S_sum > 1e-12 and
+// insA + insB > 1e-12, else 0; non-finite -> 0.  One thread per cell, bands in registers (NB <= QD_MAXBANDS).
+#define QD_MAXBANDS 32
+struct QdBandW { double a[QD_MAXBANDS], b[QD_MAXBANDS], t[QD_MAXBANDS]; int nb; };
+__global__ void __launch_bounds__(QD_BLOCK)
+k_band_insolation(QdGeom G, QdBandW W, const double* __restrict__ insA, const double* __restrict__ insB, double* __restrict__ out,
+                  size_t plane) {
+    const QdTile tl = qd_tile();
+    const int j = tl.seg * QD_BLOCK + threadIdx.x;
+    if (j >= G.nlon) return;
+    const size_t o = (size_t)qd_lrow(G, G.row0 + tl.row) * G.nlon + j;
+    const double A = insA[o], B = insB[o];
+    const double tot = A + B;
+    double S[QD_MAXBANDS];
+    double sum = 0.0;
+#pragma unroll
+    for (int b = 0; b < QD_MAXBANDS; ++b) {
+        if (b < W.nb) { S[b] = (W.a[b] * A + W.b[b] * B) * W.t[b]; sum += S[b]; }
+    }
+    const bool pos = (sum > 1e-12) && (tot > 1e-12);
+#pragma unroll
+    for (int b = 0; b < QD_MAXBANDS; ++b) {
+        if (b < W.nb) {
+            double v = pos ? (S[b] / sum) * tot : 0.0;
+            if (!(fabs(v) <= DBL_MAX)) v = 0.0;               // nan_to_num(nan=0, posinf=0, neginf=0)
+            out[(size_t)b * plane + o] = v;
+        }
+    }
+}
+
+int qd_band_insolation_impl(qd_ctx* c, int nb, const double* specA, const double* specB, const double* tray, double* out_host) {
+    if (nb < 1 || nb > QD_MAXBANDS) return qd_fail(c, "qd_band_insolation: 1 <= nb <= 32");
+    const size_t plane = c->geo.cells();
+    if (c->bands_nb < nb) {
+        if (c->bands) hipFree(c->bands);
+        c->bands = nullptr; c->bands_nb = 0;
+        if (hipMalloc(&c->bands, (size_t)nb * plane * sizeof(double)) != hipSuccess) return qd_fail(c, "hipMalloc band planes");
+        c->bands_nb = nb;
+    }
+    QdBandW W; W.nb = nb;
+    for (int b = 0; b < QD_MAXBANDS; ++b) { W.a[b] = b < nb ? specA[b] : 0.0; W.b[b] = b < nb ? specB[b] : 0.0; W.t[b] = b < nb ? tray[b] : 0.0; }
+    double** F = c->f;
+    const int m = qd_plan(c, {QD_IN(F[QD_F_ISR_A], 0), QD_IN(F[QD_F_ISR_B], 0)});
+    if (m < 0) return -1;
+    QD_ROWS(c, m, G, hipLaunchKernelGGL(k_band_insolation, qd_grid2d(G), dim3(QD_BLOCK), 0, c->stream, G, W, F[QD_F_ISR_A], F[QD_F_ISR_B],
+                                        c->bands, plane));
+    if (out_host) {
+        const QdGeom& G = c->geo;
+        const size_t rowb = (size_t)G.nlon * sizeof(double);
+        for (int b = 0; b < nb; ++b)
+            QD_HIP(c, hipMemcpyAsync((char*)out_host + ((size_t)b * G.nlat + G.row0) * rowb,
+                                     (const char*)(c->bands + (size_t)b * plane) + (size_t)G.halo * rowb, rowb * G.nrows,
+                                     hipMemcpyDeviceToHost, c->stream));
+        QD_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}

@@ -100,6 +100,26 @@ def test_phyto_transport_vs_reference(gpu, shape):
     assert np.all(C[:, mask == 1] == 0.0) and np.all(C >= 0.0)
 
 
+def test_spectral_band_insolation_vs_reference(gpu, monkeypatch):
+    """qd_band_insolation (ecology spectral sub-step, stage 1; spectral.py:304-426) on the resident ISR_A / ISR_B."""
+    import qingdai_amd as qa
+    from qingdai_amd import spectral as psp
+    from qingdai_amd.device import Device
+    meta, d = load_golden("spectral_19x36")
+    p = qa.QdParams(); p.has_csmap = 0
+    dev = Device(qa.SphericalGrid(19, 36), p)
+    for ti in (0, 1):
+        dev.upload_now("ISR_A", d[f"insA_{ti}"]); dev.upload_now("ISR_B", d[f"insB_{ti}"])
+        got = psp.dual_star_insolation_to_bands(dev, psp.make_bands(16, 380.0, 780.0), j_A=0.8, j_B=0.8)
+        assert relerr(got, d[f"ref_bands16_{ti}"]) < 1e-15, ti
+        assert np.all(got[:, (d[f"insA_{ti}"] + d[f"insB_{ti}"]) <= 1e-12] == 0.0)                         # night side stays zero
+    monkeypatch.setenv("QD_ECO_TOA_TO_SURF_MODE", "rayleigh")
+    got = psp.dual_star_insolation_to_bands(dev, psp.make_bands(8, 400.0, 700.0), j_A=0.8, j_B=0.8)
+    assert relerr(got, d["ref_bands8_rayleigh_1"]) < 1e-15
+    assert psp.dual_star_insolation_to_bands(dev, psp.make_bands(8, 400.0, 700.0), download=False) is None   # resident only
+    dev.close()
+
+
 def test_median_exact(gpu):
     import qingdai_amd as qa
     grid = qa.SphericalGrid(37, 72)

@@ -128,6 +128,24 @@ def test_phyto_transport_matches_reference(shape):
     assert np.all(C[:, mask == 1] == 0.0) and np.all(C >= 0.0)
 
 
+def test_spectral_band_insolation_matches_reference():
+    """dual_star_insolation_to_bands (pygcm/ecology/spectral.py:304-426): oracle and the product's host-side band tables
+    against the reference's outputs (NB = 16 default mode at two times; NB = 8 in Rayleigh mode)."""
+    from qd_oracle import spectral as osp
+    from qingdai_amd import spectral as psp
+    meta, d = load_golden("spectral_19x36")
+    b16 = osp.make_bands(16, 380.0, 780.0)
+    for ti in (0, 1):
+        got = osp.dual_star_insolation_to_bands(d[f"insA_{ti}"], d[f"insB_{ti}"], b16)
+        assert np.array_equal(got, d[f"ref_bands16_{ti}"])
+        tot = d[f"insA_{ti}"] + d[f"insB_{ti}"]
+        assert np.allclose(got.sum(axis=0), np.where(tot > 1e-12, tot, 0.0), rtol=1e-13, atol=1e-12)     # bands partition the total
+    got = osp.dual_star_insolation_to_bands(d["insA_1"], d["insB_1"], osp.make_bands(8, 400.0, 700.0), rayleigh=dict(mode="rayleigh"))
+    assert np.array_equal(got, d["ref_bands8_rayleigh_1"])
+    specA, specB, tray = psp.star_band_weights(psp.make_bands(16, 380.0, 780.0), j_A=0.8, j_B=0.8)
+    assert np.array_equal(specA, d["ref_specA16"]) and np.array_equal(specB, d["ref_specB16"]) and np.all(tray == 1.0)
+
+
 def test_known_answers_appendix_a3():
     """19x36, defaults, albedo passed, 12 steps of the benchmark loop."""
     meta, d = load_golden("ts_19x36_default_alb")
