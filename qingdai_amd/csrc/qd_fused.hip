@@ -461,14 +461,26 @@ __device__ __forceinline__ QdFastTile qd_fast_tile(const QdGeom& G, int i0) {
 }
 
 struct QdPoleC { int n; const double* poleA; };
+struct QdLapTabs { const double *A, *P, *Q; };      // lapA / lapP / lapQ of the cos-floor kind
 
 // one spherical Laplacian over the wave's K rows.  X: the rows in registers, Xp: LDS plane for the rows that
 // cross a wave boundary.
 template <int TR, bool POLE>
 __device__ __forceinline__ void qd_lap_rows(const double (&X)[QdFast<TR>::K], double (&L)[QdFast<TR>::K], double* __restrict__ Xp,
-                                            int lane, int rho0, int g0, const double (&sA)[QdFast<TR>::K + 2],
-                                            const double (&sP)[QdFast<TR>::K], const double (&sQ)[QdFast<TR>::K], const QdPoleC& C) {
+                                            int lane, int rho0, int g0, const QdLapTabs& LT, const QdPoleC& C) {
     constexpr int K = QdFast<TR>::K, RA = QdFast<TR>::RA, S = QD_S;
+    // The row coefficients are re-read through the scalar cache in EVERY pass (three merged s_load_dwordxN, issued here so
+    // the LDS exchange and the barrier hide their latency) instead of living in SGPRs across the kernel: with ~45 table
+    // values plus the kernel's pointers the SGPR file overflowed and every use turned into a v_readlane from a spill VGPR
+    // (measured: 4600 v_readlane in the kernel, 45 % of its VALU instructions).  The empty asm makes the row index opaque,
+    // otherwise the identical loads of consecutive passes are merged again and stay live.
+    int gq = g0;
+    asm volatile("" : "+s"(gq));
+    double sA[K + 2], sP[K], sQ[K];
+#pragma unroll
+    for (int k = 0; k < K + 2; ++k) sA[k] = qd_sload(LT.A, POLE ? qd_clampi(gq - 1 + k, 0, C.n - 1) : gq - 1 + k);
+#pragma unroll
+    for (int k = 0; k < K; ++k) { sP[k] = qd_sload(LT.P, gq + k); sQ[k] = qd_sload(LT.Q, gq + k); }
     Xp[(rho0 + 0) * S + lane] = X[0];
     Xp[(rho0 + 1) * S + lane] = X[1];
     Xp[(rho0 + K - 2) * S + lane] = X[K - 2];
@@ -510,8 +522,7 @@ __device__ __forceinline__ void qd_lap_rows(const double (&X)[QdFast<TR>::K], do
 template <int TR, bool POLE>
 __device__ __forceinline__ void qd_del4_fast(const double (&Bk)[QdFast<TR>::K], double* __restrict__ Bp, double* __restrict__ Dp,
                                              double* __restrict__ out, const QdGeom& G, const QdFastTile& t, int jraw, int lane, int rho0,
-                                             const double (&sA)[QdFast<TR>::K + 2], const double (&sP)[QdFast<TR>::K],
-                                             const double (&sQ)[QdFast<TR>::K], const double* k4row, double k4s, double dt,
+                                             const QdLapTabs& LT, const double* k4row, double k4s, double dt,
                                              const QdPoleC& C, bool& bad) {
     constexpr int K = QdFast<TR>::K;
     const int g0 = t.p0 + rho0;
@@ -519,8 +530,8 @@ __device__ __forceinline__ void qd_del4_fast(const double (&Bk)[QdFast<TR>::K], 
 #pragma unroll
     for (int k = 0; k < K; ++k) sK[k] = k4row ? qd_sload(k4row, g0 + k) : k4s;
     double Dk[K], L2[K];
-    qd_lap_rows<TR, POLE>(Bk, Dk, Bp, lane, rho0, g0, sA, sP, sQ, C);
-    qd_lap_rows<TR, POLE>(Dk, L2, Dp, lane, rho0, g0, sA, sP, sQ, C);
+    qd_lap_rows<TR, POLE>(Bk, Dk, Bp, lane, rho0, g0, LT, C);
+    qd_lap_rows<TR, POLE>(Dk, L2, Dp, lane, rho0, g0, LT, C);
     const bool col_ok = lane >= 3 && lane <= 60 && jraw < G.nlon;
     double* op = out + (size_t)qd_lrow(G, g0) * G.nlon + jraw;
 #pragma unroll
@@ -569,12 +580,10 @@ __device__ __forceinline__ bool qd_dyn_fast(const QdGeom& G, const QdTabs& T, co
         ah[k] = P.h[o]; ru[k] = P.u[o]; rv[k] = P.v[o]; rf[k] = P.fric[o];
     }
     // ---- row tables through the scalar cache
-    double sA[K + 2], sP[K], sQ[K], c8[K], c9[K];
-#pragma unroll
-    for (int k = 0; k < K + 2; ++k) sA[k] = qd_sload(T.lapA[0], POLE ? qd_clampi(g0 - 1 + k, 0, n - 1) : g0 - 1 + k);
+    const QdLapTabs LT{T.lapA[0], T.lapP[0], T.lapQ[0]};
+    double c8[K], c9[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        sP[k] = qd_sload(T.lapP[0], g0 + k); sQ[k] = qd_sload(T.lapQ[0], g0 + k);
         c8[k] = qd_sload(P.primitive ? T.mom_px : T.mom_cu, g0 + k);
         c9[k] = qd_sload(P.primitive ? T.fcor : T.mom_cv, g0 + k);
     }
@@ -622,7 +631,7 @@ __device__ __forceinline__ bool qd_dyn_fast(const QdGeom& G, const QdTabs& T, co
     const QdPoleC C{n, T.lapPoleA[0]};
 #define QD_FIELD(ARR, OUT, FI)                                                                              \
     if (P.skip[FI]) qd_store_fast<TR>(ARR, OUT, G, t, jraw, lane, rho0);                                    \
-    else qd_del4_fast<TR, POLE>(ARR, Bp, Dp, OUT, G, t, jraw, lane, rho0, sA, sP, sQ, P.k4row[FI], P.k4s[FI], P.dt, C, bad);
+    else qd_del4_fast<TR, POLE>(ARR, Bp, Dp, OUT, G, t, jraw, lane, rho0, LT, P.k4row[FI], P.k4s[FI], P.dt, C, bad);
     QD_FIELD(ru, P.uo, 0)
 #pragma unroll
     for (int k = 0; k < K; ++k) rq[k] = P.q[o0 + (unsigned)k * (unsigned)mlon];
@@ -662,12 +671,10 @@ __device__ __forceinline__ bool qd_ocn_fast(const QdGeom& G, const QdTabs& T, co
 #pragma unroll
         for (int k = 0; k < K; ++k) { const double e = ae[k] - em; bad |= qd_nonfinite(e); ae[k] = fmin(fmax(e, -cap), cap); }
     }
-    double sA[K + 2], sP[K], sQ[K], sF[K], sI[K], sX[K];
-#pragma unroll
-    for (int k = 0; k < K + 2; ++k) sA[k] = qd_sload(T.lapA[1], POLE ? qd_clampi(g0 - 1 + k, 0, n - 1) : g0 - 1 + k);
+    const QdLapTabs LT{T.lapA[1], T.lapP[1], T.lapQ[1]};
+    double sF[K], sI[K], sX[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        sP[k] = qd_sload(T.lapP[1], g0 + k); sQ[k] = qd_sload(T.lapQ[1], g0 + k);
         sF[k] = qd_sload(T.fcor, g0 + k); sI[k] = qd_sload(T.ocn_igx, g0 + k); sX[k] = qd_sload(T.r_extra, g0 + k);
     }
     Ap[rho0 * S + lane] = ae[0];
@@ -706,7 +713,7 @@ __device__ __forceinline__ bool qd_ocn_fast(const QdGeom& G, const QdTabs& T, co
     const QdPoleC C{n, T.lapPoleA[1]};
 #define QD_FIELD(ARR, OUT, FI)                                                                              \
     if (P.skip[FI]) qd_store_fast<TR>(ARR, OUT, G, t, jraw, lane, rho0);                                    \
-    else qd_del4_fast<TR, POLE>(ARR, Bp, Dp, OUT, G, t, jraw, lane, rho0, sA, sP, sQ, P.k4row[FI], P.k4s[FI], P.sub_dt, C, bad);
+    else qd_del4_fast<TR, POLE>(ARR, Bp, Dp, OUT, G, t, jraw, lane, rho0, LT, P.k4row[FI], P.k4s[FI], P.sub_dt, C, bad);
     QD_FIELD(ru, P.uo_out, 0)
     QD_FIELD(rv, P.vo_out, 1)
     QD_FIELD(ae, P.eta_out, 2)
