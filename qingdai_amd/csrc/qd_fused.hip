@@ -420,17 +420,17 @@ __device__ __forceinline__ void qd_ocn_exact(const QdGeom& G, const QdTabs& T, c
 typedef const double __attribute__((address_space(4)))* qd_cptr;
 __device__ __forceinline__ double qd_sload(const double* p, int idx) { return ((qd_cptr)(unsigned long long)p)[idx]; }
 __device__ __forceinline__ bool qd_nonfinite(double x) { return __builtin_amdgcn_class(x, 0x207); }   // sNaN|qNaN|-inf|+inf
-// value held by lane+1 / lane-1 (the edge lanes keep their own value: they are halo columns)
+// value held by lane+1 / lane-1.  bound_ctrl:1 (the lane without a neighbour reads 0) lets the move stand alone: with
+// bound_ctrl:0 the destination must first be initialised with the old value, one extra v_mov per DPP move.  Lanes 0 and
+// 63 are halo columns whose results never reach an owned cell.
 __device__ __forceinline__ double qd_east(double x) {
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);     // wave_shl:1
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x130, 0xf, 0xf, true);     // wave_shl:1
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x130, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double qd_west(double x) {
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);     // wave_shr:1
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x138, 0xf, 0xf, true);     // wave_shr:1
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x138, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 
@@ -513,7 +513,8 @@ __device__ __forceinline__ void qd_lap_rows(const double (&X)[QdFast<TR>::K], do
         }
         const double Gb = Ab * (bhi - blo);
         const double Ga = Aa * (ahi - alo);
-        const double d2 = (qd_east(c) - 2.0 * c) + qd_west(c);
+        // e - 2c in one fma: 2c is exact, so fma(-2, c, e) rounds exactly like (e - 2.0 * c) -- same bits, one instruction less
+        const double d2 = __builtin_fma(-2.0, c, qd_east(c)) + qd_west(c);
         L[k] = sP[k] * (Gb - Ga) + sQ[k] * d2;
     }
 }
