@@ -380,7 +380,7 @@ int qd_median_positive_dev(qd_ctx* c, const double* x, double dflt, int slot, in
     // digits from the top: bits 63..53, 52..42, 41..31, 30..20 (11 wide), 19..10, 9..0 (10 wide)
     const int shifts[6] = {53, 42, 31, 20, 10, 0};
     const int widths[6] = {11, 11, 11, 11, 10, 10};
-    const int nblk = 128;         // few, fat workgroups (measured: 64..256 within 10 %; thousands of tiny ones 2x slower)
+    const int nblk = 256;         // few, fat workgroups (ms/step at 721x1440 with 64/128/256/512/721: 1.371/1.324/1.307/1.323/1.345)
     dim3 grid(1, std::min(G.nrows, nblk));
     if (c->geo.full && c->sel_cand) {
         // two histogram passes, one collecting pass, one finishing workgroup
