@@ -535,13 +535,24 @@ __device__ __forceinline__ void qd_del4_fast(const double (&Bk)[QdFast<TR>::K], 
     qd_lap_rows<TR, POLE>(Dk, L2, Dp, lane, rho0, g0, LT, C);
     const bool col_ok = lane >= 3 && lane <= 60 && jraw < G.nlon;
     double* op = out + (size_t)qd_lrow(G, g0) * G.nlon + jraw;
+    double val[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const double val = Bk[k] - (sK[k] * L2[k]) * dt;
-        const int g = g0 + k;
-        if (g >= t.o0 && g < t.o1) {                          // wave-uniform
-            bad |= qd_nonfinite(val);
-            if (col_ok) op[(size_t)k * G.nlon] = val;
+    for (int k = 0; k < K; ++k) val[k] = Bk[k] - (sK[k] * L2[k]) * dt;
+    if (g0 >= t.o0 && g0 + K <= t.o1) {                       // wave-uniform: every row of this wave is owned (6 of the 8 waves)
+#pragma unroll
+        for (int k = 0; k < K; ++k) bad |= qd_nonfinite(val[k]);
+        if (col_ok) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) op[(size_t)k * G.nlon] = val[k];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int g = g0 + k;
+            if (g >= t.o0 && g < t.o1) {
+                bad |= qd_nonfinite(val[k]);
+                if (col_ok) op[(size_t)k * G.nlon] = val[k];
+            }
         }
     }
 }
