@@ -192,6 +192,11 @@ def main():
         out["roofline_ocean_substep"] = {"bound": "hbm", "kernel": also, "achieved": a2, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                          "frac": a2 / HBM_PEAK_GBS, "traffic": None, "bytes_per_cell": BYTES_PER_CELL[also],
                                          "cells": cells, "avg_kernel_ms": also_ms, "launches": also_n}
+    if rank == 0 and args.gpus == 1:      # measured streaming ceiling next to the 8 TB/s spec peak (outside the timed region)
+        try:
+            out["roofline"]["measured_copy_ceiling_gbs"] = dev.copy_ceiling()
+        except Exception:
+            pass
     # HBM-side traffic per launch: PMC counters cannot be collected from inside this process; the committed summary of
     # the separate rocprofv3 --pmc passes of this same command (profiles/, corrected as MI355X_MICROARCH.md prescribes)
     # is reported when it covers this kernel and grid, else null

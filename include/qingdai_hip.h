@@ -199,6 +199,9 @@ int qd_comm_allreduce_max(qd_handle h, double* inout, int n);     /* bench timin
 /* ---- profiling hooks ----------------------------------------------------------------- */
 /* mean device time (ms) of the kernels tagged `name` since the last reset, measured with
  * hipEvents on the handle's stream when timing is enabled. */
+/* measured streaming ceiling of the device ("also report a measured device-copy ceiling"): a device-to-device copy of
+ * `bytes` (choose > 256 MiB to get past the Infinity Cache), `reps` times; *gbs = (read + written bytes) / time. */
+int qd_copy_ceiling(qd_handle h, size_t bytes, int reps, double* gbs);
 int qd_timing_enable(qd_handle h, int on);           /* 0 off, 1 every kernel group */
 int qd_timing_select(qd_handle h, const char* name); /* time only the group `name` (implies on) */
 int qd_timing_get(qd_handle h, const char* name, double* mean_ms, int64_t* launches);

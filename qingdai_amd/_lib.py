@@ -33,7 +33,7 @@ SYMBOLS = [
     "qd_op_laplacian", "qd_op_hyperdiffuse", "qd_op_advect", "qd_op_shapiro", "qd_op_zonal_filter", "qd_op_divergence",
     "qd_op_vorticity", "qd_op_gaussian", "qd_op_median_positive", "qd_reduce", "qd_energy_diagnostics", "qd_energy_diagnostics_last", "qd_band_insolation",
     "qd_comm_unique_id", "qd_comm_init", "qd_comm_init_local", "qd_comm_stats", "qd_comm_barrier", "qd_comm_allreduce_max",
-    "qd_timing_enable", "qd_timing_select", "qd_timing_get", "qd_timing_reset",
+    "qd_copy_ceiling", "qd_timing_enable", "qd_timing_select", "qd_timing_get", "qd_timing_reset",
 ]
 
 
@@ -91,6 +91,7 @@ def load():
     lib.qd_reduce.argtypes = [vp, i32, i32, dp]
     lib.qd_energy_diagnostics.argtypes = [vp, dp]
     lib.qd_energy_diagnostics_last.argtypes = [vp, dp]
+    lib.qd_copy_ceiling.argtypes = [vp, sz, i32, dp]
     lib.qd_band_insolation.argtypes = [vp, i32, dp, dp, dp, vp]
     lib.qd_comm_unique_id.argtypes = [vp, sz]
     lib.qd_comm_init.argtypes = [vp, vp, sz]

@@ -617,6 +617,27 @@ extern "C" int qd_energy_diagnostics(qd_handle c, double* out) {
     return qd_energy_diag_impl(c, out);
 }
 
+extern "C" int qd_copy_ceiling(qd_handle c, size_t bytes, int reps, double* gbs) {
+    if (!c || !gbs || bytes == 0 || reps < 1) return -1;
+    hipSetDevice(c->desc.device);
+    void *a = nullptr, *b = nullptr;
+    if (hipMalloc(&a, bytes) != hipSuccess || hipMalloc(&b, bytes) != hipSuccess) { if (a) hipFree(a); return qd_fail(c, "qd_copy_ceiling: hipMalloc"); }
+    hipMemsetAsync(a, 1, bytes, c->stream); hipMemsetAsync(b, 2, bytes, c->stream);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, c->stream);            // warm-up
+    hipEventRecord(e0, c->stream);
+    for (int r = 0; r < reps; ++r) hipMemcpyAsync((r & 1) ? a : b, (r & 1) ? b : a, bytes, hipMemcpyDeviceToDevice, c->stream);
+    hipEventRecord(e1, c->stream);
+    hipStreamSynchronize(c->stream);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(a); hipFree(b);
+    *gbs = ms > 0.f ? (2.0 * (double)bytes * reps / 1e9) / ((double)ms / 1e3) : 0.0;
+    return 0;
+}
+
 // ------------------------------------------------------------------ timing
 extern "C" int qd_timing_enable(qd_handle c, int on) { if (!c) return -1; c->timing = on ? 1 : 0; return 0; }
 extern "C" int qd_timing_select(qd_handle c, const char* name) {

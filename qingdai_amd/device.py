@@ -222,6 +222,12 @@ class Device:
         self._chk(self.lib.qd_energy_diagnostics(self.h, out), "qd_energy_diagnostics")
         return dict(zip(self.ENERGY_DIAG_KEYS, [float(x) for x in out]))
 
+    def copy_ceiling(self, nbytes=1 << 30, reps=8):
+        """Measured device-to-device streaming rate in GB/s (read + written bytes), past the Infinity Cache by default."""
+        out = ctypes.c_double(0.0)
+        self._chk(self.lib.qd_copy_ceiling(self.h, int(nbytes), int(reps), ctypes.byref(out)), "qd_copy_ceiling")
+        return out.value
+
     def energy_diagnostics_last(self):
         """The means taken inside the last step_n(..., energy_diag=True): first step, after time_step, before the ocean."""
         out = (ctypes.c_double * 10)()
