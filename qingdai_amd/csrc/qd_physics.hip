@@ -133,14 +133,6 @@ k_cloud_from_p(QdGeom G, const double* __restrict__ precip, const double* __rest
     out[o] = cmax * tanh(precip[o] / (*pref + 1e-12));
 }
 
-__global__ void __launch_bounds__(QD_BLOCK)
-k_clip01(QdGeom G, double* __restrict__ x) {
-    const QdTile tl = qd_tile();
-    const int j = tl.seg * QD_BLOCK + threadIdx.x;
-    if (j >= G.nlon) return;
-    const size_t o = (size_t)qd_lrow(G, G.row0 + tl.row) * G.nlon + j;
-    x[o] = qd_clip(x[o], 0.0, 1.0);
-}
 
 // physics.py:72-109 before the blur
 __global__ void __launch_bounds__(QD_BLOCK)
