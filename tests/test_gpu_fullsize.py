@@ -1,0 +1,99 @@
+"""GPU (-m gpu): BASELINE's full size (721 x 1440) through size-independent properties -- the oracle needs ~2 s per
+step there, so nothing here steps it.  Operators: exact constants, linearity, projection property of the zonal
+filter, exact medians against numpy; the fused kernels' two code paths bit for bit at the tile shape the benchmark
+really uses (TR = 38: interior tiles AND shifted-plane pole tiles); 8 latitude bands against the whole globe."""
+import numpy as np
+import pytest
+
+from util import relerr
+from test_gpu_bands import _run
+
+pytestmark = pytest.mark.gpu
+NLAT, NLON = 721, 1440
+
+
+@pytest.fixture(scope="module")
+def ops(gpu):
+    import qingdai_amd as qa
+    return qa.SphericalGrid(NLAT, NLON)._ops()
+
+
+def _fields(seed):
+    r = np.random.default_rng(seed)
+    lat = np.linspace(-np.pi / 2, np.pi / 2, NLAT)[:, None]
+    lon = np.linspace(0, 2 * np.pi, NLON)[None, :]
+    F = 8000.0 + 300.0 * np.sin(lat) ** 2 + 40.0 * np.cos(lat) * np.cos(3 * lon) + r.normal(0, 2.0, (NLAT, NLON))
+    Gf = 280.0 + 30.0 * np.cos(lat) ** 2 + r.normal(0, 1.0, (NLAT, NLON))
+    u = 25.0 * np.cos(lat) * np.sin(2 * lon) + r.normal(0, 3.0, (NLAT, NLON))
+    v = 8.0 * np.sin(2 * lat) * np.cos(3 * lon) + r.normal(0, 2.0, (NLAT, NLON))
+    return F, Gf, u, v
+
+
+def test_constants_are_fixed_points(ops):
+    c = np.full((NLAT, NLON), 273.15)
+    _, _, u, v = _fields(1)
+    assert np.all(ops.op_laplacian(c) == 0.0) and np.all(ops.op_laplacian(c, ocean=True) == 0.0)
+    assert np.array_equal(ops.op_hyperdiffuse(c, 1.0e14, 300.0, 2), c)
+    assert np.array_equal(ops.op_shapiro(c, 2), c)
+    assert relerr(ops.op_advect(c, u, v, 300.0), c) < 1e-15            # bilinear weights sum to 1 up to rounding
+    assert relerr(ops.op_gaussian(c, 1.0), c) < 1e-15
+    assert relerr(ops.op_zonal_filter(c, 0.75, 0.5), c) < 1e-13         # direct DFT of 1440 terms: ~n eps of the row maximum
+    assert np.all(ops.op_divvort(np.zeros_like(c), np.zeros_like(c)) == 0.0)
+
+
+def test_operators_are_linear(ops):
+    F, Gf, u, v = _fields(2)
+    a, b = 0.75, -1.25
+    for name, op in (("lap", lambda X: ops.op_laplacian(X)), ("lap_ocn", lambda X: ops.op_laplacian(X, ocean=True)),
+                     ("shapiro", lambda X: ops.op_shapiro(X, 2)), ("gauss", lambda X: ops.op_gaussian(X, 1.0)),
+                     ("advect", lambda X: ops.op_advect(X, u, v, 300.0)), ("zonal", lambda X: ops.op_zonal_filter(X, 0.75, 0.5)),
+                     ("hyper", lambda X: ops.op_hyperdiffuse(X, 1.0e14, 300.0, 1))):
+        lhs = op(a * F + b * Gf)
+        rhs = a * op(F) + b * op(Gf)
+        assert relerr(lhs, rhs) < 2e-12, name
+    d = ops.op_divvort(a * u + b * v, a * v - b * u) - (a * ops.op_divvort(u, v) + b * ops.op_divvort(v, -u))
+    assert np.max(np.abs(d)) < 1e-12 * np.max(np.abs(ops.op_divvort(u, v)))
+
+
+def test_zonal_filter_is_a_projection_and_keeps_zonal_means(ops):
+    F, _, _, _ = _fields(3)
+    once = ops.op_zonal_filter(F, 0.6, 1.0)                            # damp = 1: the high bins are removed entirely
+    twice = ops.op_zonal_filter(once, 0.6, 1.0)
+    assert relerr(twice, once) < 1e-13
+    assert np.max(np.abs(once.mean(axis=1) - F.mean(axis=1))) < 1e-12 * np.abs(F).max()
+    spec = np.abs(np.fft.rfft(once, axis=1))
+    kcut = int(0.6 * (NLON // 2))
+    assert spec[:, kcut:].max() < 1e-9 * spec[:, 0].max()              # nothing left above the cutoff
+
+
+def test_median_exact_at_full_size(ops):
+    r = np.random.default_rng(4)
+    x = np.exp(r.normal(-11, 2.5, (NLAT, NLON))) * (r.random((NLAT, NLON)) < 0.7)
+    x[r.random(x.shape) < 0.02] *= -1.0
+    assert ops.op_median_positive(x, 1e-6) == float(np.median(x[x > 0]))
+    x = np.round(x, 6)                                                  # heavy ties
+    assert ops.op_median_positive(x, 1e-6) == float(np.median(x[x > 0]))
+
+
+def test_fused_paths_agree_at_benchmark_tile_shape(gpu, monkeypatch):
+    over = dict(energy_w=1.0)
+    monkeypatch.setenv("QD_FUSED_FAST", "0")
+    exact, _ = _run(1, NLAT, NLON, 2, over, True, True)
+    monkeypatch.setenv("QD_FUSED_FAST", "1")
+    fast, _ = _run(1, NLAT, NLON, 2, over, True, True)
+    for k in exact:
+        assert np.array_equal(fast[k], exact[k]), (k, relerr(fast[k], exact[k]))
+    monkeypatch.setenv("QD_FUSED", "0")
+    unfused, _ = _run(1, NLAT, NLON, 2, over, True, True)
+    for k in fast:
+        assert relerr(fast[k], unfused[k]) < (1e-7 if k in ("UO", "VO", "ETA") else 1e-9), k
+
+
+def test_eight_bands_match_the_whole_globe(gpu):
+    ref, _ = _run(1, NLAT, NLON, 2, dict(energy_w=1.0), True, True)
+    got, ex = _run(8, NLAT, NLON, 2, dict(energy_w=1.0), True, True)
+    print("halo exchanges per band:", ex)
+    for k in ("U", "V", "H", "TS", "Q", "CLOUD"):
+        assert np.array_equal(got[k], ref[k]), (k, relerr(got[k], ref[k]))
+    for k in ("UO", "VO", "ETA", "SST"):
+        assert relerr(got[k], ref[k]) < 1e-13, k                       # band-wise order of the eta sum
