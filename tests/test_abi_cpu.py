@@ -76,8 +76,8 @@ def test_env_parsing(monkeypatch):
 
 def test_no_gpu_fails_loudly():
     """Without a GPU the product must raise, never fall back."""
-    from tests_gpu_visible import gpu_visible
-    if gpu_visible():
+    from conftest import _gpu_visible
+    if _gpu_visible():
         pytest.skip("GPU present")
     import qingdai_amd as qa
     from qingdai_amd._lib import QdError
