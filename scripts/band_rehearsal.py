@@ -1,5 +1,6 @@
 import sys, time
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests'); sys.path.insert(0,'/root/repo/oracle')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import qingdai_amd as qa
 from qingdai_amd.bands import BandGroup, required_halo

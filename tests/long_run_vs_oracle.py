@@ -1,5 +1,8 @@
+"""TEST TOOL (not collected by pytest): how long the device loop and the oracle stay together on the coupled configuration.
+   python tests/long_run_vs_oracle.py 91 180 240   (GPU box)"""
 import sys, time
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests'); sys.path.insert(0,'/root/repo/oracle')
+ROOT = __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))
+for _p in (ROOT, ROOT + '/tests', ROOT + '/oracle'): sys.path.insert(0, _p)
 import numpy as np
 import qd_oracle as qo
 from qd_oracle.driver import DriverOracle
