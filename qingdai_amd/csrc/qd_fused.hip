@@ -10,24 +10,21 @@
 // (40 B) = 88 B/cell instead of the 22 field passes of the unfused sequence;
 // k_ocn_hyper: read uo,vo,eta,tau_x,tau_y (+mask) and write uo,vo,eta = 65 B/cell.
 //
-// Design (MI355X / CDNA4):
-//   * One 512-thread workgroup = 8 wavefronts owns a TR x 58 tile.  A wavefront IS a 64-column row
-//     segment: lane l always works on global column j0-3+l, in every plane and every phase, so every
-//     global access is one coalesced 512-byte row segment and every LDS access is conflict-free
-//     (64 consecutive 8-byte words).  Wave w handles plane rows w, w+8, w+16, ...
-//   * Each Laplacian is a 5-row x 3-column star (its latitude part gradient(cos*gradient(F)) only
-//     touches rows r-2, r, r+2), so del^4 needs F on (TR+8) x 62 and the momentum update that
-//     produces F needs h on (TR+10) x 64.  Halo cells are recomputed, never exchanged.
-//   * ALL global loads of a tile (the h plane and the thread's own u, v, friction, q, cloud cells)
-//     are issued back-to-back at kernel entry into registers: one exposed memory latency per tile.
-//     After that the kernel only touches LDS: three planes  A (h), B (field entering del^4),
-//     D (its Laplacian), re-used field after field (u', v', h, q, cloud).
-//   * Divisions by per-row / constant metrics are folded into host-computed reciprocal tables
-//     (lapA/lapP/lapQ, mom_cu/cv/px) for interior rows; the two rows next to each pole keep the
-//     reference's literal one-sided np.gradient expressions.
-//   * TR is a template parameter (fully unrolled cell loops, register-resident prefetch); the host
-//     picks the instantiation whose tile count fills 256 CUs x resident workgroups in the fewest
-//     rounds.  Tiles are dealt to the 8 XCDs in contiguous chunks so halo re-reads hit one L2.
+// Design (MI355X / CDNA4), details at the FAST / EXACT sections below and in DESIGN.md section 4:
+//   * One 512-thread workgroup = 8 wavefronts owns a TR x 58 tile (RA = TR+10 plane rows x 64 columns).  A wavefront IS a
+//     64-column row segment: lane l always works on global column j0-3+l, so every global access is one coalesced 512-byte
+//     row segment.  Each Laplacian is a 5-row x 3-column star (its latitude part gradient(cos*gradient(F)) only touches rows
+//     r-2, r, r+2), so del^4 needs F on (TR+8) x 62 and the momentum update that produces F needs h on (TR+10) x 64.  Halo
+//     cells are recomputed, never exchanged.
+//   * FAST path (every tile of a >= 64-column grid): wave w owns K = RA/8 consecutive plane rows and keeps its cells of every
+//     plane in registers; row neighbours across a wave boundary go through LDS (4 rows per pass), column neighbours through
+//     DPP wave shifts, per-row coefficients through scalar loads; no nan_to_num (one v_cmp_class per output, EXACT fallback).
+//   * EXACT path (narrow grids, short row segments, non-finite values): three LDS planes A (h), B (field entering del^4),
+//     D (its Laplacian), LDS-staged row tables, every cell masked, literal nan_to_num / np.clip.  Bit-identical to FAST.
+//   * Divisions by per-row / constant metrics are folded into host-computed reciprocal tables (lapA/lapP/lapQ, lapPoleA for the
+//     four one-sided np.gradient rows next to the poles, mom_cu/cv/px, ocn_igx).
+//   * TR is a template parameter; the host picks the instantiation whose tile count fills 256 CUs x 2 resident workgroups in
+//     one round (TR = 38 at 721 x 1440).  Tiles are dealt to the 8 XCDs in contiguous chunks, pole tiles first.
 #include "qd_internal.h"
 #include "qd_device.h"
 #include "qd_fused.h"
