@@ -33,13 +33,15 @@ def _seed_state(nlat, nlon, seed):
     return st
 
 
-def _run(world, nlat, nlon, nsteps, over, with_ocean, with_phys, seed=3):
+def _run(world, nlat, nlon, nsteps, over, with_ocean, with_phys, seed=3, mutate=None):
     from qingdai_amd.bands import BandGroup
     from qingdai_amd.device import Device
     qa, grid, mask, alb, fric, p = _setup(nlat, nlon, over)
     forcing = qa.ThermalForcing(qa.SphericalGrid(nlat, nlon), qa.OrbitalSystem())
     stars = forcing.star_table([i * 300.0 for i in range(nsteps)])
     st = _seed_state(nlat, nlon, seed)
+    if mutate is not None:
+        mutate(st)
     static = {"LAND_MASK": mask, "FRICTION": fric, "BASE_ALBEDO": alb}
     names = ["U", "V", "H", "TS", "Q", "CLOUD", "HICE"] + (["UO", "VO", "ETA", "SST"] if with_ocean else [])
     if world == 1:
@@ -98,3 +100,41 @@ def test_fused_kernel_paths_agree(gpu, shape, monkeypatch):
     print(errs)
     for k, e in errs.items():
         assert e < (1e-7 if k in ("UO", "VO", "ETA") else 1e-9), (k, e)
+
+
+def test_nonfinite_values_fall_back_to_the_exact_path(gpu, monkeypatch):
+    """The FAST path of the fused kernels omits nan_to_num and instead detects non-finite values (one v_cmp_class per
+    owned output / clip input); a workgroup that sees one recomputes its tile on the EXACT path.  Poison interior, pole and
+    ocean cells with NaN / +-inf: the result must equal the EXACT-only run bit for bit (NaN-aware) and the unfused
+    reference-order kernels (the reference's nan_to_num placement) to rounding."""
+    nlat, nlon = 181, 360
+
+    def poison(st):
+        st["U"][90, 100] = np.nan
+        st["V"][37, 11] = np.inf
+        st["Q"][120, 359] = -np.inf
+        st["CLOUD"][1, 5] = np.nan            # next to the south pole
+        st["H"][179, 200] = np.inf            # next to the north pole
+        st["H"][60, 0] = np.nan               # on the longitude seam
+        st["UO"] = np.zeros((nlat, nlon)); st["UO"][100, 200] = np.nan           # ocean fused kernel
+        st["ETA"] = np.zeros((nlat, nlon)); st["ETA"][50, 300] = np.inf; st["ETA"][0, 7] = np.nan
+    over = dict(energy_w=1.0, ocean_cfl=0.05)
+    monkeypatch.setenv("QD_FUSED_FAST", "0")
+    exact, _ = _run(1, nlat, nlon, 2, over, True, False, mutate=poison)
+    monkeypatch.setenv("QD_FUSED_FAST", "1")
+    fast, _ = _run(1, nlat, nlon, 2, over, True, False, mutate=poison)
+    monkeypatch.setenv("QD_FUSED", "0")
+    unfused, _ = _run(1, nlat, nlon, 2, over, True, False, mutate=poison)
+    for k in exact:
+        assert np.array_equal(fast[k], exact[k], equal_nan=True), k
+        assert np.array_equal(np.isfinite(fast[k]), np.isfinite(unfused[k])), k
+        # nan_to_num turns an infinity into +-1.8e308; within reach of such a cell (two steps of a 4-cell stencil + gather)
+        # everything saturates and the sign of an overflowed intermediate decides between the two clamps -- the reciprocal-table
+        # and literal-division forms need not agree there.  Away from the poisoned neighbourhoods they must.
+        far = np.ones((nlat, nlon), dtype=bool)
+        for (pi, pj) in ((90, 100), (37, 11), (120, 359), (1, 5), (179, 200), (60, 0), (100, 200), (50, 300), (0, 7)):
+            ii = np.arange(max(0, pi - 14), min(nlat, pi + 15))
+            jj = np.arange(pj - 14, pj + 15) % nlon
+            far[np.ix_(ii, jj)] = False
+        bad = ~np.isclose(fast[k], unfused[k], rtol=1e-7, atol=0.0, equal_nan=True) & far
+        assert not bad.any(), (k, np.argwhere(bad)[:5], fast[k][bad][:5], unfused[k][bad][:5])
