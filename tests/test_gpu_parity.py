@@ -187,6 +187,29 @@ def test_config1_240_steps_181x360_hyper4(gpu):
         assert e < STEP_TOL, (k, e)
 
 
+def test_time_step_scrubs_nonfinite_like_the_reference(gpu):
+    """The reference survives NaN / inf in its state through np.nan_to_num at fixed places of time_step
+    (dynamics.py:144-212, 594-667).  Poison a fixture's initial state and compare the device step with the oracle (which
+    restates those placements): identical non-finite handling everywhere -- all outputs finite -- and agreement away from
+    the saturated neighbourhoods of the poisoned cells."""
+    meta, d0 = load_golden("ts_37x72_perturbed_noalb")
+    d = {k: np.array(v, copy=True) for k, v in d0.items()}
+    d["init_u"][20, 30] = np.nan
+    d["init_q"][5, 60] = np.inf
+    d["init_cloud_cover"][30, 2] = np.nan
+    meta = dict(meta, nsteps=2)
+    with np.errstate(all="ignore"):
+        want = run_oracle_time_step(meta, d)
+    got = run_device_time_step(meta, d)
+    far = np.ones((37, 72), dtype=bool)
+    for (pi, pj) in ((20, 30), (5, 60), (30, 2)):
+        far[np.ix_(np.arange(max(0, pi - 12), min(37, pi + 13)), np.arange(pj - 12, pj + 13) % 72)] = False
+    for k in STATE:
+        a, b = getattr(got, k), getattr(want, k)
+        assert np.all(np.isfinite(a)) and np.all(np.isfinite(b)), k
+        assert np.allclose(a[far], b[far], rtol=1e-9, atol=1e-9 * np.abs(b[far]).max()), k
+
+
 def test_time_step_host_arrays_path(gpu):
     """The reference's calling shape: Teq / albedo / isr handed over as NumPy arrays."""
     meta, d = load_golden("ts_19x36_default_alb")
