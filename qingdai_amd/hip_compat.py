@@ -77,8 +77,8 @@ def laplacian_sphere(F, dlat, dlon, coslat, a):
 
 def hyperdiffuse(F, k4, dt, n_substeps, dlat, dlon, coslat, a):
     F = np.asarray(F, dtype=np.float64)
-    if float(dt) <= 0.0 or np.all(np.asarray(k4) <= 0.0):          # the reference's early-outs (dynamics.py:188-194)
-        return np.nan_to_num(F)
+    if float(dt) <= 0.0 or np.all(np.nan_to_num(np.asarray(k4, dtype=np.float64)) <= 0.0):
+        return to_numpy(F)                  # the reference's early-outs hand F back untouched (dynamics.py:190-202)
     dev = _ops(F.shape, a)
     _check_grid(dev, F.shape, dlat, dlon, a)
     ocean = _kind(coslat, ((0.2, "atm"), (0.5, "ocn"))) == "ocn"

@@ -75,7 +75,9 @@ def test_hip_compat_seam_matches_reference(gpu, shape):
     for k, val in got.items():
         assert isinstance(val, np.ndarray) and val.flags.writeable
         assert relerr(val, d["ref_" + k]) < OP_TOL, k
-    assert np.array_equal(hc.hyperdiffuse(Fh, 0.0, dt, 1, g.dlat_rad, g.dlon_rad, c02, a), np.nan_to_num(Fh))   # k4 <= 0 early-out
+    Fn = Fh.copy(); Fn[3, 4] = np.nan
+    assert np.array_equal(hc.hyperdiffuse(Fn, 0.0, dt, 1, g.dlat_rad, g.dlon_rad, c02, a), Fn, equal_nan=True)   # k4 <= 0: F untouched
+    assert np.array_equal(hc.hyperdiffuse(Fn, 1e14, 0.0, 1, g.dlat_rad, g.dlon_rad, c02, a), Fn, equal_nan=True)  # dt <= 0: F untouched
     with pytest.raises(ValueError):
         hc.laplacian_sphere(Fh, g.dlat_rad, g.dlon_rad, np.maximum(cos, 0.3), a)      # unknown floor: refuse, never guess
     with pytest.raises(ValueError):
