@@ -122,6 +122,38 @@ def test_spectral_band_insolation_vs_reference(gpu, monkeypatch):
     dev.close()
 
 
+def test_operators_nonfinite_inputs_vs_oracle(gpu):
+    """Where the reference scrubs (np.nan_to_num at the entry of _laplacian_sphere / _hyperdiffuse and on their results) and
+    where it does not (Shapiro, divergence, the bilinear gather propagate NaN): device operators against the oracle's
+    restatement on a poisoned field, NaN-aware."""
+    import qingdai_amd as qa
+    import qd_oracle as qo
+    from qd_oracle import atmos as oat, numerics as onx
+    meta, d = load_golden("ops_37x72")
+    g = qa.SphericalGrid(37, 72)
+    og = qo.Grid(37, 72)
+    dev = g._ops()
+    F = d["F"].copy(); F[10, 20] = np.nan; F[30, 71] = np.inf; F[0, 3] = -np.inf
+    a = qa.QdParams().a
+    cos = np.cos(np.deg2rad(og.lat_mesh))
+    c02, c05 = np.maximum(cos, 0.2), np.maximum(cos, 0.5)
+    with np.errstate(all="ignore"):
+        want = {"lap_atm": oat.laplacian_sphere(F, og.dlat_rad, og.dlon_rad, c02, a),
+                "lap_ocn": oat.laplacian_sphere(F, og.dlat_rad, og.dlon_rad, c05, a),
+                "hyper": oat.hyperdiffuse(F, d["k4"], meta["dt"], 1, og.dlat_rad, og.dlon_rad, c02, a),
+                "shapiro": onx.shapiro(F, 2)}
+    got = {"lap_atm": dev.op_laplacian(F), "lap_ocn": dev.op_laplacian(F, ocean=True),
+           "hyper": dev.op_hyperdiffuse(F, d["k4"], meta["dt"], 1), "shapiro": dev.op_shapiro(F, 2)}
+    for k in want:
+        assert np.array_equal(np.isnan(got[k]), np.isnan(want[k])), k
+        assert np.array_equal(np.isinf(got[k]), np.isinf(want[k])), k
+        fin = np.isfinite(want[k])
+        big = np.abs(want[k]) > 1e290                      # products with 1.8e308 sit at the edge of the range: sign only
+        assert np.array_equal(np.sign(got[k][fin & big]), np.sign(want[k][fin & big])), k
+        sel = fin & ~big
+        assert np.allclose(got[k][sel], want[k][sel], rtol=1e-12, atol=1e-13 * np.abs(want[k][sel]).max()), k
+
+
 def test_median_exact(gpu):
     import qingdai_amd as qa
     grid = qa.SphericalGrid(37, 72)
