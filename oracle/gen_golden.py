@@ -463,6 +463,51 @@ def case_spectral_bands(nlat, nlon):
     save(f"spectral_{nlat}x{nlon}", dict(kind="spectral", nlat=nlat, nlon=nlon, times=[0.0, 4.1e6]), **out)
 
 
+def case_nonfinite(nlat, nlon, seed):
+    """Where the reference scrubs non-finite values and where it lets them through: its own _laplacian_sphere (atmosphere and
+    ocean), _hyperdiffuse, _shapiro_filter and a whole time_step on a state poisoned with NaN / +-inf."""
+    from pygcm.ocean import WindDrivenSlabOcean
+    g, mask, alb, fric = surface(nlat, nlon)
+    st = perturbed_state((nlat, nlon), seed, cloudy=True)
+    F = st["h"].copy()
+    F[nlat // 2, 7] = np.nan; F[nlat - 2, nlon - 1] = np.inf; F[0, 3] = -np.inf
+    dt = 300.0
+    with ref_env({}), np.errstate(all="ignore"):
+        m = build_ref_model(g, mask, fric, st)
+        oc = WindDrivenSlabOcean(g, mask, 50.0)
+        cos3 = np.maximum(np.cos(np.deg2rad(g.lat_mesh)), 1e-3)
+        k4 = 0.02 * np.minimum(m.a * m.dlat_rad, m.a * m.dlon_rad * cos3) ** 4 / dt
+        ref = dict(lap_atm=m._laplacian_sphere(F.copy()), lap_ocn=oc._laplacian_sphere(F.copy()),
+                   hyper_atm=m._hyperdiffuse(F.copy(), k4, dt, n_substeps=1), shapiro2=m._shapiro_filter(F.copy(), n=2))
+        st2 = {k: v.copy() for k, v in st.items()}
+        st2["u"][nlat // 3, 11] = np.nan
+        st2["q"][4, nlon - 2] = np.inf
+        st2["cloud_cover"][nlat - 3, 2] = np.nan
+        m2 = build_ref_model(g, mask, fric, st2)
+        from pygcm.forcing import ThermalForcing
+        from pygcm.orbital import OrbitalSystem
+        forcing = ThermalForcing(g, OrbitalSystem())
+        albedo = np.where(mask == 0, 0.08, alb)
+        for i in range(2):
+            insA, insB = forcing.calculate_insolation_components(i * dt)
+            m2.isr_A, m2.isr_B, m2.isr = insA, insB, insA + insB
+            m2.time_step(forcing.calculate_equilibrium_temp(i * dt, albedo), dt)
+    P = qo.defaults()
+    og = qo.Grid(nlat, nlon)
+    cosl = np.cos(np.deg2rad(og.lat_mesh))
+    with np.errstate(all="ignore"):
+        orc = dict(lap_atm=oat.laplacian_sphere(F, og.dlat_rad, og.dlon_rad, np.maximum(cosl, 0.2), P.a),
+                   lap_ocn=oat.laplacian_sphere(F, og.dlat_rad, og.dlon_rad, np.maximum(cosl, 0.5), P.a),
+                   hyper_atm=oat.hyperdiffuse(F, k4, dt, 1, og.dlat_rad, og.dlon_rad, np.maximum(cosl, 0.2), P.a),
+                   shapiro2=onx.shapiro(F, 2))
+    for k in ref:
+        same = np.array_equal(orc[k], ref[k], equal_nan=True)
+        print(f"    {k:12s} oracle == reference (NaN-aware): {same}   nan {int(np.isnan(ref[k]).sum())} inf {int(np.isinf(ref[k]).sum())}")
+    save(f"nonfinite_{nlat}x{nlon}", dict(kind="nonfinite", nlat=nlat, nlon=nlon, seed=seed, dt=dt, nsteps=2, over={}, with_albedo=False),
+         F=F, k4=k4, **{"ref_" + k: v for k, v in ref.items()},
+         **{"init_" + k: st2[k] for k in STATE}, **{"ref_ts_" + k: getattr(m2, k) for k in STATE})
+
+
 def case_driver_physics(nlat, nlon, seed, nsteps=3):
     """run_simulation.py:1766-1934 + 2063-2146 composed from the REFERENCE's functions
     (physics.*, scripts.run_simulation._advect_scalar_periodic, scipy gaussian_filter), interleaved
@@ -574,6 +619,9 @@ def main():
         for (a, b, sd) in ((19, 36, 41), (37, 72, 42)):
             print(f"[driver physics {a}x{b}]")
             case_driver_physics(a, b, sd)
+    if want("nonfinite"):
+        print("[non-finite inputs 19x36]")
+        case_nonfinite(19, 36, 71)
     if want("bands"):
         print("[spectral bands 19x36]")
         case_spectral_bands(19, 36)

@@ -68,8 +68,11 @@ def bilinear_wrap(field, dep_row, dep_col):
     NI_GeometricTransform: t = 0; t += f00*wr0*wc0; t += f01*wr0*wc1;
     t += f10*wr1*wc0; t += f11*wr1*wc1."""
     nr, nc = field.shape
-    r = wrap_coord(dep_row, nr)
-    c = wrap_coord(dep_col, nc)
+    dep_row = np.asarray(dep_row, dtype=np.float64)
+    dep_col = np.asarray(dep_col, dtype=np.float64)
+    with np.errstate(invalid="ignore"):
+        r = np.nan_to_num(wrap_coord(dep_row, nr), nan=0.0, posinf=0.0, neginf=0.0)
+        c = np.nan_to_num(wrap_coord(dep_col, nc), nan=0.0, posinf=0.0, neginf=0.0)
     r0f = np.floor(r)
     c0f = np.floor(c)
     tr = r - r0f
@@ -90,6 +93,11 @@ def bilinear_wrap(field, dep_row, dep_col):
     t = t + field[r0, c1] * wr0 * wc1
     t = t + field[r1, c0] * wr1 * wc0
     t = t + field[r1, c1] * wr1 * wc1
+    # a NaN coordinate is "outside" for scipy: the constant fill value 0.0 (measured with scipy 1.15.3; infinite or
+    # astronomically large coordinates hit an undefined float->int cast inside scipy and are not pinned)
+    bad = np.isnan(dep_row) | np.isnan(dep_col)
+    if np.any(bad):
+        t = np.where(bad, 0.0, t)
     return t
 
 

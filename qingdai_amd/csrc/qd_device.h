@@ -64,7 +64,7 @@ __device__ __forceinline__ double qd_fold(double x, int n) {
     return x;
 }
 
-struct QdBilin { int l0, l1, c0, c1; double wr0, wr1, wc0, wc1; };
+struct QdBilin { int l0, l1, c0, c1; double wr0, wr1, wc0, wc1; bool nan_coord; };
 
 __device__ __forceinline__ QdBilin qd_departure(const QdGeom& G, int gi, int j, double u, double v, double dt,
                                                 double a, double cosl, double dlat, double dlon) {
@@ -74,6 +74,8 @@ __device__ __forceinline__ QdBilin qd_departure(const QdGeom& G, int gi, int j, 
     const double dy = dp / dlat;
     double r = qd_fold((double)gi - dy, G.nlat);
     double cc = qd_fold((double)j - dx, G.nlon);
+    // scipy treats a NaN coordinate as outside the array: constant fill 0.0 (measured)
+    const bool nan_coord = (dx != dx) || (dy != dy);
     // NaN/garbage-safe clamps (never fault); finite inputs are already inside the range
     r = fmin(fmax(r, 0.0), (double)(G.nlat - 1));
     cc = fmin(fmax(cc, 0.0), (double)(G.nlon - 1));
@@ -85,6 +87,7 @@ __device__ __forceinline__ QdBilin qd_departure(const QdGeom& G, int gi, int j, 
     b.l0 = qd_lrow_far(G, r0); b.l1 = qd_lrow_far(G, r1);
     const double tr = r - r0f, tc = cc - c0f;
     b.wr0 = 1.0 - tr; b.wr1 = tr; b.wc0 = 1.0 - tc; b.wc1 = tc;
+    b.nan_coord = nan_coord;
     return b;
 }
 
@@ -95,7 +98,7 @@ __device__ __forceinline__ double qd_gather(const double* __restrict__ F, const 
     t += F[r0 + b.c1] * b.wr0 * b.wc1;
     t += F[r1 + b.c0] * b.wr1 * b.wc0;
     t += F[r1 + b.c1] * b.wr1 * b.wc1;
-    return t;
+    return b.nan_coord ? 0.0 : t;
 }
 
 

@@ -122,6 +122,26 @@ def test_spectral_band_insolation_vs_reference(gpu, monkeypatch):
     dev.close()
 
 
+def test_operators_nonfinite_inputs_vs_reference(gpu):
+    """Device operators on the reference's own outputs for a NaN / +-inf poisoned field (tests/golden/nonfinite_19x36.npz):
+    same NaN and inf cells; finite cells to rounding (magnitudes near 1.8e308: sign only)."""
+    import qingdai_amd as qa
+    meta, d = load_golden("nonfinite_19x36")
+    dev = qa.SphericalGrid(19, 36)._ops()
+    F = d["F"]
+    got = {"lap_atm": dev.op_laplacian(F), "lap_ocn": dev.op_laplacian(F, ocean=True),
+           "hyper_atm": dev.op_hyperdiffuse(F, d["k4"], meta["dt"], 1), "shapiro2": dev.op_shapiro(F, 2)}
+    for k, v in got.items():
+        w = d["ref_" + k]
+        assert np.array_equal(np.isnan(v), np.isnan(w)) and np.array_equal(np.isinf(v), np.isinf(w)), k
+        assert np.array_equal(np.sign(v[np.isinf(w)]), np.sign(w[np.isinf(w)])), k
+        fin = np.isfinite(w)
+        big = fin & (np.abs(w) > 1e290)
+        assert np.array_equal(np.sign(v[big]), np.sign(w[big])), k
+        sel = fin & ~big
+        assert np.allclose(v[sel], w[sel], rtol=1e-12, atol=1e-13 * np.abs(w[sel]).max()), k
+
+
 def test_operators_nonfinite_inputs_vs_oracle(gpu):
     """Where the reference scrubs (np.nan_to_num at the entry of _laplacian_sphere / _hyperdiffuse and on their results) and
     where it does not (Shapiro, divergence, the bilinear gather propagate NaN): device operators against the oracle's
@@ -242,6 +262,20 @@ def test_time_step_scrubs_nonfinite_like_the_reference(gpu):
         a, b = getattr(got, k), getattr(want, k)
         assert np.all(np.isfinite(a)) and np.all(np.isfinite(b)), k
         assert np.allclose(a[far], b[far], rtol=1e-9, atol=1e-9 * np.abs(b[far]).max()), k
+
+
+def test_time_step_on_poisoned_state_vs_reference(gpu):
+    """Two time_steps from a state poisoned with NaN (u, cloud) and +inf (q) against the REFERENCE's own result
+    (tests/golden/nonfinite_19x36.npz): same finite mask everywhere; values agree away from the cell that was +inf (after
+    nan_to_num it is 1.8e308 and its stencil neighbourhood saturates).  Covers scipy's constant fill for NaN departure points."""
+    meta, d = load_golden("nonfinite_19x36")
+    got = run_device_time_step(meta, d)
+    far = np.ones((19, 36), dtype=bool)
+    far[np.ix_(np.arange(0, 15), np.arange(34 - 10, 34 + 11) % 36)] = False
+    for k in STATE:
+        a, b = getattr(got, k), d["ref_ts_" + k]
+        assert np.array_equal(np.isfinite(a), np.isfinite(b)), k
+        assert np.allclose(a[far], b[far], rtol=1e-9, atol=1e-9 * np.abs(b[far]).max()), (k, np.abs(a - b)[far].max())
 
 
 def test_time_step_host_arrays_path(gpu):

@@ -146,6 +146,29 @@ def test_spectral_band_insolation_matches_reference():
     assert np.array_equal(specA, d["ref_specA16"]) and np.array_equal(specB, d["ref_specB16"]) and np.all(tray == 1.0)
 
 
+def test_nonfinite_inputs_match_reference():
+    """NaN / +-inf in the inputs: the oracle scrubs (and lets through) exactly where the reference does -- its own
+    _laplacian_sphere / _hyperdiffuse / _shapiro_filter and two whole time_steps on a poisoned state, NaN-aware bit equality."""
+    meta, d = load_golden("nonfinite_19x36")
+    g, mask, _, _ = surface(19, 36)
+    P = qo.defaults()
+    cosl = np.cos(np.deg2rad(g.lat_mesh))
+    F, k4, dt = d["F"], d["k4"], meta["dt"]
+    with np.errstate(all="ignore"):
+        got = dict(lap_atm=oat.laplacian_sphere(F, g.dlat_rad, g.dlon_rad, np.maximum(cosl, 0.2), P.a),
+                   lap_ocn=oat.laplacian_sphere(F, g.dlat_rad, g.dlon_rad, np.maximum(cosl, 0.5), P.a),
+                   hyper_atm=oat.hyperdiffuse(F, k4, dt, 1, g.dlat_rad, g.dlon_rad, np.maximum(cosl, 0.2), P.a),
+                   shapiro2=onx.shapiro(F, 2))
+        m = run_oracle_time_step(meta, d)
+    for k, v in got.items():
+        assert np.array_equal(v, d["ref_" + k], equal_nan=True), k
+    assert np.isnan(d["ref_lap_atm"]).sum() > 0 and np.isinf(d["ref_lap_atm"]).sum() > 0      # the poison really bites
+    for k in STATE:
+        a, b = getattr(m, k), d["ref_ts_" + k]
+        assert np.array_equal(np.isfinite(a), np.isfinite(b)), k
+        assert np.allclose(a, b, rtol=1e-11, atol=1e-11 * np.abs(b[np.isfinite(b)]).max(), equal_nan=True), k
+
+
 def test_known_answers_appendix_a3():
     """19x36, defaults, albedo passed, 12 steps of the benchmark loop."""
     meta, d = load_golden("ts_19x36_default_alb")
