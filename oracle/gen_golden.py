@@ -274,7 +274,7 @@ def case_time_step(name, nlat, nlon, nsteps, over, with_albedo, seed=None, wet=F
     return worst
 
 
-def case_ocean(name, nlat, nlon, nsteps, over, seed, strong=False):
+def case_ocean(name, nlat, nlon, nsteps, over, seed, strong=False, poison=False):
     """WindDrivenSlabOcean.step driven by fixed winds / Q_net / ice mask."""
     from pygcm.ocean import WindDrivenSlabOcean
     g, mask, alb, fric = surface(nlat, nlon)
@@ -292,6 +292,14 @@ def case_ocean(name, nlat, nlon, nsteps, over, seed, strong=False):
         oc.uo = np.where(mask == 0, 0.3 * np.cos(np.deg2rad(g.lat_mesh)) + r.normal(0, 0.05, mask.shape), 0.0)
         oc.vo = np.where(mask == 0, r.normal(0, 0.05, mask.shape), 0.0)
         oc.eta = np.where(mask == 0, r.normal(0, 0.2, mask.shape), 0.0)
+        if poison:      # NaN in every prognostic field (ocean cells, one next to a pole): exercises the step's nan_to_num placements
+            oi, oj = np.where(mask == 0)
+            pick = [int(len(oi) * f) for f in (0.13, 0.41, 0.67, 0.93)]
+            oc.uo[oi[pick[0]], oj[pick[0]]] = np.nan
+            oc.vo[oi[pick[1]], oj[pick[1]]] = np.nan
+            oc.eta[oi[pick[2]], oj[pick[2]]] = np.nan
+            oc.Ts[oi[pick[3]], oj[pick[3]]] = np.nan
+            init_Ts = oc.Ts.copy()
         init = dict(uo=oc.uo.copy(), vo=oc.vo.copy(), eta=oc.eta.copy(), Ts=oc.Ts.copy())
         nsubs = []
         for i in range(nsteps):
@@ -610,6 +618,7 @@ def main():
         ("ocean_37x72_strong", 37, 72, 3, {}, 22, True),
         ("ocean_19x36_clamp_shapiro", 19, 36, 8, {"ocean_outlier": "clamp", "ocean_shapiro_n": 1}, 23, True),
         ("ocean_37x72_nsub", 37, 72, 3, {"ocean_cfl": 0.02}, 24, True),
+        ("ocean_19x36_nanpoison", 19, 36, 3, {}, 25, False, True),
     ]
     for c in oc_cases:
         if want(c[0]):

@@ -18,8 +18,11 @@ from .params import SIGMA_SB, is_set
 # ---------------------------------------------------------------- operators
 def laplacian_sphere(F, dlat, dlon, coslat, a):
     """dynamics.py:144-173 / ocean.py:100-117 / jax_compat.py:111-132.
-    `coslat` is the caller's already-floored cos(phi) map (0.2 atmos, 0.5 ocean)."""
-    F = np.nan_to_num(F)
+    `coslat` is the caller's already-floored cos(phi) map (0.2 atmos, 0.5 ocean).
+    Like the reference (`np.nan_to_num(F, copy=False)`, dynamics.py:165 / ocean.py:112) this scrubs the CALLER's array in
+    place -- a side effect its callers rely on: `self.Ts += dt*K_h*lap(self.Ts)` (ocean.py:386) adds to the scrubbed Ts, and
+    the second sub-step of _hyperdiffuse continues from a scrubbed `out`."""
+    F = np.nan_to_num(F, copy=False)
     dF = nx.gradient_axis0(F, dlat)
     term_phi = (1.0 / coslat) * nx.gradient_axis0(coslat * dF, dlat)
     d2 = (np.roll(F, -1, axis=1) - 2.0 * F + np.roll(F, 1, axis=1)) / (dlon ** 2)

@@ -351,7 +351,7 @@ k_sst_diffuse_heat(QdGeom G, const double* __restrict__ cos05, double dlat, doub
     const int i = G.row0 + tl.row;
     const size_t o = (size_t)qd_lrow(G, i) * G.nlon + j;
     double T = Ts1[o];
-    if (P.K_h > 0.0) T = T + P.sub_dt * P.K_h * qd_lap_point<true>(Ts1, G, cos05, i, j, dlat, dlon, a);
+    if (P.K_h > 0.0) T = qd_nn(T) + P.sub_dt * P.K_h * qd_lap_point<true>(Ts1, G, cos05, i, j, dlat, dlon, a);   // in-place scrub, ocean.py:112,386
     if (P.use_q) {
         const double heat = qnet[o] / P.rcH;
         const bool ocean = land[o] == 0;
@@ -427,7 +427,8 @@ k_sst_outlier_fused(QdGeom G, QdTabs T, double dlat, double dlon, double a, QdHe
     const size_t b = (size_t)qd_lrow(G, i) * G.nlon;
     const size_t o = b + j;
     double Tv = Ts1[o];
-    if (P.K_h > 0.0) Tv = Tv + P.sub_dt * P.K_h * qd_lap_point_fast<true>(Ts1, G, T, 1, i, j, dlat, dlon, a);
+    // ocean.py:386 `self.Ts += dt*K_h*lap(self.Ts)`: the Laplacian scrubs self.Ts IN PLACE (nan_to_num(copy=False)) before the add
+    if (P.K_h > 0.0) Tv = qd_nn(Tv) + P.sub_dt * P.K_h * qd_lap_point_fast<true>(Ts1, G, T, 1, i, j, dlat, dlon, a);
     if (P.use_q) {
         const double heat = qnet[o] / P.rcH;
         const bool ocean = land[o] == 0;

@@ -158,9 +158,9 @@ def test_operators_nonfinite_inputs_vs_oracle(gpu):
     cos = np.cos(np.deg2rad(og.lat_mesh))
     c02, c05 = np.maximum(cos, 0.2), np.maximum(cos, 0.5)
     with np.errstate(all="ignore"):
-        want = {"lap_atm": oat.laplacian_sphere(F, og.dlat_rad, og.dlon_rad, c02, a),
-                "lap_ocn": oat.laplacian_sphere(F, og.dlat_rad, og.dlon_rad, c05, a),
-                "hyper": oat.hyperdiffuse(F, d["k4"], meta["dt"], 1, og.dlat_rad, og.dlon_rad, c02, a),
+        want = {"lap_atm": oat.laplacian_sphere(F.copy(), og.dlat_rad, og.dlon_rad, c02, a),
+                "lap_ocn": oat.laplacian_sphere(F.copy(), og.dlat_rad, og.dlon_rad, c05, a),
+                "hyper": oat.hyperdiffuse(F.copy(), d["k4"], meta["dt"], 1, og.dlat_rad, og.dlon_rad, c02, a),
                 "shapiro": onx.shapiro(F, 2)}
     got = {"lap_atm": dev.op_laplacian(F), "lap_ocn": dev.op_laplacian(F, ocean=True),
            "hyper": dev.op_hyperdiffuse(F, d["k4"], meta["dt"], 1), "shapiro": dev.op_shapiro(F, 2)}

@@ -155,9 +155,9 @@ def test_nonfinite_inputs_match_reference():
     cosl = np.cos(np.deg2rad(g.lat_mesh))
     F, k4, dt = d["F"], d["k4"], meta["dt"]
     with np.errstate(all="ignore"):
-        got = dict(lap_atm=oat.laplacian_sphere(F, g.dlat_rad, g.dlon_rad, np.maximum(cosl, 0.2), P.a),
-                   lap_ocn=oat.laplacian_sphere(F, g.dlat_rad, g.dlon_rad, np.maximum(cosl, 0.5), P.a),
-                   hyper_atm=oat.hyperdiffuse(F, k4, dt, 1, g.dlat_rad, g.dlon_rad, np.maximum(cosl, 0.2), P.a),
+        got = dict(lap_atm=oat.laplacian_sphere(F.copy(), g.dlat_rad, g.dlon_rad, np.maximum(cosl, 0.2), P.a),
+                   lap_ocn=oat.laplacian_sphere(F.copy(), g.dlat_rad, g.dlon_rad, np.maximum(cosl, 0.5), P.a),
+                   hyper_atm=oat.hyperdiffuse(F.copy(), k4, dt, 1, g.dlat_rad, g.dlon_rad, np.maximum(cosl, 0.2), P.a),
                    shapiro2=onx.shapiro(F, 2))
         m = run_oracle_time_step(meta, d)
     for k, v in got.items():
