@@ -22,6 +22,9 @@ import time
 
 import numpy as np
 
+# RCCL between processes needs dmabuf IPC on this stack (the image exports it already; make sure ranks started some other way have it too)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
