@@ -60,6 +60,10 @@ enum qd_field {
     QD_F_W_LAND, QD_F_S_SNOW, QD_F_C_SNOW,
     /* P019 provisional snow / land bucket working fields (run_simulation.py:1946-2019, 2290-2339) */
     QD_F_S_SNOW_NEXT, QD_F_MELT, QD_F_P_RAIN, QD_F_GLACIER, QD_F_RUNOFF,
+    /* ecology, per physics step (population.py:252-294,831-915; adapter.py:140-186; run_simulation.py:2075-2128):
+     * total LAI, its snapshot at the last canopy recompute, cached canopy factor f, daily energy buffer, land-only
+     * ecology alpha (NaN elsewhere), daily banded alpha, ocean-colour alpha of the phytoplankton coupling */
+    QD_F_ECO_LAI, QD_F_ECO_LAI_SNAP, QD_F_ECO_F, QD_F_ECO_EDAY, QD_F_ECO_ALPHA, QD_F_ECO_ALPHA_BANDED, QD_F_WATER_ALPHA,
     QD_F_COUNT_F64,
     /* uint8 masks */
     QD_F_LAND_MASK = 100, QD_F_ICE_MASK = 101
@@ -148,7 +152,7 @@ int qd_driver_physics(qd_handle h, double dt);
 int qd_hydrology_commit(qd_handle h, double dt);
 /* benchmark_jax.py:124-158 as one resident loop of n steps: forcing -> albedo -> time_step [-> ocean
  * coupling] [-> hydrology commit].  flags bit0 = with_ocean, bit1 = with_driver_physics (else the simple
- * ocean/land albedo of benchmark_jax.py:129), bit2 = pass albedo to time_step, bit3 = hydrology commit, bit4 = energy diagnostics on the first step (qd_energy_diagnostics_last).  `stars` holds n rows of 7 host scalars
+ * ocean/land albedo of benchmark_jax.py:129), bit2 = pass albedo to time_step, bit3 = hydrology commit, bit4 = energy diagnostics on the first step (qd_energy_diagnostics_last), bit5 = ecology sub-step (qd_eco_substep, and qd_indiv_substep when a pool is configured; needs bit1).  `stars` holds n rows of 7 host scalars
  * (flux_A, decl_A, ra_A, flux_B, decl_B, ra_B, theta), evaluated by the caller as forcing.py:85-125 does. */
 int qd_step_n(qd_handle h, int n, double dt, int flags, const double* stars);
 int qd_last_ocean_nsub(qd_handle h, int* n_sub);
@@ -174,6 +178,51 @@ int qd_op_median_positive(qd_handle h, const double* x, double dflt, double* out
  * dual_star_insolation_to_bands on the resident ISR_A / ISR_B: specA/specB/tray are the NB host-computed band weights of the
  * two stars and the Rayleigh factor; the result [nb][n_lat][n_lon] f64 stays resident and is also copied to `out_host_or_null`. */
 int qd_band_insolation(qd_handle h, int nb, const double* specA, const double* specB, const double* tray, double* out_host_or_null);
+
+/* ---- ecology, the per-physics-step part (BASELINE config 5; SURVEY.md 8(f)3 stages 2-4) --------------------------------
+ * The daily population dynamics (population.py:389-830, individuals.py:193-361) stay host code that runs once per
+ * planet-day; it hands the device the LAI layers and takes the energy buffers back. */
+typedef struct qd_eco_params {
+    double k_canopy;             /* QD_ECO_LAI_K (0.5): f = 1 - exp(-k max(LAI_tot, 0)), population.py:911-915 */
+    double leaf_scalar;          /* adapter.py:61: sum_b R_leaf[b] w_b */
+    double soil_ref;             /* QD_ECO_SOIL_REFLECT (0.20), adapter.py:170 */
+    double w_lai;                /* QD_ECO_LAI_ALBEDO_WEIGHT (1.0), run_simulation.py:2089-2100 */
+    double light_update_hours;   /* QD_ECO_LIGHT_UPDATE_EVERY_HOURS (6), population.py:62-65,900 */
+    double recompute_lai_delta;  /* QD_ECO_LIGHT_RECOMPUTE_LAI_DELTA (0.05), population.py:66-69,903-907 */
+    int32_t substep_every_nphys; /* QD_ECO_SUBSTEP_EVERY_NPHYS (1), adapter.py:156 */
+    int32_t albedo_couple;       /* QD_ECO_SUBDAILY_ENABLE && QD_ECO_ALBEDO_COUPLE: run_simulation.py:2075 */
+    int32_t bands_couple;        /* QD_ECO_BANDS_COUPLE: land base albedo <- clip(ECO_ALPHA_BANDED), run_simulation.py:2107-2112 */
+    int32_t water_couple;        /* QD_PHYTO_ENABLE && QD_PHYTO_ALBEDO_COUPLE: ocean base albedo <- clip(WATER_ALPHA), :2121-2128 */
+} qd_eco_params;
+int qd_eco_configure(qd_handle h, const qd_eco_params* p, size_t sizeof_params);
+/* PopulationManager.total_LAI (population.py:288-294): layers = [n_planes][n_lat][n_lon] host f64 (the flattened
+ * [S][K] planes of LAI_layers_SK), summed plane after plane like np.sum(axis=(0,1)) into the resident ECO_LAI.
+ * init != 0 also takes the constructor's snapshot (population.py:71). */
+int qd_eco_set_lai_layers(qd_handle h, const double* layers, int n_planes, int init);
+/* EcologyAdapter.step_subdaily (adapter.py:140-186) on the resident ISR: E_day += nan_to_num(isr) dt, canopy clock and
+ * recompute policy (population.py:252-280,895-915), land-only alpha map on sub-step boundaries.  qd_step_n with flags
+ * bit5 runs the same inside its loop, where the driver does (run_simulation.py:2075-2104). */
+int qd_eco_substep(qd_handle h, double dt);
+/* population.get_surface_albedo_bands + the driver's daily reduction (population.py:875-893, run_simulation.py:1843-1844):
+ * ECO_ALPHA_BANDED <- clip(nansum_b clip(R_eff[b] f + (1 - f) soil, 0, 1) w_b, 0, 1); nb <= 32 */
+int qd_eco_banded_alpha(qd_handle h, int nb, const double* r_eff, const double* w_b);
+/* clock state for restarts / inspection: out[0] hours accumulated, [1] next time-based recompute, [2] step count,
+ * [3] canopy recomputes so far, [4] 1 when an alpha map is cached */
+int qd_eco_get_state(qd_handle h, double out[5]);
+int qd_eco_set_state(qd_handle h, const double in[3]);        /* hours, next recompute, step count */
+
+/* IndividualPool (individuals.py:37-191): n_cells sampled land cells (row j, column i), n_indiv individuals each bound to
+ * one sampled cell, with a per-band coefficient row Ab[n_indiv][nb] and a drought tolerance; band tables as in
+ * qd_band_insolation.  State (E_day, water-stress days) stays resident. */
+int qd_indiv_configure(qd_handle h, int n_cells, const int32_t* sample_j, const int32_t* sample_i, int n_indiv,
+                       const int32_t* cell_index, const double* Ab, const double* tol, int nb, const double* specA,
+                       const double* specB, const double* tray, int substeps_per_day, double day_seconds, double soil_cap);
+/* IndividualPool.try_substep (individuals.py:142-191) on the resident ISR_A / ISR_B and the soil index
+ * clip(W_LAND / max(1e-6, soil_cap), 0, 1) of run_simulation.py:2025-2033; *fired = 1 when a sub-step was consumed.
+ * The band intensities are evaluated per sampled cell and never materialised as [NB][n_lat][n_lon]. */
+int qd_indiv_substep(qd_handle h, double dt, int* fired_or_null);
+int qd_indiv_download(qd_handle h, double* E_day, double* stress_days);   /* each [n_indiv]; band handles: own cells, 0 elsewhere */
+int qd_indiv_upload(qd_handle h, const double* E_day, const double* stress_days);   /* daily reset / restart */
 
 /* ---- reductions for diagnostics (energy.py:494-538, ocean.py:535-561) -------------- */
 /* compute_energy_diagnostics (energy.py:494-538) from the resident state, with the flux formulas of the driver's

@@ -471,6 +471,136 @@ def case_spectral_bands(nlat, nlon):
     save(f"spectral_{nlat}x{nlon}", dict(kind="spectral", nlat=nlat, nlon=nlon, times=[0.0, 4.1e6]), **out)
 
 
+def case_ecology(nlat, nlon, seed):
+    """The per-step ecology of BASELINE config 5 run as the REFERENCE's own classes: EcologyAdapter.step_subdaily over
+    PopulationManager (pygcm/ecology/adapter.py:140-186, population.py:252-294,831-915), get_surface_albedo_bands
+    (population.py:875-893) with the driver's daily reduction (run_simulation.py:1843-1844), the driver's base-albedo blend
+    (run_simulation.py:2075-2141, composed here around the reference's calculate_dynamic_albedo), and
+    IndividualPool.try_substep (individuals.py:142-191).  The LAI layers are perturbed between steps the way step_daily would."""
+    from types import SimpleNamespace
+    from pygcm import physics as rph
+    from pygcm.ecology.adapter import EcologyAdapter
+    from pygcm.ecology.individuals import IndividualPool
+    from pygcm.forcing import ThermalForcing
+    from pygcm.orbital import OrbitalSystem
+    from pygcm import constants as rconst
+    from qd_oracle import ecology as oeco, spectral as osp
+    g, mask, alb, fric = surface(nlat, nlon)
+    r = np.random.default_rng(seed)
+    env = {"QD_ECO_DIAG": "0", "QD_ECO_NS": "4", "QD_ECO_COHORT_K": "2", "QD_ECO_LIGHT_UPDATE_EVERY_HOURS": "0.5",
+           "QD_ECO_SUBSTEP_EVERY_NPHYS": "2", "QD_ECO_LAI_K": "0.6", "QD_ECO_SOIL_REFLECT": "0.18",
+           "QD_ECO_INDIV_SAMPLE_FRAC": "0.3", "QD_ECO_INDIV_PER_CELL": "5", "QD_ECO_INDIV_SUBSTEPS_PER_DAY": "10"}
+    dt, nsteps = 300.0, 10
+    out, meta_steps = {}, []
+    with ref_env({}):
+        os.environ.update(env)
+        forcing = ThermalForcing(g, OrbitalSystem())
+        eco = quiet(EcologyAdapter, g, mask)
+        pop = eco.pop
+        S, K = pop.LAI_layers_SK.shape[:2]
+        land = (mask == 1)
+        L0 = np.abs(r.normal(0.4, 0.3, (S, K, nlat, nlon))) * land
+        L0[0, 0][r.random((nlat, nlon)) < 0.03] = -0.05            # a few negative layers: max(LAI_tot, 0) matters
+        L1 = L0 * (1.0 + 0.4 * r.random(L0.shape))                 # growth spurt: ratio >= delta, cache rebuilt
+        L2 = L1 * (1.0 + 0.01 * r.normal(0, 1, L0.shape))          # small drift: ratio < delta, cache kept until the clock
+        pop.LAI_layers_SK[...] = L0
+        pop._lai_snapshot = pop.total_LAI().copy()
+        n_rec = [0]
+        orig = pop._recompute_canopy_cache
+
+        def counted():
+            n_rec[0] += 1
+            orig()
+        pop._recompute_canopy_cache = counted
+        last_alpha = None
+        for i in range(nsteps):
+            if i == 2:
+                pop.LAI_layers_SK[...] = L1
+            if i == 5:
+                pop.LAI_layers_SK[...] = L2
+            insA, insB = forcing.calculate_insolation_components(i * dt * 40.0)
+            out[f"insA_{i}"], out[f"insB_{i}"] = insA, insB
+            a = eco.step_subdaily(insA + insB, 0.3, dt)
+            meta_steps.append(dict(returned=a is not None, n_recompute=n_rec[0]))
+            if a is not None:
+                out[f"ref_alpha_{i}"] = a.copy()
+                last_alpha = a.copy()
+            if i == nsteps - 1:
+                # the driver's blend (W_LAI = 0.8) + snow blend + dynamic albedo around the reference's own function
+                glacier = land & (r.random((nlat, nlon)) < 0.2)
+                C_snow = np.clip(r.random((nlat, nlon)) * 1.2 - 0.4, 0.0, 1.0) * land
+                cloud = np.clip(r.random((nlat, nlon)), 0.0, 1.0)
+                h_ice = np.maximum(r.normal(0.0, 0.3, (nlat, nlon)), 0.0) * (~land)
+                Ts = 288.0 + r.normal(0, 10, (nlat, nlon))
+                base_in = alb.copy()
+                mm = land & (~glacier) & np.isfinite(last_alpha)
+                base_in[mm] = (1.0 - 0.8) * base_in[mm] + 0.8 * last_alpha[mm]
+                base_in[land] = np.clip((1.0 - C_snow[land]) * base_in[land] + C_snow[land] * 0.70, 0.0, 1.0)
+                ice_frac = 1.0 - np.exp(-np.maximum(h_ice, 0.0) / 0.5)
+                out["ref_albedo_blend"] = rph.calculate_dynamic_albedo(cloud, Ts, base_in, 0.6, 0.5, land_mask=mask, ice_frac=ice_frac)
+                out.update(glacier=glacier.astype(np.uint8), C_snow=C_snow, cloud=cloud, h_ice=h_ice, Ts=Ts, land_mask=mask.astype(np.uint8), base_albedo=alb)
+        out["ref_E_day"] = pop.E_day.copy()
+        out["ref_f_cached"] = pop._canopy_f_cached.copy()
+        A, w_b = eco.get_surface_albedo_bands()
+        out["ref_A_bands"], out["ref_w_b"] = A, w_b
+        out["ref_alpha_banded"] = np.clip(np.nansum(A * w_b[:, None, None], axis=0), 0.0, 1.0)
+        out["R_species"] = pop._species_R_leaf.copy()
+        out["species_w"] = pop.species_weights.copy()
+        leaf_s = float(eco.alpha_leaf_scalar)
+        # individuals: sampled pool, K = 10 substeps a day, driven with a long physics step so that several fire
+        pool = quiet(IndividualPool, g, mask, eco)
+        day = 2 * np.pi / rconst.PLANET_OMEGA
+        dti = day / 25.0
+        soil = np.clip(r.random((nlat, nlon)), 0.0, 1.0)
+        fired = []
+        for i in range(30):
+            insA, insB = forcing.calculate_insolation_components(i * dti)
+            before = pool._substep_accum if pool._substep_period is not None else 0.0
+            pool.try_substep(insA, insB, eco, soil, dti, day)
+            if pool._substep_accum < before + dti - 1e-9:
+                fired.append(i)
+                out[f"ind_insA_{i}"], out[f"ind_insB_{i}"] = insA, insB
+        out.update(ind_sample_j=pool.sample_j, ind_sample_i=pool.sample_i, ind_cell=pool.indiv_cell_index, ind_Ab=pool.indiv_Ab,
+                   ind_tol=pool.indiv_tol, ind_soil=soil, ref_ind_E_day=pool.indiv_E_day.copy(),
+                   ref_ind_stress=pool.indiv_water_stress_days.copy())
+    # oracle on the same inputs
+    ob = osp.make_bands(16, 380.0, 780.0)
+    opop = oeco.CanopyPopulation(mask, L0, k_canopy=0.6, light_update_every_hours=0.5, recompute_lai_delta=0.05)
+    oad = oeco.EcoAdapter(opop, oeco.leaf_scalar(ob), soil_ref=0.18, substep_every_nphys=2)
+    print(f"    leaf scalar           oracle-vs-ref {abs(oeco.leaf_scalar(ob) - leaf_s):.2e}")
+    worst = 0.0
+    for i in range(nsteps):
+        if i == 2:
+            opop.layers = L1.copy()
+        if i == 5:
+            opop.layers = L2.copy()
+        a = oad.step_subdaily(out[f"insA_{i}"] + out[f"insB_{i}"], dt)
+        assert (a is not None) == meta_steps[i]["returned"] and opop.n_recompute == meta_steps[i]["n_recompute"], (i, opop.n_recompute)
+        if a is not None:
+            assert np.array_equal(np.isnan(a), np.isnan(out[f"ref_alpha_{i}"]))
+            worst = max(worst, maxrel(np.nan_to_num(a), np.nan_to_num(out[f"ref_alpha_{i}"])))
+    print(f"    alpha maps            oracle-vs-ref maxrel {worst:.2e}   recomputes {opop.n_recompute}")
+    print(f"    E_day / f cache       oracle-vs-ref maxrel {maxrel(opop.E_day, out['ref_E_day']):.2e} / {maxrel(opop.f_cached, out['ref_f_cached']):.2e}")
+    R_eff = oeco.effective_leaf_reflectance(out["species_w"], out["R_species"])
+    Ao = opop.surface_albedo_bands(R_eff, 0.18)
+    print(f"    A_bands / banded      oracle-vs-ref maxrel {maxrel(np.nan_to_num(Ao), np.nan_to_num(A)):.2e} / "
+          f"{maxrel(oeco.banded_alpha(Ao, oeco.band_weights(ob)), out['ref_alpha_banded']):.2e}")
+    oi = oeco.IndividualSubstep(pool.sample_j, pool.sample_i, pool.indiv_cell_index, pool.indiv_Ab, pool.indiv_tol, 10)
+    of = qo.Forcing(qo.Grid(nlat, nlon))
+    ofired = []
+    for i in range(30):
+        a_, b_ = of.insolation_components(i * dti)
+        if oi.try_substep(a_, b_, ob, soil, dti, day):
+            ofired.append(i)
+    assert ofired == fired, (ofired, fired)
+    print(f"    individuals E / stress oracle-vs-ref maxrel {maxrel(oi.E_day, pool.indiv_E_day):.2e} / "
+          f"{maxrel(oi.stress_days, pool.indiv_water_stress_days):.2e}   fired {len(fired)}")
+    save(f"eco_{nlat}x{nlon}", dict(kind="ecology", nlat=nlat, nlon=nlon, seed=seed, dt=dt, nsteps=nsteps, steps=meta_steps,
+                                    k_canopy=0.6, soil_ref=0.18, every_h=0.5, delta=0.05, substep_every=2, leaf_scalar=leaf_s,
+                                    w_lai=0.8, alpha_snow=0.70, ind_dt=dti, ind_day=day, ind_fired=fired, ind_k=10),
+         L0=L0, L1=L1, L2=L2, **out)
+
+
 def case_nonfinite(nlat, nlon, seed):
     """Where the reference scrubs non-finite values and where it lets them through: its own _laplacian_sphere (atmosphere and
     ocean), _hyperdiffuse, _shapiro_filter and a whole time_step on a state poisoned with NaN / +-inf."""
@@ -634,6 +764,9 @@ def main():
     if want("bands"):
         print("[spectral bands 19x36]")
         case_spectral_bands(19, 36)
+    if want("eco"):
+        print("[ecology canopy + individuals 19x36]")
+        case_ecology(19, 36, 81)
     if want("phyto"):
         for (a, b, s) in ((19, 36, 61), (37, 72, 62)):
             print(f"[phyto transport {a}x{b}]")

@@ -128,6 +128,12 @@ class DriverOracle:
         self.precip = np.zeros(shp)
         self.albedo = np.zeros(shp)
         self.R_flux = np.zeros(shp)
+        # optional ecology (qd_oracle.ecology): EcoCoupling blended into the base albedo, IndividualSubstep + its bands
+        self.eco = None
+        self.indiv = None
+        self.indiv_bands = None
+        self.indiv_day = None
+        self.soil_cap = 50.0
 
     def step(self, t, dt):
         from . import column as col
@@ -188,6 +194,11 @@ class DriverOracle:
         ice_frac = 1.0 - np.exp(-np.maximum(m.h_ice, 0.0) / max(1e-6, P.hice_ref))
         cloud_for_rad = m.cloud_eff_last if getattr(m, "cloud_eff_last", None) is not None else m.cloud_cover
         base_in = self.base_albedo.copy() if P.use_topo_albedo else np.full_like(m.T_s, float(P.alpha_water))
+        if self.indiv is not None:                             # run_simulation.py:2021-2046
+            soil_idx = np.clip(self.W_land / max(1e-6, self.soil_cap), 0.0, 1.0)
+            self.indiv.try_substep(m.isr_A, m.isr_B, self.indiv_bands, soil_idx, dt, self.indiv_day)
+        if self.eco is not None:                               # run_simulation.py:2075-2128
+            self.eco.apply(base_in, land, glacier, m.isr, dt)
         if P.swe_enable:
             base_in[land] = np.clip((1.0 - C_snow[land]) * base_in[land] + C_snow[land] * alpha_snow[land], 0.0, 1.0)
         albedo = ph.calculate_dynamic_albedo(cloud_for_rad, m.T_s, base_in, P.alpha_ice, P.alpha_cloud,

@@ -19,7 +19,8 @@ LIB_PATH = os.path.join(_HERE, "libqingdai_hip.so")
 FIELDS = ["U", "V", "H", "TS", "Q", "CLOUD", "HICE", "ISR", "ISR_A", "ISR_B", "TEQ", "ALBEDO",
           "OLR", "EFLUX", "PCOND", "LH", "LHREL", "CLOUD_EFF", "FRICTION", "CSMAP", "BASE_ALBEDO", "ELEVATION",
           "UO", "VO", "ETA", "SST", "QNET", "PRECIP", "CLOUD_FROM_P", "CLOUD_SRC", "W_LAND", "S_SNOW", "C_SNOW",
-          "S_SNOW_NEXT", "MELT", "P_RAIN", "GLACIER", "RUNOFF"]
+          "S_SNOW_NEXT", "MELT", "P_RAIN", "GLACIER", "RUNOFF",
+          "ECO_LAI", "ECO_LAI_SNAP", "ECO_F", "ECO_EDAY", "ECO_ALPHA", "ECO_ALPHA_BANDED", "WATER_ALPHA"]
 F = {n: i for i, n in enumerate(FIELDS)}
 F["LAND_MASK"] = 100
 F["ICE_MASK"] = 101
@@ -33,8 +34,17 @@ SYMBOLS = [
     "qd_op_laplacian", "qd_op_hyperdiffuse", "qd_op_advect", "qd_op_shapiro", "qd_op_zonal_filter", "qd_op_divergence",
     "qd_op_vorticity", "qd_op_gaussian", "qd_op_median_positive", "qd_reduce", "qd_energy_diagnostics", "qd_energy_diagnostics_last", "qd_band_insolation",
     "qd_comm_unique_id", "qd_comm_init", "qd_comm_init_local", "qd_comm_stats", "qd_comm_barrier", "qd_comm_allreduce_max",
+    "qd_eco_configure", "qd_eco_set_lai_layers", "qd_eco_substep", "qd_eco_banded_alpha", "qd_eco_get_state", "qd_eco_set_state",
+    "qd_indiv_configure", "qd_indiv_substep", "qd_indiv_download", "qd_indiv_upload",
     "qd_copy_ceiling", "qd_timing_enable", "qd_timing_select", "qd_timing_get", "qd_timing_reset",
 ]
+
+
+class qd_eco_params(ctypes.Structure):
+    """include/qingdai_hip.h: qd_eco_params"""
+    _fields_ = ([(n, ctypes.c_double) for n in ("k_canopy", "leaf_scalar", "soil_ref", "w_lai", "light_update_hours",
+                                                 "recompute_lai_delta")] +
+                [(n, ctypes.c_int32) for n in ("substep_every_nphys", "albedo_couple", "bands_couple", "water_couple")])
 
 
 class qd_grid_desc(ctypes.Structure):
@@ -93,6 +103,17 @@ def load():
     lib.qd_energy_diagnostics_last.argtypes = [vp, dp]
     lib.qd_copy_ceiling.argtypes = [vp, sz, i32, dp]
     lib.qd_band_insolation.argtypes = [vp, i32, dp, dp, dp, vp]
+    ip = ctypes.POINTER(ctypes.c_int32)
+    lib.qd_eco_configure.argtypes = [vp, ctypes.POINTER(qd_eco_params), sz]
+    lib.qd_eco_set_lai_layers.argtypes = [vp, vp, i32, i32]
+    lib.qd_eco_substep.argtypes = [vp, dbl]
+    lib.qd_eco_banded_alpha.argtypes = [vp, i32, dp, dp]
+    lib.qd_eco_get_state.argtypes = [vp, dp]
+    lib.qd_eco_set_state.argtypes = [vp, dp]
+    lib.qd_indiv_configure.argtypes = [vp, i32, ip, ip, i32, ip, vp, vp, i32, dp, dp, dp, i32, dbl, dbl]
+    lib.qd_indiv_substep.argtypes = [vp, dbl, ip]
+    lib.qd_indiv_download.argtypes = [vp, vp, vp]
+    lib.qd_indiv_upload.argtypes = [vp, vp, vp]
     lib.qd_comm_unique_id.argtypes = [vp, sz]
     lib.qd_comm_init.argtypes = [vp, vp, sz]
     lib.qd_comm_barrier.argtypes = [vp]

@@ -295,6 +295,7 @@ extern "C" int qd_destroy(qd_handle c) {
     if (c->dcount) hipFree(c->dcount); if (c->hist) hipFree(c->hist); if (c->sel_state) hipFree(c->sel_state);
     if (c->zonal_tw) hipFree(c->zonal_tw);
     if (c->bands) hipFree(c->bands);
+    qd_eco_free(c);
     if (c->sel_cand) hipFree(c->sel_cand); if (c->sel_ccount) hipFree(c->sel_ccount);
     if (c->hpin) hipHostFree(c->hpin);
     if (c->hpin_rows) hipHostFree(c->hpin_rows);
@@ -311,7 +312,7 @@ extern "C" const char* qd_last_error(qd_handle c) { return c ? c->err.c_str() : 
 // ------------------------------------------------------------------ upload / download
 // Host arrays are GLOBAL [n_lat][n_lon]; the handle copies its band (+ halo rows, period-n_lat
 // at the poles) in, and its owned rows out.
-static int band_copy_in(qd_ctx* c, void* dst, const void* host, size_t esz) {
+int qd_band_copy_in(qd_ctx* c, void* dst, const void* host, size_t esz) {
     const QdGeom& G = c->geo;
     const size_t rowb = (size_t)G.nlon * esz;
     if (G.full) return hipMemcpyAsync(dst, host, rowb * G.nlat, hipMemcpyHostToDevice, c->stream) == hipSuccess ? 0 : -1;
@@ -331,15 +332,18 @@ extern "C" int qd_upload(qd_handle c, int field, const void* host, size_t bytes)
     if (field == QD_F_LAND_MASK || field == QD_F_ICE_MASK) {
         if (bytes != n) return qd_fail(c, "qd_upload: mask size mismatch");
         uint8_t* dst = field == QD_F_LAND_MASK ? c->land : c->icemask;
-        if (band_copy_in(c, dst, host, 1)) return qd_fail(c, "qd_upload: copy failed");
+        if (qd_band_copy_in(c, dst, host, 1)) return qd_fail(c, "qd_upload: copy failed");
         qd_mark(c, {dst}, c->geo.halo);
     } else {
         if (field < 0 || field >= QD_F_COUNT_F64) return qd_fail(c, "qd_upload: unknown field");
         if (bytes != n * sizeof(double)) return qd_fail(c, "qd_upload: size mismatch (expect n_lat*n_lon float64)");
-        if (band_copy_in(c, c->f[field], host, sizeof(double))) return qd_fail(c, "qd_upload: copy failed");
+        if (qd_band_copy_in(c, c->f[field], host, sizeof(double))) return qd_fail(c, "qd_upload: copy failed");
         qd_mark(c, {c->f[field]}, c->geo.halo);
         if (field == QD_F_CLOUD_EFF) c->cloud_eff_valid = 1;
         if (field == QD_F_ELEVATION) c->has_elevation = 1;
+        if (field == QD_F_ECO_ALPHA) c->eco.alpha_valid = 1;          // a map computed elsewhere (restart, host ecology)
+        if (field == QD_F_ECO_ALPHA_BANDED) c->eco.banded_valid = 1;
+        if (field == QD_F_WATER_ALPHA) c->eco.water_valid = 1;
     }
     QD_HIP(c, hipStreamSynchronize(c->stream));    // host buffer is only borrowed for the call
     if (field == QD_F_LAND_MASK) {
@@ -461,9 +465,15 @@ extern "C" int qd_step_n(qd_handle c, int n, double dt, int flags, const double*
     if (!c || !stars) return -1;
     hipSetDevice(c->desc.device);
     const int with_ocean = flags & 1, with_phys = flags & 2, pass_alb = flags & 4, with_hydro = flags & 8, want_diag = flags & 16;
+    const int with_eco = flags & 32;
+    if (with_eco && !with_phys) return qd_fail(c, "qd_step_n: the ecology sub-step (bit5) needs the driver physics (bit1)");
+    if (with_eco && !c->eco.configured) return qd_fail(c, "qd_step_n: bit5 set but qd_eco_configure has not been called");
     for (int s = 0; s < n; ++s) {
         const double* st = stars + (size_t)7 * s;
         int rc;
+        // EcologyAdapter.step_subdaily sits between the glacier mask and the base-albedo blend (run_simulation.py:2075-2104):
+        // its clock / canopy / alpha part runs before the albedo kernel, its E_day += isr dt rides on this step's forcing launch
+        if (with_eco && c->eco.p.albedo_couple) { if ((rc = qd_eco_canopy_impl(c, dt))) return rc; c->eco.eday_dt = dt; }
         if (with_phys) { if ((rc = qd_driver_physics_impl(c, dt))) return rc; }
         else if ((rc = qd_simple_albedo_impl(c, 0.08))) return rc;
         if ((rc = qd_forcing_impl(c, st, st + 3, st[6], 1))) return rc;
@@ -472,6 +482,8 @@ extern "C" int qd_step_n(qd_handle c, int n, double dt, int flags, const double*
         // fluxes of the coupling block (run_simulation.py:2199-2246) -- and kept for qd_energy_diagnostics_last
         if (with_ocean && want_diag && s == 0 && (rc = qd_energy_diag_impl(c, c->last_diag))) return rc;
         if (with_ocean && (rc = qd_ocean_step_impl(c, dt, 1, 1, 1))) return rc;
+        // IndividualPool.try_substep reads this step's isr_A / isr_B and W_land before the bucket update (run_simulation.py:2021-2046)
+        if (with_eco && c->eco.n_indiv > 0 && (rc = qd_indiv_substep_impl(c, dt, nullptr))) return rc;
         if (with_hydro && (rc = qd_hydrology_commit_impl(c, dt))) return rc;
     }
     hipError_t e = hipGetLastError();
@@ -481,7 +493,7 @@ extern "C" int qd_step_n(qd_handle c, int n, double dt, int flags, const double*
 
 // ------------------------------------------------------------------ operator seam
 static int seam_in(qd_ctx* c, double* dst, const double* host) {
-    if (band_copy_in(c, dst, host, sizeof(double))) return qd_fail(c, "operator seam: upload failed");
+    if (qd_band_copy_in(c, dst, host, sizeof(double))) return qd_fail(c, "operator seam: upload failed");
     return 0;
 }
 static int seam_out(qd_ctx* c, const double* src, double* host) {

@@ -217,7 +217,7 @@ struct QdStar { double flux, sin_d, cos_d, alpha; };
 __global__ void __launch_bounds__(QD_BLOCK)
 k_forcing(QdGeom G, QdTabs T, QdStar A, QdStar B, double theta, double sigma, int with_teq,
           double* __restrict__ isrA, double* __restrict__ isrB, double* __restrict__ isr,
-          const double* __restrict__ albedo, double* __restrict__ Teq) {
+          const double* __restrict__ albedo, double* __restrict__ Teq, double* __restrict__ eday, double eday_dt) {
     const QdTile tl = qd_tile();
     const int j = tl.seg * QD_BLOCK + threadIdx.x;
     if (j >= G.nlon) return;
@@ -231,6 +231,7 @@ k_forcing(QdGeom G, QdTabs T, QdStar A, QdStar B, double theta, double sigma, in
     const double a_ = A.flux * czA, b_ = B.flux * czB;
     const double tot = a_ + b_;
     isrA[o] = a_; isrB[o] = b_; isr[o] = tot;
+    if (eday) eday[o] += qd_nn(tot) * eday_dt;                 // PopulationManager.step_subdaily (population.py:267-268)
     if (with_teq) {
         double num = tot * (1 - albedo[o]);
         if (num < 0) num = 0;
@@ -246,7 +247,9 @@ int qd_forcing_impl(qd_ctx* c, const double* sa, const double* sb, double theta,
     if (m < 0) return -1;
     QD_ROWS(c, m, G, hipLaunchKernelGGL(k_forcing, qd_grid2d(G), dim3(QD_BLOCK), 0, c->stream, G, c->tabs, A, B, theta,
                                         5.670374e-8, with_teq, c->f[QD_F_ISR_A], c->f[QD_F_ISR_B], c->f[QD_F_ISR],
-                                        c->f[QD_F_ALBEDO], c->f[QD_F_TEQ]));
+                                        c->f[QD_F_ALBEDO], c->f[QD_F_TEQ], c->eco.eday_dt > 0 ? c->f[QD_F_ECO_EDAY] : (double*)nullptr,
+                                        c->eco.eday_dt));
+    c->eco.eday_dt = 0;
     qd_mark(c, {c->f[QD_F_ISR_A], c->f[QD_F_ISR_B], c->f[QD_F_ISR]}, m);
     if (with_teq) qd_mark(c, {c->f[QD_F_TEQ]}, m);
     return 0;

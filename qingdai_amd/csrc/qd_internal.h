@@ -120,6 +120,26 @@ __device__ __forceinline__ QdTile qd_tile() {
 }
 
 // ---------------------------------------------------------------- host context
+// ecology sub-step: clocks and cache flags of PopulationManager / EcologyAdapter / IndividualPool (qd_eco.hip)
+#define QD_MAXBANDS 32
+struct QdEco {
+    qd_eco_params p{0.5, 0.3, 0.20, 1.0, 6.0, 0.05, 1, 0, 0, 0};
+    int configured = 0;
+    double hours = 0, next_h = 6.0;
+    int64_t count = 0;
+    int have_lai = 0, f_valid = 0, alpha_valid = 0, alpha_dirty = 1, banded_valid = 0, water_valid = 0;
+    int lai_version = 0, snap_version = 0, n_recompute = 0;
+    double eday_dt = 0;              // > 0: the next forcing launch adds nan_to_num(isr) * eday_dt to ECO_EDAY
+    // individuals
+    int n_cells = 0, n_indiv = 0, nb = 0, k_per_day = 10;
+    int32_t *sample_j = nullptr, *sample_i = nullptr, *cell = nullptr;
+    double *Ab = nullptr;            // [nb][n_indiv] (band-major: consecutive individuals are consecutive in memory)
+    double *tol = nullptr, *E_day = nullptr, *stress = nullptr;
+    double specA[QD_MAXBANDS], specB[QD_MAXBANDS], tray[QD_MAXBANDS];
+    double day_seconds = 0, soil_cap = 50.0, period = -1.0, accum = 0;
+    int64_t n_fired = 0;
+};
+
 struct QdTimer { double total_ms = 0; int64_t n = 0; };
 struct QdTileShape { int tr, tc, ntr, ntc; };
 
@@ -151,6 +171,7 @@ struct qd_ctx {
     int bands_nb = 0;
     double last_diag[10] = {0};      // energy-budget means taken inside qd_step_n (flags bit 4)
     int has_elevation = 0;           // an ELEVATION map has been uploaded (orographic factor needs one)
+    QdEco eco;                       // ecology sub-step state
     double* zonal_tw = nullptr;      // [2][nlon] cos / sin(2 pi m / nlon) of the zonal spectral filter
     double* sel_cand = nullptr;      // [2][cells] candidates of the two middle ranks after two radix passes (whole-globe handles)
     unsigned int* sel_ccount = nullptr; // [2] candidate counts
@@ -252,6 +273,13 @@ int  qd_energy_diag_impl(qd_ctx* c, double* host_out);    // qd_ocean.hip
 int  qd_band_insolation_impl(qd_ctx* c, int nb, const double* specA, const double* specB, const double* tray, double* out_host);   // qd_physics.hip
 int  qd_zonal_filter_fields(qd_ctx* c, double** fields, int nf, double cutoff, double damp, int m);
 int  qd_adv_reach(const qd_ctx* c, double dt, double vmax);
+
+// qd_eco.hip
+int  qd_eco_canopy_impl(qd_ctx* c, double dt);            // clock + recompute policy + alpha map (no E_day)
+int  qd_eco_eday_impl(qd_ctx* c, double dt);              // E_day += nan_to_num(ISR) dt as its own launch
+int  qd_indiv_substep_impl(qd_ctx* c, double dt, int* fired);
+void qd_eco_free(qd_ctx* c);
+int  qd_band_copy_in(qd_ctx* c, void* dst, const void* host, size_t esz);   // qd_api.hip
 
 // qd_reduce.hip
 int qd_reduce_field(qd_ctx* c, const double* x, int op, double* host_out);

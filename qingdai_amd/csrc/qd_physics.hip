@@ -176,14 +176,15 @@ k_cloud_blend(QdGeom G, QdBlendP P, const double* __restrict__ cfp, const double
     cloud[o] = qd_clip(c, 0.0, 1.0);
 }
 
-struct QdAlbP { double alpha, hice_ref_safe, alpha_ice, alpha_cloud, alpha_water, alpha_snow; int do_adv, use_topo, snow; };
+struct QdAlbP { double alpha, hice_ref_safe, alpha_ice, alpha_cloud, alpha_water, alpha_snow, w_lai; int do_adv, use_topo, snow, eco, banded, water; };
 
 // cloud <- clip((1-a) cloud + a adv, 0, 1)  and  the dynamic albedo (physics.py:164-250)
 __global__ void __launch_bounds__(QD_BLOCK)
 k_cloud_albedo(QdGeom G, QdAlbP P, const double* __restrict__ adv, double* __restrict__ cloud,
                const double* __restrict__ cloud_eff, const double* __restrict__ hice,
                const double* __restrict__ base, const uint8_t* __restrict__ land, const double* __restrict__ csnow,
-               double* __restrict__ albedo) {
+               const double* __restrict__ eco_alpha, const double* __restrict__ glacier, const double* __restrict__ banded,
+               const double* __restrict__ water, double* __restrict__ albedo) {
     const QdTile tl = qd_tile();
     const int j = tl.seg * QD_BLOCK + threadIdx.x;
     if (j >= G.nlon) return;
@@ -196,6 +197,18 @@ k_cloud_albedo(QdGeom G, QdAlbP P, const double* __restrict__ adv, double* __res
     double fi = qd_clip(ice_frac, 0.0, 1.0);
     fi = fi * ((land[o] == 0) ? 1.0 : 0.0);
     double b0 = P.use_topo ? base[o] : P.alpha_water;
+    if (P.eco && land[o] == 1 && glacier[o] == 0.0) {        // run_simulation.py:2086-2100: ecology alpha, not on ice sheets
+        const double ae = eco_alpha[o];
+        if (fabs(ae) <= DBL_MAX) b0 = (1.0 - P.w_lai) * b0 + P.w_lai * ae;
+    }
+    if (P.banded && land[o] == 1) {                          // run_simulation.py:2107-2112: daily banded alpha
+        const double ab = banded[o];
+        if (fabs(ab) <= DBL_MAX) b0 = qd_clip(ab, 0.0, 1.0);
+    }
+    if (P.water && land[o] == 0) {                           // run_simulation.py:2121-2128: ocean colour
+        const double aw = water[o];
+        if (fabs(aw) <= DBL_MAX) b0 = qd_clip(aw, 0.0, 1.0);
+    }
     if (P.snow && land[o] == 1) {                            // run_simulation.py:2130-2141: snow cover over land
         const double cs = csnow[o];
         b0 = qd_clip((1.0 - cs) * b0 + cs * P.alpha_snow, 0.0, 1.0);
@@ -469,8 +482,14 @@ int qd_driver_physics_impl(qd_ctx* c, double dt) {
         }
         if (m < 0) return -1;
         if (c->cloud_eff_valid) { const int me = qd_plan(c, {QD_IN(F[QD_F_CLOUD_EFF], 0)}); if (me < 0) return -1; m = std::min(m, me); }
-        QdAlbP A{p.cloud_adv_alpha, std::max(1e-6, p.hice_ref), p.alpha_ice, p.alpha_cloud, p.alpha_water, p.snow_albedo_fresh,
-                 p.cloud_advect ? 1 : 0, p.use_topo_albedo ? 1 : 0, p.swe_enable ? 1 : 0};
+        const QdEco& E = c->eco;
+        QdAlbP A{p.cloud_adv_alpha, std::max(1e-6, p.hice_ref), p.alpha_ice, p.alpha_cloud, p.alpha_water, p.snow_albedo_fresh, E.p.w_lai,
+                 p.cloud_advect ? 1 : 0, p.use_topo_albedo ? 1 : 0, p.swe_enable ? 1 : 0,
+                 (E.configured && E.p.albedo_couple && E.alpha_valid) ? 1 : 0, (E.configured && E.p.bands_couple && E.banded_valid) ? 1 : 0,
+                 (E.configured && E.p.water_couple && E.water_valid) ? 1 : 0};
+        if (A.eco) { const int me = qd_plan(c, {QD_IN(F[QD_F_ECO_ALPHA], 0)}); if (me < 0) return -1; m = std::min(m, me); }
+        if (A.banded) { const int me = qd_plan(c, {QD_IN(F[QD_F_ECO_ALPHA_BANDED], 0)}); if (me < 0) return -1; m = std::min(m, me); }
+        if (A.water) { const int me = qd_plan(c, {QD_IN(F[QD_F_WATER_ALPHA], 0)}); if (me < 0) return -1; m = std::min(m, me); }
         // P019 lapse + phase split + provisional snowpack (run_simulation.py:1946-2019): pointwise
         {
             const int msn = qd_plan(c, {QD_IN(F[QD_F_PRECIP], 0), QD_IN(F[QD_F_H], 0), QD_IN(F[QD_F_S_SNOW], 0), QD_IN(F[QD_F_ELEVATION], 0)});
@@ -490,7 +509,8 @@ int qd_driver_physics_impl(qd_ctx* c, double dt) {
         }
         QD_ROWS(c, m, G, hipLaunchKernelGGL(k_cloud_albedo, qd_grid2d(G), blk, 0, c->stream, G, A, adv, F[QD_F_CLOUD],
                                             c->cloud_eff_valid ? F[QD_F_CLOUD_EFF] : (const double*)nullptr, F[QD_F_HICE],
-                                            F[QD_F_BASE_ALBEDO], c->land, F[QD_F_C_SNOW], F[QD_F_ALBEDO]));
+                                            F[QD_F_BASE_ALBEDO], c->land, F[QD_F_C_SNOW], F[QD_F_ECO_ALPHA], F[QD_F_GLACIER],
+                                            F[QD_F_ECO_ALPHA_BANDED], F[QD_F_WATER_ALPHA], F[QD_F_ALBEDO]));
         qd_mark(c, {F[QD_F_CLOUD], F[QD_F_ALBEDO]}, m);
     }
     return 0;
@@ -501,7 +521,6 @@ int qd_driver_physics_impl(qd_ctx* c, double dt) {
 // dual_star_insolation_to_bands (pygcm/ecology/spectral.py:397-426): per cell S_b = (specA_b insA + specB_b insB) T_ray_b,
 // S_sum = sum_b S_b (in band order, like np.sum(axis=0)), I_b = S_b / S_sum * (insA + insB) where S_sum > 1e-12 and
 // insA + insB > 1e-12, else 0; non-finite -> 0.  One thread per cell, bands in registers (NB <= QD_MAXBANDS).
-#define QD_MAXBANDS 32
 struct QdBandW { double a[QD_MAXBANDS], b[QD_MAXBANDS], t[QD_MAXBANDS]; int nb; };
 __global__ void __launch_bounds__(QD_BLOCK)
 k_band_insolation(QdGeom G, QdBandW W, const double* __restrict__ insA, const double* __restrict__ insB, double* __restrict__ out,

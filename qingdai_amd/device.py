@@ -129,14 +129,15 @@ class Device:
         self.flush()
         self._chk(self.lib.qd_hydrology_commit(self.h, float(dt)), "qd_hydrology_commit")
 
-    def step_n(self, stars, dt, with_ocean=False, with_physics=False, pass_albedo=True, with_hydrology=False, energy_diag=False):
+    def step_n(self, stars, dt, with_ocean=False, with_physics=False, pass_albedo=True, with_hydrology=False, energy_diag=False,
+               ecology=False):
         """benchmark_jax.py:124-158 as one resident loop (qd_step_n).  `stars`: [n][7] host
         scalars from ThermalForcing.star_table()."""
         self.flush()
         st = np.ascontiguousarray(stars, dtype=np.float64)
         assert st.ndim == 2 and st.shape[1] == 7
         flags = ((1 if with_ocean else 0) | (2 if with_physics else 0) | (4 if pass_albedo else 0) | (8 if with_hydrology else 0) |
-                 (16 if energy_diag else 0))
+                 (16 if energy_diag else 0) | (32 if ecology else 0))
         self._chk(self.lib.qd_step_n(self.h, int(st.shape[0]), float(dt), flags,
                                      st.ctypes.data_as(ctypes.POINTER(ctypes.c_double))), "qd_step_n")
 

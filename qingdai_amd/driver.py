@@ -9,7 +9,11 @@ procedural seed-42 or NetCDF topography, slab-ocean heat capacities, restart loa
 C_snow land_mask as f4 + scalar t_seconds, run_simulation.py:63-183), SIGINT/SIGTERM/atexit autosave
 (run_simulation.py:1689-1706, exit codes 130/143), QD_SIM_DAYS / QD_TOTAL_YEARS / QD_DT_SECONDS,
 QD_USE_OCEAN, the QD_USE_OO(_STRICT) short-circuit, periodic diagnostics.
-Not carried over (out of the hot path): ecology, phytoplankton, river routing,
+Ecology (QD_ECO_ENABLE, default on like the reference): the per-step part -- EcologyAdapter.step_subdaily, the alpha blend
+into the base albedo, IndividualPool.try_substep -- runs inside the resident loop (qingdai_amd/ecology.py, qd_eco_*); the
+DAILY population dynamics are host code outside this package, reached through `Simulation(daily_hook=...)`, which is called
+where the reference calls eco.step_daily (run_simulation.py:1786-1864).  Without a hook the LAI stays at its initial value.
+Not carried over (out of the hot path): phytoplankton daily step, river routing, genes / diversity,
 matplotlib panels (a note is printed instead of a plot).
 
 Per iteration (run_simulation.py:1760-2340), all on the device through one qd_step_n call per chunk:
@@ -98,7 +102,10 @@ def load_ocean(path):
 class Simulation:
     """The reference driver's state + loop, device resident."""
 
-    def __init__(self, n_lat=None, n_lon=None, params: QdParams | None = None, use_ocean=None, quiet=False, device=0):
+    def __init__(self, n_lat=None, n_lon=None, params: QdParams | None = None, use_ocean=None, quiet=False, device=0,
+                 ecology=None, individuals=None, daily_hook=None):
+        """ecology / individuals: None = QD_ECO_ENABLE / QD_ECO_INDIV_ENABLE (both default 1, run_simulation.py:1324,1404).
+        daily_hook(sim, soil_idx, glacier_mask): the host-side daily ecology, called at planet-day boundaries."""
         env = os.environ
         n_lat = int(n_lat if n_lat is not None else env.get("QD_N_LAT", "121"))   # run_simulation.py:1195 is 121x240
         n_lon = int(n_lon if n_lon is not None else env.get("QD_N_LON", "240"))
@@ -149,6 +156,23 @@ class Simulation:
         self.t = 0.0
         self._step_index = 0
         self.dt = int(env.get("QD_DT_SECONDS", "300"))
+        # ecology (run_simulation.py:1324-1423): adapter + canopy population + sampled individuals, state on the device
+        self.eco = self.indiv = None
+        self.daily_hook = daily_hook
+        self.day_seconds = 2 * np.pi / PLANET_OMEGA
+        self._accum_day = 0.0
+        eco_on = (int(env.get("QD_ECO_ENABLE", "1")) == 1) if ecology is None else bool(ecology)
+        if eco_on:
+            from .ecology import EcologyAdapter, IndividualPool
+            self.eco = EcologyAdapter(self.grid, self.land_mask, dev=self.dev)
+            ind_on = (int(env.get("QD_ECO_INDIV_ENABLE", "1")) == 1) if individuals is None else bool(individuals)
+            if ind_on:
+                self.indiv = IndividualPool(self.grid, self.land_mask, self.eco, sample_frac=0.02, per_cell=150,
+                                            substeps_per_day=10, day_seconds=self.day_seconds)
+            if not quiet:
+                s_ = self.eco.pop.summary()
+                print(f"[Ecology] device sub-step: NB={self.eco.bands.nbands}, alpha_leaf={self.eco.alpha_leaf_scalar:.3f}, "
+                      f"LAI mean {s_['LAI_mean']:.2f}, individuals {self.indiv.n_indiv if self.indiv else 0}")
         # banded initial surface temperature (run_simulation.py:310-328)
         if int(env.get("QD_INIT_BANDED", "0")) == 1:
             T_eq, T_pole = float(env.get("QD_INIT_T_EQ", "295.0")), float(env.get("QD_INIT_T_POLE", "265.0"))
@@ -184,11 +208,52 @@ class Simulation:
                                          self.friction, elevation=self.elevation)
 
     # -- the loop
+    def bootstrap_ecology(self):
+        """run_simulation.py:1716-1726: one step_subdaily on the t = 0 insolation before the loop starts."""
+        if self.eco is None or not self.eco.params.albedo_couple:
+            return
+        self.forcing.update_device(0.0, with_teq=False)
+        self.eco.step_subdaily(None, None, float(self.dt))
+
+    def _daily(self):
+        """The day-boundary block of run_simulation.py:1786-1864 for the ecology: soil index from W_land, zero on ice sheets."""
+        if self.daily_hook is None:
+            return
+        cap = float(os.environ.get("QD_ECO_SOIL_WATER_CAP", "50.0"))
+        for k in ("W_LAND", "GLACIER"):
+            self.dev._host.pop(k, None)
+        glacier = self.dev.get("GLACIER") != 0.0
+        soil_idx = np.clip(self.dev.get("W_LAND") / max(1e-6, cap), 0.0, 1.0) * (~glacier)
+        self.daily_hook(self, soil_idx, glacier)
+
     def run_steps(self, n):
-        """n iterations of run_simulation.py:1760-2340, one resident qd_step_n call (chunks of QD_ENERGY_TUNE_EVERY
-        steps when the greenhouse autotuner is on)."""
+        """n iterations of run_simulation.py:1760-2340 as resident qd_step_n calls: one per stretch between planet-day
+        boundaries when a daily ecology hook is installed (the hook runs where the reference runs eco.step_daily, i.e. before
+        the rest of the step that completes the day), one per QD_ENERGY_TUNE_EVERY steps when the autotuner is on."""
         if n <= 0:
             return
+        if self.eco is not None and self.daily_hook is not None:
+            left = n
+            while left > 0:
+                a, k = self._accum_day, 0                      # run_simulation.py:1784-1786: accum += dt; while accum >= day
+                while k < left and a + self.dt < self.day_seconds:
+                    a += self.dt
+                    k += 1
+                if k > 0:
+                    self._run_span(k)
+                    self._accum_day = a
+                    left -= k
+                    continue
+                self._accum_day += self.dt
+                while self._accum_day >= self.day_seconds:
+                    self._accum_day -= self.day_seconds
+                    self._daily()
+                self._run_span(1)
+                left -= 1
+            return
+        self._run_span(n)
+
+    def _run_span(self, n):
         p = self.dev.params
         autotune = (int(p.gh_lock) == 0) and int(os.environ.get("QD_ENERGY_AUTOTUNE", "0")) == 1 and self.ocean is not None
         if autotune:                                           # run_simulation.py:1256-1257, 2242-2246
@@ -214,7 +279,7 @@ class Simulation:
         times = self.t + self.dt * np.arange(n)
         stars = self.forcing.star_table(times)
         self.dev.step_n(stars, float(self.dt), with_ocean=self.ocean is not None, with_physics=True, pass_albedo=False,
-                        with_hydrology=True, energy_diag=energy_diag)
+                        with_hydrology=True, energy_diag=energy_diag, ecology=self.eco is not None)
         self.t = float(times[-1] + self.dt)
         self._step_index += n
 
@@ -250,6 +315,7 @@ def main(argv=None):
             sim.t = float(env["QD_ORBIT_EPOCH_SECONDS"])
         elif env.get("QD_ORBIT_EPOCH_DAYS"):
             sim.t = float(env["QD_ORBIT_EPOCH_DAYS"]) * day
+    sim.bootstrap_ecology()
     t0 = sim.t
     n_total = len(np.arange(t0, t0 + duration, sim.dt))
     print(f"Grid resolution: {sim.grid.n_lat} lat x {sim.grid.n_lon} lon | dt = {sim.dt} s | "

@@ -92,3 +92,34 @@ def dual_star_insolation_to_bands(dev, bands, download=True, **star_kw):
     dev._chk(dev.lib.qd_band_insolation(dev.h, int(bands.nbands), specA.ctypes.data_as(dp), specB.ctypes.data_as(dp),
                                         tray.ctypes.data_as(dp), out.ctypes.data if download else None), "qd_band_insolation")
     return out
+
+
+def band_weights_from_mode(bands, mode=None):
+    """Normalised reduction weights w_b (spectral.py:138-162): flat, or the Rayleigh factor, over its sum + 1e-12."""
+    mode = (mode or os.getenv("QD_ECO_TOA_TO_SURF_MODE", "simple")).strip().lower()
+    if mode == "rayleigh":
+        t0 = float(os.getenv("QD_ECO_RAYLEIGH_T0", "0.9"))
+        lref = float(os.getenv("QD_ECO_RAYLEIGH_LREF_NM", "550"))
+        eta = float(os.getenv("QD_ECO_RAYLEIGH_ETA", "4.0"))
+        w = np.clip(t0 * (np.maximum(1e-6, bands.lambda_centers) / max(1e-6, lref)) ** eta, 0.0, None)
+    else:
+        w = np.ones_like(bands.lambda_centers, dtype=float)
+    return w / (float(np.sum(w)) + 1e-12)
+
+
+def default_leaf_reflectance(bands):
+    """Green-ish leaf template (spectral.py:70-82,165-169): 0.25 + 0.15 exp(-(lam - 550)^2 / (2 60^2)), clipped to [0, 1]."""
+    lam = np.asarray(bands.lambda_centers, dtype=float)
+    return np.clip(0.25 + 0.15 * np.exp(-((lam - 550.0) ** 2) / (2.0 * 60.0 ** 2)), 0.0, 1.0)
+
+
+def absorbance_from_peaks(bands, peaks):
+    """Band absorbance of a list of (center_nm, width_nm, height) Gaussian peaks (genes.py:95-111): peaks with a non-positive
+    width or height are skipped, the sum is clipped to [0, 1]."""
+    lam = np.asarray(bands.lambda_centers, dtype=float)
+    A = np.zeros_like(lam)
+    for (c, w, h) in peaks:
+        if w <= 0 or h <= 0:
+            continue
+        A += h * np.exp(-((lam - c) ** 2) / (2 * (w ** 2)))
+    return np.clip(A, 0.0, 1.0)

@@ -10,7 +10,7 @@ from qingdai_amd.driver import Simulation
 import qingdai_amd as qa
 from util import relerr
 nlat, nlon, nsteps = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
-sim = Simulation(nlat, nlon, params=qa.QdParams(), use_ocean=True, quiet=True)
+sim = Simulation(nlat, nlon, params=qa.QdParams(), use_ocean=True, quiet=True, ecology=False)
 g = qo.Grid(nlat, nlon); P = qo.defaults()
 m = qo.AtmosOracle(g, sim.friction, sim.land_mask, P, C_s_map=np.where(sim.land_mask == 1, 3e6, P.Cs_ocean).astype(float))
 oc = qo.OceanOracle(g, sim.land_mask, P, init_Ts=np.full((nlat, nlon), 288.0))

@@ -138,3 +138,67 @@ def test_nonfinite_values_fall_back_to_the_exact_path(gpu, monkeypatch):
             far[np.ix_(ii, jj)] = False
         bad = ~np.isclose(fast[k], unfused[k], rtol=1e-7, atol=0.0, equal_nan=True) & far
         assert not bad.any(), (k, np.argwhere(bad)[:5], fast[k][bad][:5], unfused[k][bad][:5])
+
+
+def test_bands_ecology_substep(gpu, monkeypatch):
+    """The ecology sub-step (qd_step_n bit5) on 3 latitude bands against the whole-globe handle: the LAI-change ratio is a
+    band-wise sum (all-reduced), the alpha blend and E_day are pointwise, each sampled individual is advanced by the band
+    that owns its cell (no exchange); the per-band energy arrays add up to the whole-globe one."""
+    import os
+    from qingdai_amd.bands import BandGroup
+    from qingdai_amd.device import Device
+    from qingdai_amd.ecology import EcologyAdapter, IndividualPool
+    for k in list(os.environ):
+        if k.startswith("QD_ECO_"):
+            monkeypatch.delenv(k)
+    for k, v in {"QD_ECO_NS": "3", "QD_ECO_SUBSTEP_EVERY_NPHYS": "2", "QD_ECO_INDIV_SAMPLE_FRAC": "0.1", "QD_ECO_INDIV_PER_CELL": "4",
+                 "QD_ECO_INDIV_SUBSTEPS_PER_DAY": "144", "QD_ECO_LAI_ALBEDO_WEIGHT": "0.7"}.items():
+        monkeypatch.setenv(k, v)
+    nlat, nlon, nsteps = 61, 96, 5
+    qa, grid, mask, alb, fric, p = _setup(nlat, nlon, dict(energy_w=1.0))
+    forcing = qa.ThermalForcing(qa.SphericalGrid(nlat, nlon), qa.OrbitalSystem())
+    stars = forcing.star_table([i * 300.0 for i in range(nsteps)])
+    st = _seed_state(nlat, nlon, 9)
+    r = np.random.default_rng(11)
+    land = (mask == 1)
+    st["W_LAND"] = np.where(land, 45.0 * r.random((nlat, nlon)), 0.0)
+    L0 = np.abs(r.normal(0.5, 0.4, (3, 1, nlat, nlon))) * land
+    L1 = L0 * (1.0 + 0.5 * r.random(L0.shape))
+    static = {"LAND_MASK": mask, "FRICTION": fric, "BASE_ALBEDO": alb}
+    names = ["ALBEDO", "ECO_EDAY", "ECO_ALPHA", "TS", "W_LAND"]
+
+    def attach(dev):
+        eco = EcologyAdapter(grid, mask, dev=dev, albedo_couple=True)
+        eco.pop.push_layers(L0, init=True)
+        return eco, IndividualPool(grid, mask, eco)
+
+    def go(dev, eco, n0, n1):
+        dev.step_n(stars[n0:n1], 300.0, with_ocean=True, with_physics=True, pass_albedo=False, with_hydrology=True, ecology=True)
+
+    dev = Device(grid, p)
+    for k, v in {**static, **st}.items():
+        dev.upload_now(k, v)
+    eco, pool = attach(dev)
+    go(dev, eco, 0, 2); eco.pop.push_layers(L1); go(dev, eco, 2, nsteps)
+    ref = {k: dev.get(k).copy() for k in names}
+    ref_E, ref_state = pool.indiv_E_day, eco.pop.state()
+    dev.close()
+    grp = BandGroup(grid, 3, p)
+    for k, v in {**static, **st}.items():
+        grp.set(k, v)
+    att = [attach(d) for d in grp.devs]
+    grp.run(lambda d, k: go(d, att[k][0], 0, 2))
+    for e_, _ in att:
+        e_.pop.push_layers(L1)
+    grp.run(lambda d, k: go(d, att[k][0], 2, nsteps))
+    got = {k: grp.get(k) for k in names}
+    got_E = sum(pl.indiv_E_day for _, pl in att)
+    states = [e_.pop.state() for e_, _ in att]
+    grp.close()
+    print(ref_state, "individual energy max", ref_E.max())
+    assert all(s == ref_state for s in states) and ref_state["n_recompute"] == 2
+    assert ref_E.max() > 0 and np.array_equal(got_E, ref_E)
+    for k in names:
+        e = relerr(np.nan_to_num(got[k]), np.nan_to_num(ref[k]))
+        assert e < 1e-12, (k, e)
+    assert np.array_equal(np.isnan(got["ECO_ALPHA"]), np.isnan(ref["ECO_ALPHA"]))

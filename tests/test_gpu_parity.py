@@ -441,7 +441,7 @@ def test_driver_loop_vs_oracle(gpu, use_ocean):
     from qd_oracle.driver import DriverOracle
     from qingdai_amd.driver import Simulation
     nlat, nlon, nsteps = 61, 96, 4
-    sim = Simulation(nlat, nlon, params=__import__("qingdai_amd").QdParams(), use_ocean=bool(use_ocean), quiet=True)
+    sim = Simulation(nlat, nlon, params=__import__("qingdai_amd").QdParams(), use_ocean=bool(use_ocean), quiet=True, ecology=False)
     lat = np.deg2rad(sim.grid.lat_mesh)
     h0 = 8000.0 - 10500.0 * np.sin(lat) ** 2                       # T_a = 263 K at the poles -> snowfall
     Ts0 = 262.0 + 36.0 * np.cos(lat) ** 2

@@ -146,6 +146,68 @@ def test_spectral_band_insolation_matches_reference():
     assert np.array_equal(specA, d["ref_specA16"]) and np.array_equal(specB, d["ref_specB16"]) and np.all(tray == 1.0)
 
 
+def test_ecology_substep_matches_reference(monkeypatch):
+    """The per-step ecology (adapter.step_subdaily over PopulationManager, banded alpha, the driver's base-albedo blend,
+    IndividualPool.try_substep): oracle against what the reference's own classes produced, bit for bit -- alpha maps on the
+    returned steps, the recompute history (first call / LAI-change ratio / clock), E_day, canopy cache, individuals."""
+    from qd_oracle import ecology as oeco, spectral as osp
+    meta, d = load_golden("eco_19x36")
+    nlat, nlon = meta["nlat"], meta["nlon"]
+    mask = d["land_mask"].astype(int)
+    ob = osp.make_bands(16, 380.0, 780.0)
+    assert oeco.leaf_scalar(ob) == meta["leaf_scalar"]
+    pop = oeco.CanopyPopulation(mask, d["L0"], k_canopy=meta["k_canopy"], light_update_every_hours=meta["every_h"],
+                                recompute_lai_delta=meta["delta"])
+    ad = oeco.EcoAdapter(pop, oeco.leaf_scalar(ob), soil_ref=meta["soil_ref"], substep_every_nphys=meta["substep_every"])
+    last = None
+    for i, st in enumerate(meta["steps"]):
+        if i == 2:
+            pop.layers = d["L1"].copy()
+        if i == 5:
+            pop.layers = d["L2"].copy()
+        a = ad.step_subdaily(d[f"insA_{i}"] + d[f"insB_{i}"], meta["dt"])
+        assert (a is not None) == st["returned"] and pop.n_recompute == st["n_recompute"], i
+        if a is not None:
+            assert np.array_equal(a, d[f"ref_alpha_{i}"], equal_nan=True), i
+            assert np.all(np.isnan(a[mask == 0])) and np.all(np.isfinite(a[mask == 1]))
+            last = a
+    assert [s["n_recompute"] for s in meta["steps"]][-1] == 3          # all three triggers are in the fixture
+    assert np.array_equal(pop.E_day, d["ref_E_day"]) and np.array_equal(pop.f_cached, d["ref_f_cached"])
+    R_eff = oeco.effective_leaf_reflectance(d["species_w"], d["R_species"])
+    A = pop.surface_albedo_bands(R_eff, meta["soil_ref"])
+    assert np.array_equal(A, d["ref_A_bands"], equal_nan=True)
+    assert np.array_equal(oeco.band_weights(ob), d["ref_w_b"])
+    assert np.array_equal(oeco.banded_alpha(A, oeco.band_weights(ob)), d["ref_alpha_banded"])
+    # the driver's blend around the reference's calculate_dynamic_albedo
+    land = (mask == 1)
+    base_in = oeco.blend_base_albedo(d["base_albedo"].copy(), land, d["glacier"].astype(bool), last, meta["w_lai"])
+    base_in[land] = np.clip((1.0 - d["C_snow"][land]) * base_in[land] + d["C_snow"][land] * meta["alpha_snow"], 0.0, 1.0)
+    ice_frac = 1.0 - np.exp(-np.maximum(d["h_ice"], 0.0) / 0.5)
+    alb = oph.calculate_dynamic_albedo(d["cloud"], d["Ts"], base_in, 0.6, 0.5, land_mask=mask, ice_frac=ice_frac)
+    assert np.array_equal(alb, d["ref_albedo_blend"])
+    # individuals
+    ind = oeco.IndividualSubstep(d["ind_sample_j"], d["ind_sample_i"], d["ind_cell"], d["ind_Ab"], d["ind_tol"], meta["ind_k"])
+    of = qo.Forcing(qo.Grid(nlat, nlon))
+    fired = []
+    for i in range(30):
+        a_, b_ = of.insolation_components(i * meta["ind_dt"])
+        if i in meta["ind_fired"]:
+            assert np.array_equal(a_, d[f"ind_insA_{i}"]) and np.array_equal(b_, d[f"ind_insB_{i}"])
+        if ind.try_substep(a_, b_, ob, d["ind_soil"], meta["ind_dt"], meta["ind_day"]):
+            fired.append(i)
+    assert fired == meta["ind_fired"]
+    assert np.array_equal(ind.E_day, d["ref_ind_E_day"]) and np.array_equal(ind.stress_days, d["ref_ind_stress"])
+    assert ind.E_day.max() > 0 and ind.stress_days.max() > 0
+    # the product's host-side tables (qingdai_amd.spectral) equal the reference's
+    from qingdai_amd import spectral as psp
+    pb = psp.make_bands(16, 380.0, 780.0)
+    monkeypatch.delenv("QD_ECO_TOA_TO_SURF_MODE", raising=False)
+    assert np.array_equal(psp.band_weights_from_mode(pb), d["ref_w_b"])
+    assert float(np.sum(psp.default_leaf_reflectance(pb) * psp.band_weights_from_mode(pb))) == meta["leaf_scalar"]
+    R0 = np.clip(1.0 - psp.absorbance_from_peaks(pb, [(450.0, 40.0, 0.6), (680.0, 30.0, 0.8)]), 0.0, 1.0)
+    assert np.array_equal(np.tile(R0, (d["R_species"].shape[0], 1)), d["R_species"])
+
+
 def test_nonfinite_inputs_match_reference():
     """NaN / +-inf in the inputs: the oracle scrubs (and lets through) exactly where the reference does -- its own
     _laplacian_sphere / _hyperdiffuse / _shapiro_filter and two whole time_steps on a poisoned state, NaN-aware bit equality."""
