@@ -106,6 +106,45 @@ def cpu_baseline(nlat, nlon, with_ocean, budget_s=20.0):
                       f"NumPy is single-threaded, {os.cpu_count()} host cores available"}
 
 
+def ecology_leg(dev, grid, mask, forcing, dt, W, K):
+    """ms/step of the driver loop (physics + ocean + hydrology) without and with the ecology sub-step (qd_step_n bit5):
+    default population (QD_ECO_NS=20 species), 16 bands, 2 % of the land cells x 150 sampled individuals."""
+    from qingdai_amd.ecology import EcologyAdapter, IndividualPool
+    stars = forcing.star_table([i * dt for i in range(W + K)])
+
+    def run(eco_on, n):
+        dev.sync()
+        t0 = time.perf_counter()
+        dev.step_n(stars[:n], dt, with_ocean=True, with_physics=True, pass_albedo=False, with_hydrology=True, ecology=eco_on)
+        dev.sync()
+        return (time.perf_counter() - t0) / n * 1e3, dev.last_ocean_nsub()
+    eco = EcologyAdapter(grid, mask, dev=dev, albedo_couple=True)
+    pool = IndividualPool(grid, mask, eco, sample_frac=0.02, per_cell=150, substeps_per_day=10)
+    t0 = time.perf_counter()
+    eco.pop.push_layers()                                   # what the daily step costs the device side: the LAI stack upload + sum
+    dev.sync()
+    up_ms = (time.perf_counter() - t0) * 1e3
+    run(True, W)
+    # the ocean's sub-step count drifts with the state, so the two loops alternate (A B A B) and each is averaged
+    h = max(1, K // 2)
+    legs = [run(False, h), run(True, h), run(False, h), run(True, h)]
+    # compare a neighbouring pair that ran with the same sub-step count (else the first pair)
+    pair = next(((a, b) for a, b in ((legs[0], legs[1]), (legs[2], legs[1]), (legs[2], legs[3])) if a[1] == b[1]), (legs[0], legs[1]))
+    base, with_eco = pair[0][0], pair[1][0]
+    dev.timing(select="eco_indiv,eco_canopy")
+    run(True, min(240, W + K))                              # one planet-day: 10 individual sub-steps at the default K = 10
+    ind_ms, ind_n = dev.timing_get("eco_indiv")
+    can_ms, can_n = dev.timing_get("eco_canopy")
+    dev.timing(on=False)
+    st = eco.pop.state()
+    return {"ms_per_step": with_eco, "individual_substep_kernel_ms": ind_ms, "individual_substeps_timed": ind_n,
+            "canopy_policy_launch_ms": can_ms, "canopy_policy_launches_timed": can_n, "ms_per_step_without_ecology": base, "bands": int(eco.bands.nbands),
+            "species_planes": int(eco.pop.LAI_layers_SK.shape[0] * eco.pop.LAI_layers_SK.shape[1]),
+            "individuals": int(pool.n_indiv), "lai_stack_upload_ms_per_day": up_ms, "canopy_recomputes": st["n_recompute"],
+            "ocean_n_sub_of_the_pair": pair[0][1], "legs_ms_nsub_A_B_A_B": [[round(a, 4), b] for a, b in legs],
+            "dtype": "f64", "note": "loop = driver iteration incl. hydrology commit; daily population dynamics are host code, not timed"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,6 +156,8 @@ def main():
     ap.add_argument("--no-driver-physics", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--no-ecology-leg", action="store_true",
+                    help="skip the supplementary BASELINE configs[4] measurement (16-band ecology sub-step in the loop)")
     ap.add_argument("--profile-kernel", default="k_dyn_hyper",
                     help="kernel whose HIP-event time feeds `roofline` (k_dyn_hyper: the fused dynamics + del^4 kernel)")
     args = ap.parse_args()
@@ -215,6 +256,13 @@ def main():
                     out["roofline_ocean_substep"]["traffic"] = val["traffic_bytes"]
     except Exception:
         pass
+    # supplementary, outside the timed region: the same grid with the driver's full iteration (+ hydrology commit) and the
+    # 16-band ecology sub-step inside the resident loop (BASELINE configs[4], arithmetic in f64)
+    if rank == 0 and args.gpus == 1 and with_phys and with_ocean and not args.no_ecology_leg:
+        try:
+            out["ecology_config5"] = ecology_leg(dev, grid, mask, forcing, dt, W, K)
+        except Exception as e:       # noqa: BLE001  (never lose the main line to the supplementary leg)
+            out["ecology_config5"] = {"error": str(e)}
     if not args.no_cpu_baseline and rank == 0 and args.gpus == 1:
         out["cpu_baseline"] = cpu_baseline(args.nlat, args.nlon, with_ocean, args.cpu_budget)
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

@@ -97,3 +97,71 @@ def test_eight_bands_match_the_whole_globe(gpu):
         assert np.array_equal(got[k], ref[k]), (k, relerr(got[k], ref[k]))
     for k in ("UO", "VO", "ETA", "SST"):
         assert relerr(got[k], ref[k]) < 1e-13, k                       # band-wise order of the eta sum
+
+
+def test_ecology_substep_full_size(gpu, monkeypatch):
+    """BASELINE configs[4] at 721 x 1440: 20 species planes, 16 bands, ~6 k sampled cells x 150 individuals inside the resident
+    loop.  Properties: E_day is the step-by-step sum of isr dt (same star row every step: exact repeated addition); the alpha map
+    is NaN off land and inside [min(leaf, soil), max(leaf, soil)] on it, and equals the closed form of the uploaded LAI; the
+    albedo changes only where the blend may act (land without ice sheet); one individual sub-step equals the oracle's
+    gather + einsum on the sampled cells."""
+    import os
+    import qingdai_amd as qa
+    import qd_oracle as qo
+    from qd_oracle import ecology as oeco, spectral as osp
+    from qingdai_amd.driver import Simulation
+    for k in list(os.environ):
+        if k.startswith("QD_ECO_"):
+            monkeypatch.delenv(k)
+    monkeypatch.setenv("QD_ECO_INDIV_SUBSTEPS_PER_DAY", "80")          # period = 900 s: the third 300 s step fires
+    sim = Simulation(NLAT, NLON, params=qa.QdParams(), use_ocean=True, quiet=True)
+    land = (sim.land_mask == 1)
+    assert sim.indiv.n_indiv == int(0.02 * land.sum()) * 150 and sim.eco.pop.LAI_layers_SK.shape[:2] == (20, 1)
+    r = np.random.default_rng(3)
+    L = np.abs(r.normal(0.3, 0.3, (20, 1, NLAT, NLON))) * land
+    sim.eco.pop.push_layers(L, init=True)
+    Ltot = np.sum(L, axis=(0, 1))
+    assert np.array_equal(sim.eco.pop.total_LAI(), Ltot)
+    W0 = np.where(land, 50.0 * r.random((NLAT, NLON)), 0.0)
+    sim.dev.set("W_LAND", W0)
+    # same star row for all steps -> the resident ISR is the same field every step
+    star = sim.forcing.star_table([1.0e5])
+    n = 4
+    sim.dev.step_n(np.repeat(star, n, axis=0), 300.0, with_ocean=True, with_physics=True, pass_albedo=False, with_hydrology=False,
+                   ecology=True)
+    isr = sim.dev.get("ISR").copy()
+    acc = np.zeros_like(isr)
+    for _ in range(n):
+        acc += isr * 300.0
+    assert np.array_equal(sim.eco.pop.E_day, acc) and acc.max() > 0
+    alpha = sim.dev.get("ECO_ALPHA")
+    leaf, soil = sim.eco.params.leaf_scalar, sim.eco.params.soil_ref
+    assert np.all(np.isnan(alpha[~land])) and np.all(np.isfinite(alpha[land]))
+    assert alpha[land].min() >= min(leaf, soil) - 1e-15 and alpha[land].max() <= max(leaf, soil) + 1e-15
+    f = 1.0 - np.exp(-0.5 * np.maximum(Ltot, 0.0))
+    assert np.max(np.abs(alpha[land] - np.clip(leaf * f + (1.0 - f) * soil, 0, 1)[land])) < 1e-15
+    st = sim.eco.pop.state()
+    assert st["step_count"] == n and st["n_recompute"] == 1            # untouched layers: one canopy build, then cached
+    # individuals: exactly one sub-step fired (accum 300, 600, 900 >= 900), on this ISR and the initial W_land
+    pool = sim.indiv
+    ob = osp.make_bands(16, 380.0, 780.0)
+    oi = oeco.IndividualSubstep(pool.sample_j, pool.sample_i, pool.indiv_cell_index, pool.indiv_Ab, pool.indiv_tol, 80)
+    oi.period, oi.accum = sim.day_seconds / 80.0, sim.day_seconds / 80.0 - 300.0
+    assert oi.try_substep(sim.dev.get("ISR_A"), sim.dev.get("ISR_B"), ob, np.clip(W0 / 50.0, 0, 1), 300.0, sim.day_seconds)
+    E, S = pool.indiv_E_day, pool.indiv_water_stress_days
+    assert E.max() > 0 and relerr(E, oi.E_day) < 1e-14 and np.array_equal(S, oi.stress_days)
+    # the blend only acts on land that is not an ice sheet
+    alb_eco = sim.dev.get("ALBEDO").copy()
+    glacier = sim.dev.get("GLACIER") != 0.0
+    sim2 = Simulation(NLAT, NLON, params=qa.QdParams(), use_ocean=True, quiet=True, ecology=False)
+    sim2.dev.set("W_LAND", W0)
+    sim2.dev.step_n(star, 300.0, with_ocean=True, with_physics=True, pass_albedo=False, with_hydrology=False)
+    sim3 = Simulation(NLAT, NLON, params=qa.QdParams(), use_ocean=True, quiet=True, individuals=False)
+    sim3.eco.pop.push_layers(L, init=True)
+    sim3.dev.step_n(star, 300.0, with_ocean=True, with_physics=True, pass_albedo=False, with_hydrology=False, ecology=True)
+    a2, a3 = sim2.dev.get("ALBEDO"), sim3.dev.get("ALBEDO")
+    gl3 = sim3.dev.get("GLACIER") != 0.0
+    assert np.array_equal(a2[~land | gl3], a3[~land | gl3])
+    assert np.abs(a2 - a3)[land & ~gl3].max() > 0.01
+    for s_ in (sim, sim2, sim3):
+        s_.dev.close()
