@@ -135,9 +135,14 @@ def ecology_leg(dev, grid, mask, forcing, dt, W, K):
     run(True, min(240, W + K))                              # one planet-day: 10 individual sub-steps at the default K = 10
     ind_ms, ind_n = dev.timing_get("eco_indiv")
     can_ms, can_n = dev.timing_get("eco_canopy")
+    pool32 = IndividualPool(grid, mask, eco, sample_frac=0.02, per_cell=150, substeps_per_day=10, f32_storage=True)
+    dev.timing(select="eco_indiv")
+    run(True, min(240, W + K))
+    ind32_ms, _ = dev.timing_get("eco_indiv")
     dev.timing(on=False)
     st = eco.pop.state()
     return {"ms_per_step": with_eco, "individual_substep_kernel_ms": ind_ms, "individual_substeps_timed": ind_n,
+            "individual_substep_kernel_ms_f32_table": ind32_ms, "individual_table_bytes_f64": int(pool32.n_indiv) * int(eco.bands.nbands) * 8,
             "canopy_policy_launch_ms": can_ms, "canopy_policy_launches_timed": can_n, "ms_per_step_without_ecology": base, "bands": int(eco.bands.nbands),
             "species_planes": int(eco.pop.LAI_layers_SK.shape[0] * eco.pop.LAI_layers_SK.shape[1]),
             "individuals": int(pool.n_indiv), "lai_stack_upload_ms_per_day": up_ms, "canopy_recomputes": st["n_recompute"],

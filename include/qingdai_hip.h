@@ -213,10 +213,13 @@ int qd_eco_set_state(qd_handle h, const double in[3]);        /* hours, next rec
 
 /* IndividualPool (individuals.py:37-191): n_cells sampled land cells (row j, column i), n_indiv individuals each bound to
  * one sampled cell, with a per-band coefficient row Ab[n_indiv][nb] and a drought tolerance; band tables as in
- * qd_band_insolation.  State (E_day, water-stress days) stays resident. */
+ * qd_band_insolation.  State (E_day, water-stress days) stays resident.  ab_f32 != 0 keeps the coefficient table -- the
+ * only large array of the sub-step -- as f32 in HBM (the "f32 mixed precision" of BASELINE configs[4]); all arithmetic and
+ * the state stay f64, so results move by the f32 rounding of Ab (<= 6e-8 relative). */
 int qd_indiv_configure(qd_handle h, int n_cells, const int32_t* sample_j, const int32_t* sample_i, int n_indiv,
                        const int32_t* cell_index, const double* Ab, const double* tol, int nb, const double* specA,
-                       const double* specB, const double* tray, int substeps_per_day, double day_seconds, double soil_cap);
+                       const double* specB, const double* tray, int substeps_per_day, double day_seconds, double soil_cap,
+                       int ab_f32);
 /* IndividualPool.try_substep (individuals.py:142-191) on the resident ISR_A / ISR_B and the soil index
  * clip(W_LAND / max(1e-6, soil_cap), 0, 1) of run_simulation.py:2025-2033; *fired = 1 when a sub-step was consumed.
  * The band intensities are evaluated per sampled cell and never materialised as [NB][n_lat][n_lon]. */

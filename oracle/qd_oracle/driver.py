@@ -229,3 +229,4 @@ class DriverOracle:
         self.W_land, R_bucket = update_land_bucket(self.W_land, P_in, E_land * non_gl, P, dt)
         self.R_flux = R_bucket + melt_land * glacier
         self.C_snow, self.precip, self.albedo = C_snow, precip, albedo
+        self.glacier = glacier

@@ -110,7 +110,7 @@ def load():
     lib.qd_eco_banded_alpha.argtypes = [vp, i32, dp, dp]
     lib.qd_eco_get_state.argtypes = [vp, dp]
     lib.qd_eco_set_state.argtypes = [vp, dp]
-    lib.qd_indiv_configure.argtypes = [vp, i32, ip, ip, i32, ip, vp, vp, i32, dp, dp, dp, i32, dbl, dbl]
+    lib.qd_indiv_configure.argtypes = [vp, i32, ip, ip, i32, ip, vp, vp, i32, dp, dp, dp, i32, dbl, dbl, i32]
     lib.qd_indiv_substep.argtypes = [vp, dbl, ip]
     lib.qd_indiv_download.argtypes = [vp, vp, vp]
     lib.qd_indiv_upload.argtypes = [vp, vp, vp]

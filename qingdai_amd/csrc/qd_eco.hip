@@ -126,9 +126,10 @@ k_eco_ratio_finish(const double* __restrict__ partial, int nrows, double* __rest
 struct QdIndivW { double a[QD_MAXBANDS], b[QD_MAXBANDS], t[QD_MAXBANDS]; int nb; };
 // individuals.py:164-191 for individual i: band split of its cell's two-star insolation (spectral.py:397-426), energy
 // increment max(0, sum_b Ab[i][b] I_b * period), water-stress days where the soil index is below its tolerance
+template <typename TA>
 __global__ void __launch_bounds__(QD_BLOCK)
 k_indiv_substep(QdGeom G, QdIndivW W, int n_indiv, const int32_t* __restrict__ cell, const int32_t* __restrict__ sj,
-                const int32_t* __restrict__ si, const double* __restrict__ Ab, const double* __restrict__ tol,
+                const int32_t* __restrict__ si, const TA* __restrict__ Ab, const double* __restrict__ tol,
                 const double* __restrict__ insA, const double* __restrict__ insB, const double* __restrict__ wland,
                 double soil_cap_safe, double period, double stress_inc, double* __restrict__ E, double* __restrict__ stress) {
     const int i = blockIdx.x * QD_BLOCK + threadIdx.x;
@@ -151,7 +152,7 @@ k_indiv_substep(QdGeom G, QdIndivW W, int n_indiv, const int32_t* __restrict__ c
         if (b < W.nb) {
             double v = pos ? (S[b] / sum) * tot : 0.0;
             if (!(fabs(v) <= DBL_MAX)) v = 0.0;
-            dE += Ab[(size_t)b * n_indiv + i] * v;
+            dE += (double)Ab[(size_t)b * n_indiv + i] * v;
         }
     E[i] += qd_max(0.0, dE * period);
     const double soil = qd_clip(wland[o] / soil_cap_safe, 0.0, 1.0);
@@ -163,9 +164,9 @@ static inline dim3 flat_grid(size_t n) { return dim3((unsigned)((n + QD_BLOCK - 
 
 void qd_eco_free(qd_ctx* c) {
     QdEco& E = c->eco;
-    void* p[] = {E.sample_j, E.sample_i, E.cell, E.Ab, E.tol, E.E_day, E.stress};
+    void* p[] = {E.sample_j, E.sample_i, E.cell, E.Ab, E.Ab32, E.tol, E.E_day, E.stress};
     for (void* q : p) if (q) hipFree(q);
-    E.sample_j = E.sample_i = E.cell = nullptr; E.Ab = E.tol = E.E_day = E.stress = nullptr;
+    E.sample_j = E.sample_i = E.cell = nullptr; E.Ab = E.tol = E.E_day = E.stress = nullptr; E.Ab32 = nullptr;
     E.n_indiv = E.n_cells = 0;
 }
 
@@ -314,7 +315,8 @@ static int up(qd_ctx* c, T** dst, const T* src, size_t n) {
 
 extern "C" int qd_indiv_configure(qd_handle c, int n_cells, const int32_t* sample_j, const int32_t* sample_i, int n_indiv,
                                   const int32_t* cell_index, const double* Ab, const double* tol, int nb, const double* specA,
-                                  const double* specB, const double* tray, int substeps_per_day, double day_seconds, double soil_cap) {
+                                  const double* specB, const double* tray, int substeps_per_day, double day_seconds, double soil_cap,
+                                  int ab_f32) {
     if (!c || !sample_j || !sample_i || !cell_index || !Ab || !tol || !specA || !specB || !tray) return -1;
     hipSetDevice(c->desc.device);
     if (nb < 1 || nb > QD_MAXBANDS) return qd_fail(c, "qd_indiv_configure: 1 <= nb <= 32");
@@ -331,8 +333,10 @@ extern "C" int qd_indiv_configure(qd_handle c, int n_cells, const int32_t* sampl
     std::vector<double> abt((size_t)nb * n_indiv);              // [n_indiv][nb] -> [nb][n_indiv]
     for (int i = 0; i < n_indiv; ++i)
         for (int b = 0; b < nb; ++b) abt[(size_t)b * n_indiv + i] = Ab[(size_t)i * nb + b];
+    std::vector<float> abt32;
+    if (ab_f32) { abt32.assign(abt.begin(), abt.end()); }       // storage only: the dot product still accumulates in f64
     if (up(c, &E.sample_j, sample_j, n_cells) || up(c, &E.sample_i, sample_i, n_cells) || up(c, &E.cell, cell_index, n_indiv) ||
-        up(c, &E.Ab, abt.data(), abt.size()) || up(c, &E.tol, tol, n_indiv) || up<double>(c, &E.E_day, nullptr, n_indiv) ||
+        (ab_f32 ? up(c, &E.Ab32, abt32.data(), abt32.size()) : up(c, &E.Ab, abt.data(), abt.size())) || up(c, &E.tol, tol, n_indiv) || up<double>(c, &E.E_day, nullptr, n_indiv) ||
         up<double>(c, &E.stress, nullptr, n_indiv)) { qd_eco_free(c); return qd_fail(c, "qd_indiv_configure: device allocation / copy failed"); }
     E.n_cells = n_cells; E.n_indiv = n_indiv; E.nb = nb; E.k_per_day = std::max(1, substeps_per_day);
     for (int b = 0; b < QD_MAXBANDS; ++b) { E.specA[b] = b < nb ? specA[b] : 0.0; E.specB[b] = b < nb ? specB[b] : 0.0; E.tray[b] = b < nb ? tray[b] : 0.0; }
@@ -355,9 +359,15 @@ int qd_indiv_substep_impl(qd_ctx* c, double dt, int* fired) {
     QdIndivW W; W.nb = E.nb;
     for (int b = 0; b < QD_MAXBANDS; ++b) { W.a[b] = E.specA[b]; W.b[b] = E.specB[b]; W.t[b] = E.tray[b]; }
     const QdGeom G = qd_segments(c, 0).g[0];
-    hipLaunchKernelGGL(k_indiv_substep, dim3((E.n_indiv + QD_BLOCK - 1) / QD_BLOCK), dim3(QD_BLOCK), 0, c->stream, G, W, E.n_indiv,
-                       E.cell, E.sample_j, E.sample_i, E.Ab, E.tol, F[QD_F_ISR_A], F[QD_F_ISR_B], F[QD_F_W_LAND],
-                       std::max(1e-6, E.soil_cap), E.period, E.period / E.day_seconds, E.E_day, E.stress);
+    const dim3 grid((E.n_indiv + QD_BLOCK - 1) / QD_BLOCK);
+    if (E.Ab32)
+        hipLaunchKernelGGL(k_indiv_substep<float>, grid, dim3(QD_BLOCK), 0, c->stream, G, W, E.n_indiv, E.cell, E.sample_j, E.sample_i,
+                           (const float*)E.Ab32, E.tol, F[QD_F_ISR_A], F[QD_F_ISR_B], F[QD_F_W_LAND], std::max(1e-6, E.soil_cap),
+                           E.period, E.period / E.day_seconds, E.E_day, E.stress);
+    else
+        hipLaunchKernelGGL(k_indiv_substep<double>, grid, dim3(QD_BLOCK), 0, c->stream, G, W, E.n_indiv, E.cell, E.sample_j, E.sample_i,
+                           (const double*)E.Ab, E.tol, F[QD_F_ISR_A], F[QD_F_ISR_B], F[QD_F_W_LAND], std::max(1e-6, E.soil_cap),
+                           E.period, E.period / E.day_seconds, E.E_day, E.stress);
     E.n_fired++;
     if (fired) *fired = 1;
     return 0;

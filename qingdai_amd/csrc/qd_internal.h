@@ -134,6 +134,7 @@ struct QdEco {
     int n_cells = 0, n_indiv = 0, nb = 0, k_per_day = 10;
     int32_t *sample_j = nullptr, *sample_i = nullptr, *cell = nullptr;
     double *Ab = nullptr;            // [nb][n_indiv] (band-major: consecutive individuals are consecutive in memory)
+    float *Ab32 = nullptr;           // the same table stored as f32 (qd_indiv_configure ab_f32: BASELINE configs[4] "f32 mixed")
     double *tol = nullptr, *E_day = nullptr, *stress = nullptr;
     double specA[QD_MAXBANDS], specB[QD_MAXBANDS], tray[QD_MAXBANDS];
     double day_seconds = 0, soil_cap = 50.0, period = -1.0, accum = 0;

@@ -237,7 +237,7 @@ class IndividualPool:
     the same pool."""
 
     def __init__(self, grid, land_mask, eco_adapter, *, sample_frac=0.02, per_cell=100, substeps_per_day=10, day_seconds=None,
-                 soil_cap=None, diag=False):
+                 soil_cap=None, diag=False, f32_storage=None):
         self._dev = eco_adapter._dev
         self.land_mask = (np.asarray(land_mask) == 1)
         self.h, self.w = self.land_mask.shape
@@ -273,6 +273,8 @@ class IndividualPool:
         from .forcing import PLANET_OMEGA
         self.day_seconds = float(day_seconds) if day_seconds else 2 * np.pi / PLANET_OMEGA
         self.soil_cap = float(soil_cap) if soil_cap is not None else _envf("QD_ECO_SOIL_WATER_CAP", 50.0)
+        # QD_ECO_F32=1: keep the [N, NB] coefficient table as f32 on the device (BASELINE configs[4] "f32 mixed precision")
+        self.f32_storage = (_envi("QD_ECO_F32", 0) == 1) if f32_storage is None else bool(f32_storage)
         self.configure()
 
     def configure(self, **star_kw):
@@ -284,7 +286,7 @@ class IndividualPool:
         d._chk(d.lib.qd_indiv_configure(d.h, self.n_cells, sj.ctypes.data_as(_ip), si.ctypes.data_as(_ip), self.n_indiv,
                                         ci.ctypes.data_as(_ip), Ab.ctypes.data, tol.ctypes.data, self.nb, specA.ctypes.data_as(_dp),
                                         specB.ctypes.data_as(_dp), tray.ctypes.data_as(_dp), self.substeps_per_day,
-                                        self.day_seconds, self.soil_cap), "qd_indiv_configure")
+                                        self.day_seconds, self.soil_cap, 1 if self.f32_storage else 0), "qd_indiv_configure")
 
     def try_substep(self, isr_A=None, isr_B=None, eco_adapter=None, soil_W_land=None, dt_seconds=300.0, day_length_seconds=None):
         """individuals.py:142-191 on the resident ISR_A / ISR_B / W_LAND (arrays given here are uploaded first; `soil_W_land`

@@ -93,3 +93,17 @@ def test_topography_seed42_fingerprint():
     m = create_land_sea_mask(qo.Grid(181, 360))
     assert int(m.sum()) == 16242
     assert hashlib.sha1(m.tobytes()).hexdigest().startswith("17de315c9bb5")
+
+
+def test_eco_param_struct_layout_matches_header():
+    from qingdai_amd._lib import qd_eco_params
+    h = _header()
+    body = h[h.index("typedef struct qd_eco_params {"):h.index("} qd_eco_params;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for line in body.split("\n")[1:]:
+        m = re.match(r"\s*(double|int32_t)\s+(.*);", line)
+        if m:
+            names += [(m.group(1), n.strip()) for n in m.group(2).split(",")]
+    py = [("double" if t is ctypes.c_double else "int32_t", n) for n, t in qd_eco_params._fields_]
+    assert names == py and ctypes.sizeof(qd_eco_params) == 6 * 8 + 4 * 4

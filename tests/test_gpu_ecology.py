@@ -98,6 +98,14 @@ def test_individual_pool_vs_reference(gpu, monkeypatch):
     assert relerr(E, d["ref_ind_E_day"]) < 1e-14 and np.array_equal(S, d["ref_ind_stress"])
     pool.reset()
     assert np.all(pool.indiv_E_day == 0.0)
+    # f32 storage of the coefficient table (QD_ECO_F32 / BASELINE configs[4] "f32 mixed"): same sub-steps, f32 rounding of Ab only
+    pool32 = IndividualPool(dev.grid, d["land_mask"], eco, day_seconds=meta["ind_day"], soil_cap=1.0, f32_storage=True)
+    for i in range(30):
+        a_, b_ = of.insolation_components(i * meta["ind_dt"])
+        pool32.try_substep(a_, b_, eco, None, meta["ind_dt"], meta["ind_day"])
+    e32 = relerr(pool32.indiv_E_day, d["ref_ind_E_day"])
+    print("f32 table:", e32)
+    assert 0 < e32 < 1e-7 and np.array_equal(pool32.indiv_water_stress_days, d["ref_ind_stress"])
     # a cell index outside the grid never reaches the device
     from qingdai_amd._lib import QdError
     pool.sample_j = pool.sample_j.copy(); pool.sample_j[0] = nlat
@@ -184,4 +192,72 @@ def test_driver_loop_with_ecology_vs_oracle(gpu, monkeypatch, variant):
     # the blend really acted: the albedo over snow-free, ice-free land differs from the run without ecology
     a_noeco = np.clip(sim.base_albedo, 0, 1)
     assert np.abs(drv.eco.last_alpha[land] - a_noeco[land]).max() > 0.01
+    sim.dev.close()
+
+
+def test_daily_hook_at_day_boundaries(gpu, monkeypatch):
+    """The seam to the host-side daily ecology (run_simulation.py:1784-1864): `Simulation(daily_hook=...)` is called inside the
+    step that completes a planet-day, before the rest of that step, with the soil index of the previous step's W_land (zero on
+    ice sheets); it reads E_day, resets it and pushes new LAI layers.  A shortened day (5 steps) and a toy growth rule, mirrored
+    on DriverOracle."""
+    import qd_oracle as qo
+    from qd_oracle import ecology as oeco, spectral as osp
+    from qd_oracle.driver import DriverOracle
+    from qingdai_amd.driver import Simulation
+    _setenv(monkeypatch, {"QD_ECO_SUBSTEP_EVERY_NPHYS": "1", "QD_ECO_LIGHT_UPDATE_EVERY_HOURS": "6"})
+    nlat, nlon, nsteps, day = 61, 96, 12, 1500.0
+    calls = []
+
+    def grow(L, E, soil):
+        return L * (1.0 + 2.0e-6 * E)[None, None] * (0.6 + 0.4 * soil)[None, None]
+
+    def hook(sim_, soil_idx, glacier):
+        E = sim_.eco.pop.E_day
+        calls.append((sim_._step_index, float(E.sum()), float(soil_idx.sum()), int(glacier.sum())))
+        sim_.eco.pop.E_day = 0.0
+        sim_.eco.pop.push_layers(grow(sim_.eco.pop.LAI_layers_SK, E, soil_idx))
+
+    sim = Simulation(nlat, nlon, params=__import__("qingdai_amd").QdParams(), use_ocean=False, quiet=True, individuals=False,
+                     daily_hook=hook)
+    sim.day_seconds = day
+    r = np.random.default_rng(8)
+    lat = np.deg2rad(sim.grid.lat_mesh)
+    land = (sim.land_mask == 1)
+    h0 = 8000.0 - 10500.0 * np.sin(lat) ** 2
+    Ts0 = 262.0 + 36.0 * np.cos(lat) ** 2
+    S0 = np.where(land & (np.abs(sim.grid.lat_mesh) > 55), 60.0, 0.0)             # >= 50 mm: ice sheet from the first step
+    W0 = np.where(land, 40.0 * r.random((nlat, nlon)), 0.0)
+    sim.gcm.h, sim.gcm.T_s = h0, Ts0
+    sim.dev.set("S_SNOW", S0); sim.dev.set("W_LAND", W0)
+    S, K = sim.eco.pop.LAI_layers_SK.shape[:2]
+    L0 = np.abs(r.normal(0.5, 0.4, (S, K, nlat, nlon))) * land
+    sim.eco.pop.push_layers(L0, init=True)
+    g, P = qo.Grid(nlat, nlon), qo.defaults()
+    m = qo.AtmosOracle(g, sim.friction, sim.land_mask, P, C_s_map=np.where(land, 3e6, P.Cs_ocean).astype(float))
+    m.h, m.T_s = h0.copy(), Ts0.copy()
+    drv = DriverOracle(g, m, None, qo.Forcing(g), sim.land_mask, sim.base_albedo, P)
+    drv.S_snow, drv.W_land = S0.copy(), W0.copy()
+    ob = osp.make_bands(16, 380.0, 780.0)
+    opop = oeco.CanopyPopulation(sim.land_mask, L0, k_canopy=0.6, light_update_every_hours=6.0, recompute_lai_delta=0.05)
+    drv.eco = oeco.EcoCoupling(oeco.EcoAdapter(opop, oeco.leaf_scalar(ob), soil_ref=0.18, substep_every_nphys=1), w_lai=1.0)
+    sim.run_steps(7)
+    sim.run_steps(nsteps - 7)
+    accum, ocalls = 0.0, []
+    for i in range(nsteps):
+        accum += 300.0
+        while accum >= day:
+            accum -= day
+            soil = np.clip(drv.W_land / 50.0, 0.0, 1.0) * (~drv.glacier)
+            ocalls.append((i, float(opop.E_day.sum()), float(soil.sum()), int(drv.glacier.sum())))
+            opop.layers = grow(opop.layers, opop.E_day, soil)
+            opop.E_day = np.zeros_like(opop.E_day)
+        drv.step(i * 300.0, 300)
+    print(calls, ocalls, sim.eco.pop.state(), opop.n_recompute)
+    assert [c[0] for c in calls] == [4, 9] == [c[0] for c in ocalls]
+    for a, b in zip(calls, ocalls):
+        assert abs(a[1] - b[1]) <= 1e-12 * abs(b[1]) and abs(a[2] - b[2]) <= 1e-9 * abs(b[2]) and a[3] == b[3] and b[3] > 0
+    assert sim.eco.pop.state()["n_recompute"] == opop.n_recompute == 3           # first step + the two LAI jumps
+    assert relerr(sim.eco.pop.total_LAI(), opop.total_LAI()) < 1e-12
+    assert relerr(sim.eco.pop.E_day, opop.E_day) < 1e-14
+    assert relerr(sim.dev.get("ALBEDO"), drv.albedo) < 1e-9 and relerr(sim.gcm.T_s, m.T_s) < 1e-9
     sim.dev.close()
