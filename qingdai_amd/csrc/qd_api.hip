@@ -265,6 +265,9 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
         if ((e = hipMalloc(&c->sel_cand, 2 * cells * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
         if ((e = hipMalloc(&c->sel_ccount, 2 * sizeof(unsigned int))) != hipSuccess) return bail("hipMalloc", e);
         hipMemsetAsync(c->sel_ccount, 0, 2 * sizeof(unsigned int), c->stream);
+        if ((e = hipMalloc(&c->med_pred, 64 * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
+        hipMemsetAsync(c->med_pred, 0, 64 * sizeof(double), c->stream);
+        { const char* ef = std::getenv("QD_MEDIAN_PREDICT"); if (ef && ef[0] == '0') c->med_predict = 0; }
     }
     if ((e = hipHostMalloc((void**)&c->hpin, 64 * sizeof(double))) != hipSuccess) return bail("hipHostMalloc", e);
     if ((e = hipHostMalloc((void**)&c->hpin_rows, (size_t)2 * c->geo.lrows() * sizeof(double))) != hipSuccess) return bail("hipHostMalloc", e);
@@ -286,6 +289,14 @@ extern "C" int qd_destroy(qd_handle c) {
     if (!c) return 0;
     hipSetDevice(c->desc.device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->med_pred && std::getenv("QD_MEDIAN_DEBUG")) {
+        double h[64];
+        if (hipMemcpy(h, c->med_pred, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess)
+            for (int s = 0; s < 4; ++s)
+                fprintf(stderr, "[median site %d] last median %.6g bracket [%.6g, %.6g] hits %.0f misses %.0f last list %.0f of %.0f; "
+                        "last miss at call %.0f: centre %.6g -> median %.6g\n", s, h[16 * s], h[16 * s + 8], h[16 * s + 9], h[16 * s + 4],
+                        h[16 * s + 5], h[16 * s + 6], h[16 * s + 7], h[16 * s + 13], h[16 * s + 14], h[16 * s + 15]);
+    }
     for (int f = 0; f < QD_F_COUNT_F64; ++f) if (c->f[f]) hipFree(c->f[f]);
     for (int s = 0; s < QD_NSCRATCH; ++s) if (c->scratch[s]) hipFree(c->scratch[s]);
     for (double* t : c->tab_alloc) hipFree(t);
@@ -297,6 +308,7 @@ extern "C" int qd_destroy(qd_handle c) {
     if (c->bands) hipFree(c->bands);
     qd_eco_free(c);
     if (c->sel_cand) hipFree(c->sel_cand); if (c->sel_ccount) hipFree(c->sel_ccount);
+    if (c->med_pred) hipFree(c->med_pred);
     if (c->hpin) hipHostFree(c->hpin);
     if (c->hpin_rows) hipHostFree(c->hpin_rows);
     if (c->stage) hipHostFree(c->stage);
@@ -594,7 +606,7 @@ extern "C" int qd_op_median_positive(qd_handle c, const double* x, double dflt, 
     if (!c || !x || !out) return -1;
     hipSetDevice(c->desc.device);
     if (seam_in(c, c->scratch[10], x)) return -1;
-    qd_median_positive_dev(c, c->scratch[10], dflt, QD_S_MED_OUT, 0, 0.0);
+    qd_median_positive_dev(c, c->scratch[10], dflt, QD_S_MED_OUT, 0, 0.0, 0);
     QD_HIP(c, hipMemcpyAsync(c->hpin, c->dscal + QD_S_MED_OUT, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     QD_HIP(c, hipStreamSynchronize(c->stream));
     *out = c->hpin[0];

@@ -346,7 +346,7 @@ int qd_atmos_step_impl(qd_ctx* c, double dt, int has_albedo) {
             QD_ROWS(c, m, G, hipLaunchKernelGGL((k_column<0, true>), qd_grid2d(G), blk, 0, c->stream, G, P, A));
         } else {
             QD_ROWS(c, m, G, hipLaunchKernelGGL((k_column<1, true>), qd_grid2d(G), blk, 0, c->stream, G, P, A));
-            if (qd_median_positive_dev(c, F[QD_F_PCOND], 1e-6, QD_S_PREF, 0, 0.0)) return -1;
+            if (qd_median_positive_dev(c, F[QD_F_PCOND], 1e-6, QD_S_PREF, 0, 0.0, 1)) return -1;
             QD_ROWS(c, m, G, hipLaunchKernelGGL((k_column<2, true>), qd_grid2d(G), blk, 0, c->stream, G, P, A));
         }
         qd_mark(c, {F[QD_F_H], F[QD_F_TS], F[QD_F_Q], F[QD_F_EFLUX], F[QD_F_PCOND], F[QD_F_LH], F[QD_F_LHREL], F[QD_F_OLR]}, m);

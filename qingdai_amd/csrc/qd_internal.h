@@ -176,6 +176,9 @@ struct qd_ctx {
     double* zonal_tw = nullptr;      // [2][nlon] cos / sin(2 pi m / nlon) of the zonal spectral filter
     double* sel_cand = nullptr;      // [2][cells] candidates of the two middle ranks after two radix passes (whole-globe handles)
     unsigned int* sel_ccount = nullptr; // [2] candidate counts
+    double* med_pred = nullptr;      // [4 sites][16]: last median, valid flag, statistics, published bracket (see qd_reduce.hip): predicted median brackets (qd_reduce.hip)
+    int med_predict = 1;             // QD_MEDIAN_PREDICT=0: always the two-histogram-pass select
+    int med_seen[4] = {0, 0, 0, 0};  // call sites that have a window centre on the device
     double* hpin = nullptr;        // pinned host scalars
     double* hpin_rows = nullptr;   // pinned, 2 x slab rows: per-row partial maxima read back in one copy
     double wsum_ocean = 0, wsum_all = 0;
@@ -284,7 +287,8 @@ int  qd_band_copy_in(qd_ctx* c, void* dst, const void* host, size_t esz);   // q
 
 // qd_reduce.hip
 int qd_reduce_field(qd_ctx* c, const double* x, int op, double* host_out);
-int qd_median_positive_dev(qd_ctx* c, const double* x, double dflt, int slot, int transform, double tparam);
+// site: call-site id 0..3 (keeps a predicted bracket per site on whole-globe handles), -1 = no prediction
+int qd_median_positive_dev(qd_ctx* c, const double* x, double dflt, int slot, int transform, double tparam, int site = -1);
 
 // qd_atmos.hip
 int qd_atmos_step_impl(qd_ctx* c, double dt, int has_albedo);

@@ -361,7 +361,7 @@ int qd_driver_physics_impl(qd_ctx* c, double dt) {
         int m = qd_plan(c, {QD_IN(F[QD_F_U], 1), QD_IN(F[QD_F_V], 1), QD_IN(F[QD_F_PCOND], 0)});
         if (m < 0) return -1;
         qd_launch_divvort(c, F[QD_F_U], F[QD_F_V], tmp, 0, m);
-        if (qd_median_positive_dev(c, tmp, 1e-12, QD_S_PSCALE, 1, p.D_crit)) return -1;
+        if (qd_median_positive_dev(c, tmp, 1e-12, QD_S_PSCALE, 1, p.D_crit, 2)) return -1;
         // orographic enhancement (run_simulation.py:1769-1775): only with QD_OROG=1 and an elevation map
         const double* orog = nullptr;
         if (p.orog_enable && c->has_elevation) {
@@ -437,7 +437,7 @@ int qd_driver_physics_impl(qd_ctx* c, double dt) {
         if (isset(p.pref) && p.pref != 0.0) {
             hipMemcpyAsync(c->dscal + QD_S_MED_OUT, &p.pref, sizeof(double), hipMemcpyHostToDevice, c->stream);
         } else {
-            if (qd_median_positive_dev(c, F[QD_F_PRECIP], 1e-6, QD_S_MED_OUT, 0, 0.0)) return -1;
+            if (qd_median_positive_dev(c, F[QD_F_PRECIP], 1e-6, QD_S_MED_OUT, 0, 0.0, 3)) return -1;
         }
         double*& cfp = F[QD_F_CLOUD_FROM_P];
         double*& src = F[QD_F_CLOUD_SRC];

@@ -359,6 +359,302 @@ k_sel_final(unsigned long long* st, const double* __restrict__ cand, unsigned in
     }
 }
 
+
+// ------------------------------------------------------------------ windowed-histogram median (whole-globe handles)
+// The medians of a step are medians of fields whose scale does not jump between steps.  Each call site keeps its last
+// median on the device.  Pass 1 (k_med_hist) histograms the positives over a WINDOW of bit patterns centred on it -- a factor
+// 16 either way, 2048 bins of 2^44 ulps (0.2 % wide) -- and counts the positives and those below the window; the last
+// workgroup locates the bins of the two middle ranks and publishes their value range [lo, hi].  Pass 2 (k_med_bracket) copies
+// the positives inside [lo, hi] to a list (a few thousand values) and recounts; one workgroup (k_med_final) selects the ranks
+// from the list.  That is three launches and two passes over the field where the digit-by-digit select needs four and three.
+// Exact whatever the window was: if a rank falls outside it (first use after an upload, a field that became all-zero) the
+// finishing workgroup runs the radix select over the whole field itself -- slow, rare, and it re-centres the window.
+// pred[site]: {last median, -, -, valid, hits, misses, last list length, last count | lo, hi, -, bracket ok}
+#define QD_MED_SITES 4
+#define QD_MED_WSHIFT 44
+__global__ void __launch_bounds__(QD_BLOCK)
+k_med_hist(QdGeom G, const double* __restrict__ x, int transform, double tparam, double* pred, unsigned long long* st,
+           unsigned int* hist) {
+    __shared__ unsigned int sh[QD_HIST_BINS + 2];             // + count of positives, + count below the window
+    __shared__ unsigned long long s_st[2];
+    __shared__ int s_last;
+    const int t = threadIdx.x, lane = t & 63;
+    const bool valid = pred[3] != 0.0;
+    // window of bit patterns [base, base + 2048 << 44): centre / 16 .. centre * 16 (8 binades)
+    const unsigned long long cbits = (unsigned long long)__double_as_longlong(valid ? pred[0] : 1.0);
+    const unsigned long long four = 4ull << 52;
+    const unsigned long long base = cbits > four ? cbits - four : 0ull;
+    for (int k = t; k < QD_HIST_BINS + 2; k += QD_BLOCK) sh[k] = 0u;
+    __syncthreads();
+    const int jstep = gridDim.x * QD_BLOCK;
+    unsigned int n_pos = 0, n_below = 0;
+    for (int i = G.row0 + (int)blockIdx.y; i < G.row0 + G.nrows; i += (int)gridDim.y) {
+        const size_t b = (size_t)qd_lrow(G, i) * G.nlon;
+        for (int jb = blockIdx.x * QD_BLOCK; jb < G.nlon; jb += 8 * jstep) {
+            double vbuf[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int j = jb + q * jstep + t;
+                vbuf[q] = x[b + (j < G.nlon ? j : G.nlon - 1)];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int j0 = jb + q * jstep;
+                if (j0 >= G.nlon) break;
+                const int j = j0 + t;
+                const double v = (j < G.nlon) ? qd_med_value(vbuf[q], transform, tparam) : 0.0;
+                const bool pos = v > 0.0;
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+                n_pos += pos ? 1u : 0u;
+                const bool below = pos && bits < base;
+                n_below += below ? 1u : 0u;
+                const unsigned long long idx = (bits - base) >> QD_MED_WSHIFT;
+                if (pos && !below && idx < (unsigned long long)QD_HIST_BINS) atomicAdd(&sh[(unsigned int)idx], 1u);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { n_pos += __shfl_down(n_pos, o, 64); n_below += __shfl_down(n_below, o, 64); }
+    if (lane == 0) {                                          // one global atomic per workgroup and counter, like any other bin
+        if (n_pos) atomicAdd(&sh[QD_HIST_BINS], n_pos);
+        if (n_below) atomicAdd(&sh[QD_HIST_BINS + 1], n_below);
+    }
+    __syncthreads();
+    for (int k = t; k < QD_HIST_BINS + 2; k += QD_BLOCK) if (sh[k]) atomicAdd(&hist[k], sh[k]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) {
+        const unsigned long long ticket = atomicAdd(&st[6], 1ull);
+        s_last = (ticket == (unsigned long long)(gridDim.x * gridDim.y) - 1ull) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // ---- last workgroup: bins of the two middle ranks
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    for (int k = t; k < QD_HIST_BINS; k += QD_BLOCK) sh[k] = __hip_atomic_load(&hist[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t < 2) s_st[t] = (unsigned long long)__hip_atomic_load(&hist[QD_HIST_BINS + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int per = QD_HIST_BINS / QD_BLOCK;
+    __shared__ unsigned int wtot[QD_BLOCK / 64];
+    __shared__ int s_bin[2];
+    unsigned int sacc = 0;
+    for (int k = 0; k < per; ++k) sacc += sh[t * per + k];
+    unsigned int inc = sacc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned int y = __shfl_up(inc, o, 64); if (lane >= o) inc += y; }
+    if (lane == 63) wtot[t >> 6] = inc;
+    if (t < 2) s_bin[t] = -1;
+    __syncthreads();
+    unsigned int wbase = 0, total = 0;
+    for (int k = 0; k < (t >> 6); ++k) wbase += wtot[k];
+    for (int k = 0; k < QD_BLOCK / 64; ++k) total += wtot[k];
+    const unsigned long long excl = (unsigned long long)wbase + inc - sacc;
+    const unsigned long long m = s_st[0], below = s_st[1];
+    const unsigned long long k1 = m ? (m - 1ull) / 2ull : 0ull, k2 = m / 2ull;
+    const bool inside = valid && m > 0ull && k1 >= below && k2 < below + (unsigned long long)total;
+    if (inside && sacc > 0) {
+        for (int which = 0; which < 2; ++which) {
+            const unsigned long long r = (which == 0 ? k1 : k2) - below;
+            if (r >= excl && r < excl + sacc) {
+                unsigned long long cum = excl;
+                int d = t * per;
+                for (; d < t * per + per; ++d) { const unsigned int hv = sh[d]; if (cum + hv > r) break; cum += hv; }
+                s_bin[which] = d;
+            }
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
+        const bool ok = inside && s_bin[0] >= 0 && s_bin[1] >= s_bin[0];
+        const unsigned long long top = base + ((unsigned long long)QD_HIST_BINS << QD_MED_WSHIFT);   // first pattern above the window
+        const unsigned long long maxb = 0x7FEFFFFFFFFFFFFFull;                                        // DBL_MAX
+        unsigned long long lo_b = 1ull, hi_b = maxb;           // no usable window: every positive value is a candidate
+        if (ok) {
+            lo_b = base + ((unsigned long long)s_bin[0] << QD_MED_WSHIFT);
+            hi_b = base + ((unsigned long long)(s_bin[1] + 1) << QD_MED_WSHIFT) - 1ull;
+        } else if (valid && m > 0ull) {
+            // the ranks left the window (a regime change of the field): hand the finisher the side they went to
+            if (k2 < below) hi_b = base - 1ull;
+            else if (k1 >= below + (unsigned long long)total) lo_b = top;
+        }
+        if (lo_b < 1ull) lo_b = 1ull;
+        if (hi_b > maxb) hi_b = maxb;
+        pred[8] = __longlong_as_double((long long)lo_b);
+        pred[9] = __longlong_as_double((long long)hi_b);
+        pred[11] = 1.0;
+        __hip_atomic_store(&st[6], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (int k = t; k < QD_HIST_BINS + 2; k += QD_BLOCK) __hip_atomic_store(&hist[k], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void k_med_seed(double* pred, const double* out, const unsigned long long* count) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { pred[0] = *out; pred[3] = (*count > 0ull) ? 1.0 : 0.0; }
+}
+
+__global__ void __launch_bounds__(QD_BLOCK)
+k_med_bracket(QdGeom G, const double* __restrict__ x, int transform, double tparam, const double* __restrict__ pred,
+              unsigned long long* st, double* __restrict__ cand, unsigned int* __restrict__ ccount) {
+    const bool valid = pred[3] != 0.0;
+    const double lo = valid ? pred[0] : 0.0, hi = valid ? pred[1] : -1.0;     // invalid: empty bracket, the finisher falls back
+    const int t = threadIdx.x, lane = t & 63;
+    const int jstep = gridDim.x * QD_BLOCK;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    unsigned int n_pos = 0, n_below = 0;
+    for (int i = G.row0 + (int)blockIdx.y; i < G.row0 + G.nrows; i += (int)gridDim.y) {
+        const size_t b = (size_t)qd_lrow(G, i) * G.nlon;
+        for (int jb = blockIdx.x * QD_BLOCK; jb < G.nlon; jb += 8 * jstep) {
+            double vbuf[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int j = jb + q * jstep + t;
+                vbuf[q] = x[b + (j < G.nlon ? j : G.nlon - 1)];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int j0 = jb + q * jstep;
+                if (j0 >= G.nlon) break;                                  // wave-uniform
+                const int j = j0 + t;
+                const double v = (j < G.nlon) ? qd_med_value(vbuf[q], transform, tparam) : 0.0;
+                const bool pos = v > 0.0;
+                n_pos += pos ? 1u : 0u;
+                n_below += (pos && v < lo) ? 1u : 0u;
+                const bool in = pos && v >= lo && v <= hi;
+                const unsigned long long m = __ballot(in);
+                if (m) {
+                    unsigned int base = 0;
+                    const int leader = __ffsll((long long)m) - 1;
+                    if (lane == leader) base = atomicAdd(&ccount[0], (unsigned int)__popcll(m));
+                    base = (unsigned int)__shfl((int)base, leader, 64);
+                    if (in) cand[base + (unsigned int)__popcll(m & lt)] = v;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { n_pos += __shfl_down(n_pos, o, 64); n_below += __shfl_down(n_below, o, 64); }
+    __shared__ unsigned int s_c[2][QD_BLOCK / 64];
+    if (lane == 0) { s_c[0][t >> 6] = n_pos; s_c[1][t >> 6] = n_below; }
+    __syncthreads();
+    if (t < 2) {                                              // one global atomic per workgroup and counter
+        unsigned int a = 0;
+        for (int k = 0; k < QD_BLOCK / 64; ++k) a += s_c[t][k];
+        if (a) atomicAdd(&st[t], (unsigned long long)a);
+    }
+}
+
+// value of element k of the select source: the candidate list, or (fallback) the transformed field; non-positive = skip
+__device__ __forceinline__ double qd_med_src(const double* __restrict__ list, const double* __restrict__ field, bool use_field,
+                                             size_t k, int transform, double tparam) {
+    return use_field ? qd_med_value(field[k], transform, tparam) : list[k];
+}
+
+__global__ void __launch_bounds__(QD_FIN_BLOCK)
+k_med_final(unsigned long long* st, const double* __restrict__ cand, unsigned int* ccount, double* pred,
+            const double* __restrict__ field, unsigned long long n_field, int transform, double tparam, double dflt, double* out,
+            unsigned long long* count_out) {
+    __shared__ unsigned int sh[QD_HIST_BINS];
+    __shared__ unsigned int wtot[QD_FIN_BLOCK / 64];
+    __shared__ unsigned long long s_prefix, s_rank;
+    __shared__ double s_min[QD_FIN_BLOCK / 64];
+    __shared__ unsigned int s_cnt[QD_FIN_BLOCK / 64];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const unsigned long long m = __hip_atomic_load(&st[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long c_lo = __hip_atomic_load(&st[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned int M = __hip_atomic_load(&ccount[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool valid = pred[11] != 0.0;
+    const double plo = pred[8], phi = pred[9];
+    __syncthreads();                                                     // every thread has read the state before thread 0 resets it
+    if (m == 0ull) {
+        if (t == 0) { *out = dflt; if (count_out) *count_out = 0ull; pred[3] = 0.0; st[0] = 0ull; st[1] = 0ull; ccount[0] = 0u; }
+        return;
+    }
+    const unsigned long long k1 = (m - 1ull) / 2ull, k2 = m / 2ull;
+    const bool hit = valid && c_lo <= k1 && k2 < c_lo + (unsigned long long)M;
+    const bool use_field = !hit;
+    const size_t N = use_field ? (size_t)n_field : (size_t)M;
+    // leading bits shared by every value inside [lo, hi] (positive doubles order like their bit patterns)
+    int common = 0;
+    unsigned long long pre0 = 0ull;
+    if (hit) {
+        const unsigned long long bl = (unsigned long long)__double_as_longlong(plo), bh = (unsigned long long)__double_as_longlong(phi);
+        common = (bl == bh) ? 64 : __clzll((long long)(bl ^ bh));
+        pre0 = bl;
+    }
+    if (t == 0) { s_prefix = 0ull; s_rank = hit ? (k1 - c_lo) : k1; }
+    __syncthreads();
+    const int shifts[6] = {53, 42, 31, 20, 10, 0};
+    const int widths[6] = {11, 11, 11, 11, 10, 10};
+    int done = 0;
+    for (int p = 0; p < 6; ++p) {
+        const int shift = shifts[p], width = widths[p], up = shift + width;
+        done += width;
+        if (done <= common) {                                            // digit fixed by the bracket: take it from lo
+            if (t == 0) s_prefix |= pre0 & (((1ull << width) - 1ull) << shift);
+            __syncthreads();
+            continue;
+        }
+        for (int k = t; k < QD_HIST_BINS; k += QD_FIN_BLOCK) sh[k] = 0u;
+        __syncthreads();
+        const unsigned long long pre = up >= 64 ? 0ull : (s_prefix >> up), r = s_rank;
+        for (size_t k = t; k < N; k += QD_FIN_BLOCK) {
+            const double v = qd_med_src(cand, field, use_field, k, transform, tparam);
+            if (!(v > 0.0)) continue;
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+            if (up >= 64 || (bits >> up) == pre) atomicAdd(&sh[(unsigned int)((bits >> shift) & ((1u << width) - 1u))], 1u);
+        }
+        __syncthreads();
+        const unsigned int h0 = sh[2 * t], h1 = sh[2 * t + 1];
+        const unsigned int mine = h0 + h1;
+        unsigned int inc = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned int y = __shfl_up(inc, o, 64); if (lane >= o) inc += y; }
+        if (lane == 63) wtot[wv] = inc;
+        __syncthreads();
+        unsigned int base = 0;
+        for (int k = 0; k < wv; ++k) base += wtot[k];
+        const unsigned long long excl = (unsigned long long)base + inc - mine;
+        if (mine > 0 && r >= excl && r < excl + mine) {
+            const int d = (r < excl + h0) ? 2 * t : 2 * t + 1;
+            s_prefix = s_prefix | ((unsigned long long)d << shift);
+            s_rank = r - (d == 2 * t ? excl : excl + h0);
+        }
+        __syncthreads();
+    }
+    const double v1 = __longlong_as_double((long long)s_prefix);
+    double v2 = v1;
+    if (!(m & 1ull)) {
+        // rank k1 + 1: v1 again when it is repeated beyond rank k1, else the smallest value above it.  s_rank is now the rank
+        // of the target inside its run of equal values (0-based), so the run must be longer than s_rank + 1.
+        unsigned int c_eq = 0;
+        double mn = DBL_MAX;
+        for (size_t k = t; k < N; k += QD_FIN_BLOCK) {
+            const double v = qd_med_src(cand, field, use_field, k, transform, tparam);
+            if (!(v > 0.0)) continue;
+            c_eq += (v == v1) ? 1u : 0u;
+            if (v > v1 && v < mn) mn = v;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { c_eq += __shfl_down(c_eq, o, 64); const double y = __shfl_down(mn, o, 64); mn = y < mn ? y : mn; }
+        if (lane == 0) { s_cnt[wv] = c_eq; s_min[wv] = mn; }
+        __syncthreads();
+        if (t == 0) {
+            unsigned int ce = 0; double mm = DBL_MAX;
+            for (int k = 0; k < QD_FIN_BLOCK / 64; ++k) { ce += s_cnt[k]; mm = s_min[k] < mm ? s_min[k] : mm; }
+            v2 = ((unsigned long long)ce > s_rank + 1ull) ? v1 : mm;
+        }
+    }
+    if (t == 0) {
+        const double med = (m & 1ull) ? v1 : (v1 + v2) / 2.0;           // np.median: mean of the two middles
+        *out = med;
+        if (count_out) *count_out = m;
+        pred[12] += 1.0;
+        if (!hit) { pred[13] = pred[12]; pred[14] = pred[0]; pred[15] = med; }  // last miss: call number, window centre, result
+        pred[0] = med; pred[3] = 1.0;                                     // centre of the next call's window
+        pred[hit ? 4 : 5] += 1.0; pred[6] = (double)M; pred[7] = (double)m;      // statistics (QD_MEDIAN_DEBUG)
+        st[0] = 0ull; st[1] = 0ull; ccount[0] = 0u;
+    }
+}
+
 // result + reset of the select state for the next call; `count_out` (optional) keeps the count
 __global__ void k_sel_finish(unsigned long long* st, double dflt, double* out, unsigned long long* count_out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -375,13 +671,35 @@ __global__ void k_sel_finish(unsigned long long* st, double dflt, double* out, u
 }
 
 // median of the positive entries of x (after `transform`) -> device scalar slot; `dflt` if none
-int qd_median_positive_dev(qd_ctx* c, const double* x, double dflt, int slot, int transform, double tparam) {
+int qd_median_positive_dev(qd_ctx* c, const double* x, double dflt, int slot, int transform, double tparam, int site) {
     const QdGeom G = qd_segments(c, 0).g[0];                 // owned rows only
     // digits from the top: bits 63..53, 52..42, 41..31, 30..20 (11 wide), 19..10, 9..0 (10 wide)
     const int shifts[6] = {53, 42, 31, 20, 10, 0};
     const int widths[6] = {11, 11, 11, 11, 10, 10};
     const int nblk = 256;         // few, fat workgroups (ms/step at 721x1440 with 64/128/256/512/721: 1.371/1.324/1.307/1.323/1.345)
     dim3 grid(1, std::min(G.nrows, nblk));
+    if (c->geo.full && c->sel_cand && c->med_pred && c->med_predict && site >= 0 && site < QD_MED_SITES) {
+        // windowed histogram around the site's last median, one collecting pass, one finishing workgroup
+        double* pred = c->med_pred + 16 * site;
+        if (c->med_seen[site]) {
+            hipLaunchKernelGGL(k_med_hist, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, pred, c->sel_state, c->hist);
+            hipLaunchKernelGGL(k_med_bracket, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, pred + 8, c->sel_state,
+                               c->sel_cand, c->sel_ccount);
+            hipLaunchKernelGGL(k_med_final, dim3(1), dim3(QD_FIN_BLOCK), 0, c->stream, c->sel_state, c->sel_cand, c->sel_ccount, pred, x,
+                               (unsigned long long)c->geo.cells(), transform, tparam, dflt, c->dscal + slot, c->dcount);
+            return 0;
+        }
+        c->med_seen[site] = 1;                                // first use: the digit-by-digit select below, then seed the window
+        for (int p = 0; p < 2; ++p)
+            hipLaunchKernelGGL(k_sel_pass, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, c->sel_state,
+                               c->hist, shifts[p], widths[p], p == 0 ? 1 : 0, 0);
+        hipLaunchKernelGGL(k_sel_collect, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, c->sel_state,
+                           c->sel_cand, c->sel_ccount, (unsigned long long)c->geo.cells(), 22);
+        hipLaunchKernelGGL(k_sel_final, dim3(1), dim3(QD_FIN_BLOCK), 0, c->stream, c->sel_state, c->sel_cand, c->sel_ccount,
+                           (unsigned long long)c->geo.cells(), 22, dflt, c->dscal + slot, c->dcount);
+        hipLaunchKernelGGL(k_med_seed, dim3(1), dim3(64), 0, c->stream, pred, c->dscal + slot, c->dcount);
+        return 0;
+    }
     if (c->geo.full && c->sel_cand) {
         // two histogram passes, one collecting pass, one finishing workgroup
         for (int p = 0; p < 2; ++p)

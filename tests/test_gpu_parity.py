@@ -204,6 +204,44 @@ def test_median_exact(gpu):
         assert bdev.op_median_positive(x, 1e-6) == float(np.median(pos)), trial
 
 
+def test_median_predicted_bracket(gpu, monkeypatch):
+    """The predicted-bracket select (qd_reduce.hip: k_med_bracket + k_med_final): a slowly drifting field keeps the median inside
+    the bracket kept from the previous call (fast path), jumps / empty fields / ties force the in-kernel fallback; every result
+    is numpy's median bit for bit, and equals the histogram-pass select (QD_MEDIAN_PREDICT=0)."""
+    import qingdai_amd as qa
+    from qingdai_amd.device import Device
+    r = np.random.default_rng(17)
+    grid = qa.SphericalGrid(181, 300)
+    dev = grid._ops()
+    base = np.exp(r.normal(-9, 2, (181, 300))) * (r.random((181, 300)) < 0.7)
+    base[r.random(base.shape) < 0.01] *= -1.0
+
+    def want(x):
+        pos = x[x > 0]
+        return float(np.median(pos)) if pos.size else 1e-6
+    seq = []
+    for k in range(12):                                              # drift of 0.3 % per call: inside the +-2 % bracket
+        seq.append(base * (1.0 + 0.003 * k) * (1.0 + 1e-4 * r.normal(0, 1, base.shape)))
+    seq.append(base * 50.0)                                          # jump: bracket misses, fallback, wider bracket next time
+    seq.append(base * 50.5)
+    seq.append(np.zeros_like(base))                                  # no positive entry: default, predictor dropped
+    seq.append(base)
+    odd = base.copy(); odd.ravel()[np.flatnonzero(odd.ravel() > 0)[0]] = 0.0      # flips the parity of the count
+    seq.append(odd)
+    seq.append(np.where(base > 0, 2.5, 0.0))                         # all candidates equal
+    seq.append(np.where(base > 0, 2.5, 0.0) * (1.0 + 1e-3))
+    two = np.where(np.arange(base.size).reshape(base.shape) % 2 == 0, 1.0, 1.0 + 2.0 ** -40)   # middles in neighbouring runs
+    seq.append(two); seq.append(two)
+    got = [dev.op_median_positive(x, 1e-6) for x in seq]
+    for k, (g, x) in enumerate(zip(got, seq)):
+        assert g == want(x), (k, g, want(x))
+    monkeypatch.setenv("QD_MEDIAN_PREDICT", "0")
+    p = qa.QdParams(); p.has_csmap = 0
+    dev0 = Device(qa.SphericalGrid(181, 300), p)
+    assert [dev0.op_median_positive(x, 1e-6) for x in seq] == got
+    dev0.close()
+
+
 @pytest.mark.parametrize("case", TS_CASES)
 def test_time_step_vs_reference_and_oracle(gpu, case):
     meta, d = load_golden(case)
