@@ -193,6 +193,9 @@ typedef struct qd_eco_params {
     int32_t albedo_couple;       /* QD_ECO_SUBDAILY_ENABLE && QD_ECO_ALBEDO_COUPLE: run_simulation.py:2075 */
     int32_t bands_couple;        /* QD_ECO_BANDS_COUPLE: land base albedo <- clip(ECO_ALPHA_BANDED), run_simulation.py:2107-2112 */
     int32_t water_couple;        /* QD_PHYTO_ENABLE && QD_PHYTO_ALBEDO_COUPLE: ocean base albedo <- clip(WATER_ALPHA), :2121-2128 */
+    int32_t use_lai;             /* QD_ECO_USE_LAI (1).  0 = the adapter's M1 branch (adapter.py:162-166): no population, no E_day,
+                                    alpha = clip(leaf_scalar) on land */
+    int32_t reserved;
 } qd_eco_params;
 int qd_eco_configure(qd_handle h, const qd_eco_params* p, size_t sizeof_params);
 /* PopulationManager.total_LAI (population.py:288-294): layers = [n_planes][n_lat][n_lon] host f64 (the flattened

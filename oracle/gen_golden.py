@@ -563,6 +563,17 @@ def case_ecology(nlat, nlon, seed):
         out.update(ind_sample_j=pool.sample_j, ind_sample_i=pool.sample_i, ind_cell=pool.indiv_cell_index, ind_Ab=pool.indiv_Ab,
                    ind_tol=pool.indiv_tol, ind_soil=soil, ref_ind_E_day=pool.indiv_E_day.copy(),
                    ref_ind_stress=pool.indiv_water_stress_days.copy())
+    # the adapter without a population (QD_ECO_USE_LAI=0, adapter.py:79-80,162-166)
+    with ref_env({}):
+        os.environ.update(env)
+        os.environ["QD_ECO_USE_LAI"] = "0"
+        eco1 = quiet(EcologyAdapter, g, mask)
+        m1 = [eco1.step_subdaily(out["insA_0"] + out["insB_0"], 0.3, dt) for _ in range(4)]
+    assert eco1.pop is None and [a is not None for a in m1] == [False, True, False, True]
+    out["ref_alpha_m1"] = m1[1]
+    o1 = oeco.EcoAdapter(None, leaf_s, soil_ref=0.18, substep_every_nphys=2)
+    got1 = [o1.step_subdaily(None, dt, land_mask=mask) for _ in range(4)]
+    assert [a is not None for a in got1] == [False, True, False, True] and np.array_equal(got1[3], m1[3], equal_nan=True)
     # oracle on the same inputs
     ob = osp.make_bands(16, 380.0, 780.0)
     opop = oeco.CanopyPopulation(mask, L0, k_canopy=0.6, light_update_every_hours=0.5, recompute_lai_delta=0.05)

@@ -485,7 +485,7 @@ extern "C" int qd_step_n(qd_handle c, int n, double dt, int flags, const double*
         int rc;
         // EcologyAdapter.step_subdaily sits between the glacier mask and the base-albedo blend (run_simulation.py:2075-2104):
         // its clock / canopy / alpha part runs before the albedo kernel, its E_day += isr dt rides on this step's forcing launch
-        if (with_eco && c->eco.p.albedo_couple) { if ((rc = qd_eco_canopy_impl(c, dt))) return rc; c->eco.eday_dt = dt; }
+        if (with_eco && c->eco.p.albedo_couple) { if ((rc = qd_eco_canopy_impl(c, dt))) return rc; c->eco.eday_dt = c->eco.p.use_lai ? dt : 0.0; }
         if (with_phys) { if ((rc = qd_driver_physics_impl(c, dt))) return rc; }
         else if ((rc = qd_simple_albedo_impl(c, 0.08))) return rc;
         if ((rc = qd_forcing_impl(c, st, st + 3, st[6], 1))) return rc;

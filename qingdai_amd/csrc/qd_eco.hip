@@ -57,6 +57,7 @@ k_eco_alpha(size_t n, const double* __restrict__ f, const uint8_t* __restrict__ 
             double* __restrict__ alpha) {
     const size_t o = (size_t)blockIdx.x * QD_BLOCK + threadIdx.x;
     if (o >= n) return;
+    if (!f) { alpha[o] = (land[o] == 1) ? qd_clip(leaf_s, 0.0, 1.0) : NAN; return; }      // M1 branch: no population (adapter.py:162-166)
     const double fv = f[o];
     alpha[o] = (land[o] == 1) ? qd_clip(leaf_s * fv + (1.0 - fv) * soil, 0.0, 1.0) : NAN;
 }
@@ -175,7 +176,7 @@ extern "C" int qd_eco_configure(qd_handle c, const qd_eco_params* p, size_t sz) 
     if (sz != sizeof(qd_eco_params)) return qd_fail(c, "qd_eco_configure: struct size mismatch (ABI)");
     QdEco& E = c->eco;
     const bool first = !E.configured;
-    if (!first && (p->leaf_scalar != E.p.leaf_scalar || p->soil_ref != E.p.soil_ref)) E.alpha_dirty = 1;
+    if (!first && (p->leaf_scalar != E.p.leaf_scalar || p->soil_ref != E.p.soil_ref || p->use_lai != E.p.use_lai)) E.alpha_dirty = 1;
     E.p = *p;
     if (first) E.next_h = p->light_update_hours;               // population.py:72
     E.configured = 1;
@@ -223,9 +224,19 @@ static int eco_ratio(qd_ctx* c, double* ratio) {
 int qd_eco_canopy_impl(qd_ctx* c, double dt) {
     QdEco& E = c->eco;
     if (!E.configured) return qd_fail(c, "ecology sub-step: qd_eco_configure has not been called");
+    const size_t n = c->geo.cells();
+    if (!E.p.use_lai) {                                         // adapter.py:146-166 without a population
+        E.count++;
+        if (E.count % std::max(1, (int)E.p.substep_every_nphys) == 0 && (E.alpha_dirty || !E.alpha_valid)) {
+            hipLaunchKernelGGL(k_eco_alpha, flat_grid(n), dim3(QD_BLOCK), 0, c->stream, n, (const double*)nullptr, c->land,
+                               E.p.leaf_scalar, E.p.soil_ref, c->f[QD_F_ECO_ALPHA]);
+            qd_mark(c, {c->f[QD_F_ECO_ALPHA]}, c->geo.halo);
+            E.alpha_valid = 1; E.alpha_dirty = 0;
+        }
+        return 0;
+    }
     if (!E.have_lai) return qd_fail(c, "ecology sub-step: no LAI layers (qd_eco_set_lai_layers)");
     QdScope sc(c, "eco_canopy");
-    const size_t n = c->geo.cells();
     E.count++;
     E.hours += dt / 3600.0;                                     // population.py:271
     bool rec = !E.f_valid || E.hours >= E.next_h;               // population.py:897-901
@@ -263,7 +274,7 @@ extern "C" int qd_eco_substep(qd_handle c, double dt) {
     if (!c) return -1;
     hipSetDevice(c->desc.device);
     if (!c->eco.configured) return qd_fail(c, "qd_eco_substep: qd_eco_configure has not been called");
-    if (qd_eco_eday_impl(c, dt)) return -1;                     // pop.step_subdaily first (adapter.py:151-155)
+    if (c->eco.p.use_lai && qd_eco_eday_impl(c, dt)) return -1; // pop.step_subdaily first (adapter.py:151-155)
     if (qd_eco_canopy_impl(c, dt)) return -1;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return qd_fail(c, "qd_eco_substep: launch", e);

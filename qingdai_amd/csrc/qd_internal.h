@@ -123,7 +123,7 @@ __device__ __forceinline__ QdTile qd_tile() {
 // ecology sub-step: clocks and cache flags of PopulationManager / EcologyAdapter / IndividualPool (qd_eco.hip)
 #define QD_MAXBANDS 32
 struct QdEco {
-    qd_eco_params p{0.5, 0.3, 0.20, 1.0, 6.0, 0.05, 1, 0, 0, 0};
+    qd_eco_params p{0.5, 0.3, 0.20, 1.0, 6.0, 0.05, 1, 0, 0, 0, 1, 0};
     int configured = 0;
     double hours = 0, next_h = 6.0;
     int64_t count = 0;

@@ -166,13 +166,13 @@ class Simulation:
             from .ecology import EcologyAdapter, IndividualPool
             self.eco = EcologyAdapter(self.grid, self.land_mask, dev=self.dev)
             ind_on = (int(env.get("QD_ECO_INDIV_ENABLE", "1")) == 1) if individuals is None else bool(individuals)
-            if ind_on:
+            if ind_on and self.eco.pop is not None:
                 self.indiv = IndividualPool(self.grid, self.land_mask, self.eco, sample_frac=0.02, per_cell=150,
                                             substeps_per_day=10, day_seconds=self.day_seconds)
             if not quiet:
-                s_ = self.eco.pop.summary()
+                lai = f"LAI mean {self.eco.pop.summary()['LAI_mean']:.2f}" if self.eco.pop is not None else "no population (M1)"
                 print(f"[Ecology] device sub-step: NB={self.eco.bands.nbands}, alpha_leaf={self.eco.alpha_leaf_scalar:.3f}, "
-                      f"LAI mean {s_['LAI_mean']:.2f}, individuals {self.indiv.n_indiv if self.indiv else 0}")
+                      f"{lai}, individuals {self.indiv.n_indiv if self.indiv else 0}")
         # banded initial surface temperature (run_simulation.py:310-328)
         if int(env.get("QD_INIT_BANDED", "0")) == 1:
             T_eq, T_pole = float(env.get("QD_INIT_T_EQ", "295.0")), float(env.get("QD_INIT_T_POLE", "265.0"))

@@ -176,19 +176,19 @@ class EcologyAdapter:
             recompute_lai_delta=_envf("QD_ECO_LIGHT_RECOMPUTE_LAI_DELTA", 0.05),
             substep_every_nphys=max(1, self.cfg.substep_every_nphys), albedo_couple=1 if albedo_couple else 0,
             bands_couple=1 if _envi("QD_ECO_BANDS_COUPLE", 0) == 1 else 0,
-            water_couple=1 if (_envi("QD_PHYTO_ENABLE", 0) == 1 and _envi("QD_PHYTO_ALBEDO_COUPLE", 1) == 1) else 0)
+            water_couple=1 if (_envi("QD_PHYTO_ENABLE", 0) == 1 and _envi("QD_PHYTO_ALBEDO_COUPLE", 1) == 1) else 0,
+            use_lai=1 if _envi("QD_ECO_USE_LAI", 1) == 1 else 0, reserved=0)
         self.configure()
-        if _envi("QD_ECO_USE_LAI", 1) != 1:
-            raise NotImplementedError("QD_ECO_USE_LAI=0 (the scalar M1 branch of adapter.py:162-166) is not on the device path")
+        self._count = 0
+        self.pop = None
+        if not self.params.use_lai:        # M1 branch (adapter.py:79-80,162-166): no population, scalar leaf alpha on land
+            self.species_drought_tolerance = None
+            return
         self.pop = PopulationCanopy(self._dev, self.land_mask.astype(int))
         # per-species leaf reflectance and drought tolerance from the QD_ECO_SPECIES_{i}_* genes (adapter.py:90-116, genes.py:45-90)
-        R, tol = [], []
-        for i in range(self.pop.Ns):
-            pre = f"QD_ECO_SPECIES_{i}_"
-            R.append(np.clip(1.0 - sp.absorbance_from_peaks(self.bands, _peaks_from_env(pre)), 0.0, 1.0))
-            tol.append(_envf(pre + "DROUGHT_TOL", 0.3))
-        self.pop.set_species_reflectance_bands(np.stack(R, axis=0))
-        self.species_drought_tolerance = np.asarray(tol, dtype=float)
+        R, tol = species_tables(self.bands, self.pop.Ns)
+        self.pop.set_species_reflectance_bands(R)
+        self.species_drought_tolerance = tol
 
     def configure(self):
         self._dev._chk(self._dev.lib.qd_eco_configure(self._dev.h, ctypes.byref(self.params), ctypes.sizeof(self.params)),
@@ -202,7 +202,9 @@ class EcologyAdapter:
             d.set("ISR", I_total)
         d.flush()
         d._chk(d.lib.qd_eco_substep(d.h, float(dt_seconds)), "qd_eco_substep")
-        if self.pop.state()["step_count"] % max(1, self.cfg.substep_every_nphys) != 0:
+        out = (ctypes.c_double * 5)()
+        d._chk(d.lib.qd_eco_get_state(d.h, out), "qd_eco_get_state")
+        if int(out[2]) % max(1, self.cfg.substep_every_nphys) != 0:
             return None
         d._host.pop("ECO_ALPHA", None)
         return d.get("ECO_ALPHA").copy()
@@ -231,6 +233,52 @@ class EcologyAdapter:
         return A, self.w_b.copy()
 
 
+def sample_pool(land_mask, species_weights, R_species, drought_tol, nb, sample_frac, per_cell):
+    """The arrays IndividualPool.__init__ draws (individuals.py:63-131), as a pure host function: sampled cells without
+    replacement from default_rng(42), the cell index of every individual, species by weight, per-band coefficients = species
+    leaf reflectance + N(0, 0.02) jitter clipped to [0, 1], drought tolerance by species.  Same generator calls in the same
+    order as the reference, so the same land mask and species table give the same pool."""
+    land = (np.asarray(land_mask) == 1)
+    width = land.shape[1]
+    w = np.asarray(species_weights, dtype=float)
+    if w.ndim != 1 or w.size <= 0:
+        w = np.asarray([1.0])
+    ns = int(w.size)
+    spw = w / w.sum() if w.sum() > 0 else np.full((ns,), 1.0 / ns)
+    rng = np.random.default_rng(seed=42)
+    land_idx = np.flatnonzero(land.ravel())
+    want = max(1, int(sample_frac * land_idx.size))
+    picked = land_idx if want >= land_idx.size else rng.choice(land_idx, size=want, replace=False)
+    sample_j = np.asarray(picked // width, dtype=np.int32)
+    sample_i = np.asarray(picked % width, dtype=np.int32)
+    n_cells = int(sample_j.size)
+    n_indiv = n_cells * int(per_cell)
+    cell = np.repeat(np.arange(n_cells, dtype=np.int32), int(per_cell))
+    species_id = rng.choice(np.arange(ns, dtype=np.int32), size=n_indiv, p=spw)
+    R = R_species
+    if R is None or R.shape[0] != ns:
+        R = np.full((ns, nb), 0.5)
+    if R.shape[1] > nb:
+        R = R[:, :nb]
+    elif R.shape[1] < nb:
+        R = np.pad(R, ((0, 0), (0, nb - R.shape[1])), mode="edge")
+    Ab = np.clip(R[species_id, :] + rng.normal(0.0, 0.02, size=(n_indiv, nb)), 0.0, 1.0)
+    tol = np.full((ns,), 0.5) if drought_tol is None or len(drought_tol) != ns else np.asarray(drought_tol, dtype=float)
+    return {"sp_weights": spw, "sample_j": sample_j, "sample_i": sample_i, "indiv_cell_index": cell, "indiv_species_id": species_id,
+            "indiv_Ab": Ab, "indiv_tol": np.clip(tol, 0.0, 1.0)[species_id]}
+
+
+def species_tables(bands, n_species):
+    """Per-species leaf reflectance [Ns, NB] and drought tolerance [Ns] from the QD_ECO_SPECIES_{i}_* genes
+    (adapter.py:90-116, genes.py:45-111)."""
+    R, tol = [], []
+    for i in range(n_species):
+        pre = f"QD_ECO_SPECIES_{i}_"
+        R.append(np.clip(1.0 - sp.absorbance_from_peaks(bands, _peaks_from_env(pre)), 0.0, 1.0))
+        tol.append(_envf(pre + "DROUGHT_TOL", 0.3))
+    return np.stack(R, axis=0), np.asarray(tol, dtype=float)
+
+
 class IndividualPool:
     """Sampled individuals (individuals.py:37-191).  The sampling uses the same generator calls in the same order as the
     reference (default_rng(42): cells without replacement, species by weight, N(0, 0.02) jitter), so a given land mask yields
@@ -238,6 +286,8 @@ class IndividualPool:
 
     def __init__(self, grid, land_mask, eco_adapter, *, sample_frac=0.02, per_cell=100, substeps_per_day=10, day_seconds=None,
                  soil_cap=None, diag=False, f32_storage=None):
+        if getattr(eco_adapter, "pop", None) is None:
+            raise RuntimeError("IndividualPool requires EcologyAdapter.pop (QD_ECO_USE_LAI=1)")     # individuals.py:67-69
         self._dev = eco_adapter._dev
         self.land_mask = (np.asarray(land_mask) == 1)
         self.h, self.w = self.land_mask.shape
@@ -247,29 +297,13 @@ class IndividualPool:
         frac = _envf("QD_ECO_INDIV_SAMPLE_FRAC", sample_frac)
         self.per_cell = _envi("QD_ECO_INDIV_PER_CELL", per_cell)
         self.substeps_per_day = max(1, _envi("QD_ECO_INDIV_SUBSTEPS_PER_DAY", substeps_per_day))
-        w = np.asarray(pop.species_weights, dtype=float)
-        self.ns = int(w.size)
-        self.sp_weights = w / w.sum() if w.sum() > 0 else np.full((self.ns,), 1.0 / self.ns)
-        rng = np.random.default_rng(seed=42)
-        land_idx = np.flatnonzero(self.land_mask.ravel())
-        want = max(1, int(frac * land_idx.size))
-        picked = land_idx if want >= land_idx.size else rng.choice(land_idx, size=want, replace=False)
-        self.sample_j = np.asarray(picked // self.w, dtype=np.int32)
-        self.sample_i = np.asarray(picked % self.w, dtype=np.int32)
+        arr = sample_pool(self.land_mask, pop.species_weights, pop._species_R_leaf,
+                          getattr(eco_adapter, "species_drought_tolerance", None), self.nb, frac, self.per_cell)
+        for k, v in arr.items():
+            setattr(self, k, v)
+        self.ns = int(self.sp_weights.size)
         self.n_cells = int(self.sample_j.size)
         self.n_indiv = self.n_cells * self.per_cell
-        self.indiv_cell_index = np.repeat(np.arange(self.n_cells, dtype=np.int32), self.per_cell)
-        self.indiv_species_id = rng.choice(np.arange(self.ns, dtype=np.int32), size=self.n_indiv, p=self.sp_weights)
-        R = pop._species_R_leaf
-        if R is None or R.shape[0] != self.ns:
-            R = np.full((self.ns, self.nb), 0.5)
-        if R.shape[1] > self.nb:
-            R = R[:, :self.nb]
-        elif R.shape[1] < self.nb:
-            R = np.pad(R, ((0, 0), (0, self.nb - R.shape[1])), mode="edge")
-        self.indiv_Ab = np.clip(R[self.indiv_species_id, :] + rng.normal(0.0, 0.02, size=(self.n_indiv, self.nb)), 0.0, 1.0)
-        tol = np.clip(getattr(eco_adapter, "species_drought_tolerance", np.full((self.ns,), 0.5)), 0.0, 1.0)
-        self.indiv_tol = np.asarray(tol, dtype=float)[self.indiv_species_id]
         from .forcing import PLANET_OMEGA
         self.day_seconds = float(day_seconds) if day_seconds else 2 * np.pi / PLANET_OMEGA
         self.soil_cap = float(soil_cap) if soil_cap is not None else _envf("QD_ECO_SOIL_WATER_CAP", 50.0)

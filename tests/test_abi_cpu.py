@@ -106,4 +106,4 @@ def test_eco_param_struct_layout_matches_header():
         if m:
             names += [(m.group(1), n.strip()) for n in m.group(2).split(",")]
     py = [("double" if t is ctypes.c_double else "int32_t", n) for n, t in qd_eco_params._fields_]
-    assert names == py and ctypes.sizeof(qd_eco_params) == 6 * 8 + 4 * 4
+    assert names == py and ctypes.sizeof(qd_eco_params) == 6 * 8 + 6 * 4

@@ -72,6 +72,25 @@ def test_canopy_alpha_sequence_vs_reference(gpu, monkeypatch):
     dev.close()
 
 
+def test_adapter_without_population_vs_reference(gpu, monkeypatch):
+    """QD_ECO_USE_LAI=0, the adapter's M1 branch (adapter.py:79-80,162-166): no population, no E_day, the scalar leaf alpha on
+    land on every 2nd call; a pool of individuals cannot be built on it (individuals.py:67-69)."""
+    from qingdai_amd.ecology import EcologyAdapter, IndividualPool
+    _setenv(monkeypatch, {"QD_ECO_USE_LAI": "0"})
+    meta, d = load_golden("eco_19x36")
+    dev = _device(meta["nlat"], meta["nlon"], d["land_mask"])
+    eco = EcologyAdapter(dev.grid, d["land_mask"], dev=dev, albedo_couple=True)
+    assert eco.pop is None
+    got = [eco.step_subdaily(d["insA_0"] + d["insB_0"], 0.3, meta["dt"]) for _ in range(4)]
+    assert [a is not None for a in got] == [False, True, False, True]
+    assert np.array_equal(got[1], d["ref_alpha_m1"], equal_nan=True) and np.array_equal(got[3], d["ref_alpha_m1"], equal_nan=True)
+    dev._host.pop("ECO_EDAY", None)
+    assert np.all(dev.get("ECO_EDAY") == 0.0)
+    with pytest.raises(RuntimeError, match="requires EcologyAdapter.pop"):
+        IndividualPool(dev.grid, d["land_mask"], eco)
+    dev.close()
+
+
 def test_individual_pool_vs_reference(gpu, monkeypatch):
     """IndividualPool (individuals.py:37-191): the mirror draws the reference's pool (same cells, species, jitter), and 30 long
     physics steps fire the 12 sub-steps the reference fired, with its energies and stress days."""

@@ -206,6 +206,20 @@ def test_ecology_substep_matches_reference(monkeypatch):
     assert float(np.sum(psp.default_leaf_reflectance(pb) * psp.band_weights_from_mode(pb))) == meta["leaf_scalar"]
     R0 = np.clip(1.0 - psp.absorbance_from_peaks(pb, [(450.0, 40.0, 0.6), (680.0, 30.0, 0.8)]), 0.0, 1.0)
     assert np.array_equal(np.tile(R0, (d["R_species"].shape[0], 1)), d["R_species"])
+    # the adapter without a population (QD_ECO_USE_LAI=0): scalar leaf alpha on land, every 2nd call
+    o1 = oeco.EcoAdapter(None, meta["leaf_scalar"], soil_ref=meta["soil_ref"], substep_every_nphys=2)
+    got1 = [o1.step_subdaily(None, meta["dt"], land_mask=mask) for _ in range(2)]
+    assert got1[0] is None and np.array_equal(got1[1], d["ref_alpha_m1"], equal_nan=True)
+    # the product's host-side pool sampling draws the reference's pool (same generator calls in the same order)
+    from qingdai_amd import ecology as peco
+    for k in [k for k in os.environ if k.startswith("QD_ECO_SPECIES_")]:
+        monkeypatch.delenv(k)
+    R, tol = peco.species_tables(pb, d["R_species"].shape[0])
+    assert np.array_equal(R, d["R_species"])
+    arr = peco.sample_pool(mask, d["species_w"], R, tol, 16, 0.3, 5)
+    for key, ref in (("sample_j", "ind_sample_j"), ("sample_i", "ind_sample_i"), ("indiv_cell_index", "ind_cell"),
+                     ("indiv_Ab", "ind_Ab"), ("indiv_tol", "ind_tol")):
+        assert np.array_equal(arr[key], d[ref]), key
 
 
 def test_nonfinite_inputs_match_reference():
