@@ -248,6 +248,7 @@ int qd_comm_init(qd_handle h, const void* id128, size_t bytes);   /* all ranks: 
  * logic (margins, ring halos, reductions) without RCCL; handles[] ordered by rank */
 int qd_comm_init_local(qd_handle* handles, int n);
 int qd_comm_stats(qd_handle h, int* halo_exchanges);
+int qd_comm_allreduce_count(qd_handle h, int* allreduces);        /* all-reduce collectives issued so far (statistics) */
 int qd_comm_barrier(qd_handle h);
 int qd_comm_allreduce_max(qd_handle h, double* inout, int n);     /* bench timing: max over ranks */
 

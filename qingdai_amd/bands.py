@@ -103,6 +103,14 @@ class BandGroup:
             out.append(n.value)
         return out
 
+    def allreduces(self):
+        out = []
+        for d in self.devs:
+            n = ctypes.c_int(0)
+            d.lib.qd_comm_allreduce_count(d.h, ctypes.byref(n))
+            out.append(n.value)
+        return out
+
     def close(self):
         for d in self.devs:
             d.close()

@@ -261,6 +261,14 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
     hipMemsetAsync(c->dcount, 0, 8 * sizeof(unsigned long long), c->stream);
     hipMemsetAsync(c->hist, 0, 2 * QD_HIST_BINS * sizeof(unsigned int), c->stream);
     hipMemsetAsync(c->sel_state, 0, 8 * sizeof(unsigned long long), c->stream);
+    if (!full) {
+        if ((e = hipMalloc(&c->med_pred, 64 * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
+        hipMemsetAsync(c->med_pred, 0, 64 * sizeof(double), c->stream);
+        if ((e = hipMalloc(&c->med_gather, (size_t)std::max(1, d->world) * 4096 * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
+        if ((e = hipMalloc(&c->sel_ccount, 2 * sizeof(unsigned int))) != hipSuccess) return bail("hipMalloc", e);
+        hipMemsetAsync(c->sel_ccount, 0, 2 * sizeof(unsigned int), c->stream);
+        { const char* ef = std::getenv("QD_MEDIAN_PREDICT"); if (ef && ef[0] == '0') c->med_predict = 0; }
+    }
     if (full) {
         if ((e = hipMalloc(&c->sel_cand, 2 * cells * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
         if ((e = hipMalloc(&c->sel_ccount, 2 * sizeof(unsigned int))) != hipSuccess) return bail("hipMalloc", e);
@@ -309,6 +317,7 @@ extern "C" int qd_destroy(qd_handle c) {
     qd_eco_free(c);
     if (c->sel_cand) hipFree(c->sel_cand); if (c->sel_ccount) hipFree(c->sel_ccount);
     if (c->med_pred) hipFree(c->med_pred);
+    if (c->med_gather) hipFree(c->med_gather);
     if (c->hpin) hipHostFree(c->hpin);
     if (c->hpin_rows) hipHostFree(c->hpin_rows);
     if (c->stage) hipHostFree(c->stage);

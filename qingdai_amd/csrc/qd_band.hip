@@ -128,6 +128,7 @@ int qd_exchange(qd_ctx* c, const QdUse* slots, int n) {
 
 int qd_allreduce_f64(qd_ctx* c, double* dptr, int n, int op) {
     if (c->geo.full) return 0;
+    c->allreduces++;
     if (c->comm) {
         ncclResult_t r = ncclAllReduce(dptr, dptr, n, ncclDouble, op ? ncclMax : ncclSum, (ncclComm_t)c->comm, c->stream);
         if (r != ncclSuccess) { c->err = std::string("allreduce: ") + ncclGetErrorString(r); return -1; }
@@ -154,8 +155,10 @@ int qd_allreduce_f64(qd_ctx* c, double* dptr, int n, int op) {
     return qd_fail(c, "band handle without a communicator");
 }
 
+#define QD_LOCAL_U32_MAX (64 * 2 * 4096)        // the gathered median segments of up to 64 in-process bands
 int qd_allreduce_u32(qd_ctx* c, unsigned int* dptr, int n) {
     if (c->geo.full) return 0;
+    c->allreduces++;
     if (c->comm) {
         ncclResult_t r = ncclAllReduce(dptr, dptr, n, ncclUint32, ncclSum, (ncclComm_t)c->comm, c->stream);
         if (r != ncclSuccess) { c->err = std::string("allreduce: ") + ncclGetErrorString(r); return -1; }
@@ -164,12 +167,12 @@ int qd_allreduce_u32(qd_ctx* c, unsigned int* dptr, int n) {
     if (c->lgroup) {
         QdLocalGroup* g = c->lgroup;
         const int world = c->desc.world, rank = c->desc.rank;
-        if (n > 4096) return qd_fail(c, "qd_allreduce_u32: n > 4096");
-        QD_HIP(c, hipMemcpyAsync(&g->stage_u[(size_t)rank * 4096], dptr, n * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        if (n > QD_LOCAL_U32_MAX) return qd_fail(c, "qd_allreduce_u32: n too large for the in-process transport");
+        QD_HIP(c, hipMemcpyAsync(&g->stage_u[(size_t)rank * QD_LOCAL_U32_MAX], dptr, n * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
         QD_HIP(c, hipStreamSynchronize(c->stream));
         pthread_barrier_wait(&g->bar);
         std::vector<unsigned int> acc(n);
-        for (int k = 0; k < n; ++k) { unsigned a = 0; for (int r = 0; r < world; ++r) a += g->stage_u[(size_t)r * 4096 + k]; acc[k] = a; }
+        for (int k = 0; k < n; ++k) { unsigned a = 0; for (int r = 0; r < world; ++r) a += g->stage_u[(size_t)r * QD_LOCAL_U32_MAX + k]; acc[k] = a; }
         pthread_barrier_wait(&g->bar);
         QD_HIP(c, hipMemcpyAsync(dptr, acc.data(), n * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
         QD_HIP(c, hipStreamSynchronize(c->stream));
@@ -206,7 +209,7 @@ extern "C" int qd_comm_init_local(qd_handle* handles, int n) {
     g->peers.assign(handles, handles + n);
     pthread_barrier_init(&g->bar, nullptr, (unsigned)n);
     g->stage_d.assign((size_t)n * 64, 0.0);
-    g->stage_u.assign((size_t)n * 4096, 0u);
+    g->stage_u.assign((size_t)n * QD_LOCAL_U32_MAX, 0u);
     for (int k = 0; k < n; ++k) {
         if (!handles[k] || handles[k]->desc.rank != k || handles[k]->desc.world != n) { delete g; return -1; }
         handles[k]->lgroup = g;
@@ -233,3 +236,4 @@ extern "C" int qd_comm_barrier(qd_handle c) {
 }
 
 extern "C" int qd_comm_stats(qd_handle c, int* exchanges) { if (!c || !exchanges) return -1; *exchanges = c->exchanges; return 0; }
+extern "C" int qd_comm_allreduce_count(qd_handle c, int* allreduces) { if (!c || !allreduces) return -1; *allreduces = c->allreduces; return 0; }

@@ -179,6 +179,7 @@ struct qd_ctx {
     double* med_pred = nullptr;      // [4 sites][16]: last median, valid flag, statistics, published bracket (see qd_reduce.hip): predicted median brackets (qd_reduce.hip)
     int med_predict = 1;             // QD_MEDIAN_PREDICT=0: always the two-histogram-pass select
     int med_seen[4] = {0, 0, 0, 0};  // call sites that have a window centre on the device
+    double* med_gather = nullptr;    // band handles: [world][4 + 4092] gathered candidate segments of the windowed median
     double* hpin = nullptr;        // pinned host scalars
     double* hpin_rows = nullptr;   // pinned, 2 x slab rows: per-row partial maxima read back in one copy
     double wsum_ocean = 0, wsum_all = 0;
@@ -197,6 +198,7 @@ struct qd_ctx {
     void* comm = nullptr;          // RCCL communicator (one process per GPU)
     struct QdLocalGroup* lgroup = nullptr;   // in-process peers on one device (tests of the band logic)
     int exchanges = 0;             // statistics
+    int allreduces = 0;
     // timing
     const char* lap_tag = "k_laplacian";       // timing-group names of the two del^4 kernels
     const char* hyp_tag = "k_hyper_apply";     // (the ocean switches them to ocean_* around its calls)

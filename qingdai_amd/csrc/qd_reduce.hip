@@ -371,10 +371,13 @@ k_sel_final(unsigned long long* st, const double* __restrict__ cand, unsigned in
 // finishing workgroup runs the radix select over the whole field itself -- slow, rare, and it re-centres the window.
 // pred[site]: {last median, -, -, valid, hits, misses, last list length, last count | lo, hi, -, bracket ok}
 #define QD_MED_SITES 4
+#define QD_MED_BAND_CAP 4092u      // candidates per band in the gathered segments (4096 doubles each)
 #define QD_MED_WSHIFT 44
 __global__ void __launch_bounds__(QD_BLOCK)
 k_med_hist(QdGeom G, const double* __restrict__ x, int transform, double tparam, double* pred, unsigned long long* st,
-           unsigned int* hist) {
+           unsigned int* hist, int mode) {
+    // mode 0: histogram + scan by the last workgroup (whole-globe handles)
+    // mode 1: histogram only   mode 2: scan only (one workgroup) -- latitude bands all-reduce the histogram in between
     __shared__ unsigned int sh[QD_HIST_BINS + 2];             // + count of positives, + count below the window
     __shared__ unsigned long long s_st[2];
     __shared__ int s_last;
@@ -384,6 +387,7 @@ k_med_hist(QdGeom G, const double* __restrict__ x, int transform, double tparam,
     const unsigned long long cbits = (unsigned long long)__double_as_longlong(valid ? pred[0] : 1.0);
     const unsigned long long four = 4ull << 52;
     const unsigned long long base = cbits > four ? cbits - four : 0ull;
+    if (mode != 2) {
     for (int k = t; k < QD_HIST_BINS + 2; k += QD_BLOCK) sh[k] = 0u;
     __syncthreads();
     const int jstep = gridDim.x * QD_BLOCK;
@@ -422,6 +426,7 @@ k_med_hist(QdGeom G, const double* __restrict__ x, int transform, double tparam,
     __syncthreads();
     for (int k = t; k < QD_HIST_BINS + 2; k += QD_BLOCK) if (sh[k]) atomicAdd(&hist[k], sh[k]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (mode == 1) return;
     __syncthreads();
     if (t == 0) {
         const unsigned long long ticket = atomicAdd(&st[6], 1ull);
@@ -429,6 +434,7 @@ k_med_hist(QdGeom G, const double* __restrict__ x, int transform, double tparam,
     }
     __syncthreads();
     if (!s_last) return;
+    }   // mode != 2
     // ---- last workgroup: bins of the two middle ranks
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     for (int k = t; k < QD_HIST_BINS; k += QD_BLOCK) sh[k] = __hip_atomic_load(&hist[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -493,7 +499,7 @@ __global__ void k_med_seed(double* pred, const double* out, const unsigned long 
 
 __global__ void __launch_bounds__(QD_BLOCK)
 k_med_bracket(QdGeom G, const double* __restrict__ x, int transform, double tparam, const double* __restrict__ pred,
-              unsigned long long* st, double* __restrict__ cand, unsigned int* __restrict__ ccount) {
+              unsigned long long* st, double* __restrict__ cand, unsigned int* __restrict__ ccount, unsigned int cap) {
     const bool valid = pred[3] != 0.0;
     const double lo = valid ? pred[0] : 0.0, hi = valid ? pred[1] : -1.0;     // invalid: empty bracket, the finisher falls back
     const int t = threadIdx.x, lane = t & 63;
@@ -525,7 +531,8 @@ k_med_bracket(QdGeom G, const double* __restrict__ x, int transform, double tpar
                     const int leader = __ffsll((long long)m) - 1;
                     if (lane == leader) base = atomicAdd(&ccount[0], (unsigned int)__popcll(m));
                     base = (unsigned int)__shfl((int)base, leader, 64);
-                    if (in) cand[base + (unsigned int)__popcll(m & lt)] = v;
+                    const unsigned int idx = base + (unsigned int)__popcll(m & lt);
+                    if (in && idx < cap) cand[idx] = v;          // the count keeps running past the capacity: overflow is visible
                 }
             }
         }
@@ -543,35 +550,68 @@ k_med_bracket(QdGeom G, const double* __restrict__ x, int transform, double tpar
 }
 
 // value of element k of the select source: the candidate list, or (fallback) the transformed field; non-positive = skip
-__device__ __forceinline__ double qd_med_src(const double* __restrict__ list, const double* __restrict__ field, bool use_field,
-                                             size_t k, int transform, double tparam) {
-    return use_field ? qd_med_value(field[k], transform, tparam) : list[k];
+// src 0: candidate list; 1: the field; 2: the gathered per-band segments [world][4 + cap] = {m_r, c_lo_r, M_r, -, candidates}
+__device__ __forceinline__ double qd_med_src(const double* __restrict__ list, const double* __restrict__ field, int src,
+                                             size_t k, int transform, double tparam, unsigned int cap) {
+    if (src == 1) return qd_med_value(field[k], transform, tparam);
+    if (src == 0) return list[k];
+    const size_t r = k / cap, i = k - r * cap;
+    const double* seg = list + r * (size_t)(cap + 4u);
+    return ((double)i < seg[2]) ? seg[4 + i] : 0.0;
+}
+
+// band handles: counts of the bracket pass into the header of this band's segment, select state reset
+__global__ void k_med_pack(unsigned long long* st, unsigned int* ccount, double* seg) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        seg[0] = (double)st[0]; seg[1] = (double)st[1]; seg[2] = (double)ccount[0]; seg[3] = 0.0;
+        st[0] = 0ull; st[1] = 0ull; ccount[0] = 0u;
+    }
 }
 
 __global__ void __launch_bounds__(QD_FIN_BLOCK)
 k_med_final(unsigned long long* st, const double* __restrict__ cand, unsigned int* ccount, double* pred,
             const double* __restrict__ field, unsigned long long n_field, int transform, double tparam, double dflt, double* out,
-            unsigned long long* count_out) {
+            unsigned long long* count_out, int world, unsigned int cap, double* miss_flag) {
+    // world > 0: latitude bands -- `cand` holds the all-gathered segments; counts are the sums of their headers; when the
+    // ranks are not inside the gathered lists (a band overflowed its capacity, or the window missed) nothing is written but
+    // *miss_flag = 1 and the host falls back to the digit-by-digit select on every band
     __shared__ unsigned int sh[QD_HIST_BINS];
     __shared__ unsigned int wtot[QD_FIN_BLOCK / 64];
     __shared__ unsigned long long s_prefix, s_rank;
     __shared__ double s_min[QD_FIN_BLOCK / 64];
     __shared__ unsigned int s_cnt[QD_FIN_BLOCK / 64];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const unsigned long long m = __hip_atomic_load(&st[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long c_lo = __hip_atomic_load(&st[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned int M = __hip_atomic_load(&ccount[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long m, c_lo;
+    unsigned int M;
+    bool overflow = false;
+    if (world > 0) {
+        m = 0ull; c_lo = 0ull; M = 0u;
+        for (int r = 0; r < world; ++r) {
+            const double* seg = cand + (size_t)r * (cap + 4u);
+            m += (unsigned long long)seg[0]; c_lo += (unsigned long long)seg[1];
+            overflow |= seg[2] > (double)cap;
+            M += (unsigned int)(seg[2] > (double)cap ? (double)cap : seg[2]);
+        }
+    } else {
+        m = __hip_atomic_load(&st[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c_lo = __hip_atomic_load(&st[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        M = __hip_atomic_load(&ccount[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     const bool valid = pred[11] != 0.0;
     const double plo = pred[8], phi = pred[9];
     __syncthreads();                                                     // every thread has read the state before thread 0 resets it
     if (m == 0ull) {
-        if (t == 0) { *out = dflt; if (count_out) *count_out = 0ull; pred[3] = 0.0; st[0] = 0ull; st[1] = 0ull; ccount[0] = 0u; }
+        if (t == 0) {
+            *out = dflt; if (count_out) *count_out = 0ull; pred[3] = 0.0;
+            if (world > 0) *miss_flag = 0.0; else { st[0] = 0ull; st[1] = 0ull; ccount[0] = 0u; }
+        }
         return;
     }
     const unsigned long long k1 = (m - 1ull) / 2ull, k2 = m / 2ull;
-    const bool hit = valid && c_lo <= k1 && k2 < c_lo + (unsigned long long)M;
-    const bool use_field = !hit;
-    const size_t N = use_field ? (size_t)n_field : (size_t)M;
+    const bool hit = valid && !overflow && c_lo <= k1 && k2 < c_lo + (unsigned long long)M;
+    if (world > 0 && !hit) { if (t == 0) *miss_flag = 1.0; return; }
+    const int src = (world > 0) ? 2 : (hit ? 0 : 1);
+    const size_t N = (src == 2) ? (size_t)world * cap : (src == 1 ? (size_t)n_field : (size_t)M);
     // leading bits shared by every value inside [lo, hi] (positive doubles order like their bit patterns)
     int common = 0;
     unsigned long long pre0 = 0ull;
@@ -597,7 +637,7 @@ k_med_final(unsigned long long* st, const double* __restrict__ cand, unsigned in
         __syncthreads();
         const unsigned long long pre = up >= 64 ? 0ull : (s_prefix >> up), r = s_rank;
         for (size_t k = t; k < N; k += QD_FIN_BLOCK) {
-            const double v = qd_med_src(cand, field, use_field, k, transform, tparam);
+            const double v = qd_med_src(cand, field, src, k, transform, tparam, cap);
             if (!(v > 0.0)) continue;
             const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
             if (up >= 64 || (bits >> up) == pre) atomicAdd(&sh[(unsigned int)((bits >> shift) & ((1u << width) - 1u))], 1u);
@@ -628,7 +668,7 @@ k_med_final(unsigned long long* st, const double* __restrict__ cand, unsigned in
         unsigned int c_eq = 0;
         double mn = DBL_MAX;
         for (size_t k = t; k < N; k += QD_FIN_BLOCK) {
-            const double v = qd_med_src(cand, field, use_field, k, transform, tparam);
+            const double v = qd_med_src(cand, field, src, k, transform, tparam, cap);
             if (!(v > 0.0)) continue;
             c_eq += (v == v1) ? 1u : 0u;
             if (v > v1 && v < mn) mn = v;
@@ -651,7 +691,7 @@ k_med_final(unsigned long long* st, const double* __restrict__ cand, unsigned in
         if (!hit) { pred[13] = pred[12]; pred[14] = pred[0]; pred[15] = med; }  // last miss: call number, window centre, result
         pred[0] = med; pred[3] = 1.0;                                     // centre of the next call's window
         pred[hit ? 4 : 5] += 1.0; pred[6] = (double)M; pred[7] = (double)m;      // statistics (QD_MEDIAN_DEBUG)
-        st[0] = 0ull; st[1] = 0ull; ccount[0] = 0u;
+        if (world > 0) *miss_flag = 0.0; else { st[0] = 0ull; st[1] = 0ull; ccount[0] = 0u; }
     }
 }
 
@@ -682,11 +722,12 @@ int qd_median_positive_dev(qd_ctx* c, const double* x, double dflt, int slot, in
         // windowed histogram around the site's last median, one collecting pass, one finishing workgroup
         double* pred = c->med_pred + 16 * site;
         if (c->med_seen[site]) {
-            hipLaunchKernelGGL(k_med_hist, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, pred, c->sel_state, c->hist);
+            hipLaunchKernelGGL(k_med_hist, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, pred, c->sel_state, c->hist, 0);
             hipLaunchKernelGGL(k_med_bracket, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, pred + 8, c->sel_state,
-                               c->sel_cand, c->sel_ccount);
+                               c->sel_cand, c->sel_ccount, (unsigned int)c->geo.cells());
             hipLaunchKernelGGL(k_med_final, dim3(1), dim3(QD_FIN_BLOCK), 0, c->stream, c->sel_state, c->sel_cand, c->sel_ccount, pred, x,
-                               (unsigned long long)c->geo.cells(), transform, tparam, dflt, c->dscal + slot, c->dcount);
+                               (unsigned long long)c->geo.cells(), transform, tparam, dflt, c->dscal + slot, c->dcount, 0, 0u,
+                               (double*)nullptr);
             return 0;
         }
         c->med_seen[site] = 1;                                // first use: the digit-by-digit select below, then seed the window
@@ -711,6 +752,31 @@ int qd_median_positive_dev(qd_ctx* c, const double* x, double dflt, int slot, in
                            (unsigned long long)c->geo.cells(), 22, dflt, c->dscal + slot, c->dcount);
         return 0;
     }
+    const bool band_window = !c->geo.full && c->med_pred && c->med_gather && c->med_predict && site >= 0 && site < QD_MED_SITES;
+    double* bpred = band_window ? c->med_pred + 16 * site : nullptr;
+    if (band_window && c->med_seen[site]) {
+        // latitude bands, 2 collectives instead of 6: all-reduce the windowed histogram, every band publishes the same bracket,
+        // collects its own candidates into its segment, one all-reduce of the zero-padded segments acts as an all-gather, every
+        // band selects from the same gathered list.  An overflowing segment or a missed window shows up in the flag the host
+        // reads back (bands synchronise with the host once per step anyway) and falls through to the six-pass select below.
+        const int world = c->desc.world, rank = c->desc.rank;
+        const unsigned int cap = QD_MED_BAND_CAP;
+        const size_t segd = (size_t)cap + 4u;
+        hipLaunchKernelGGL(k_med_hist, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, bpred, c->sel_state, c->hist, 1);
+        if (qd_allreduce_u32(c, c->hist, QD_HIST_BINS + 2)) return -1;
+        hipLaunchKernelGGL(k_med_hist, dim3(1, 1), dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, bpred, c->sel_state, c->hist, 2);
+        QD_HIP(c, hipMemsetAsync(c->med_gather, 0, (size_t)world * segd * sizeof(double), c->stream));
+        double* seg = c->med_gather + (size_t)rank * segd;
+        hipLaunchKernelGGL(k_med_bracket, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, bpred + 8, c->sel_state,
+                           seg + 4, c->sel_ccount, cap);
+        hipLaunchKernelGGL(k_med_pack, dim3(1), dim3(64), 0, c->stream, c->sel_state, c->sel_ccount, seg);
+        if (qd_allreduce_u32(c, (unsigned int*)c->med_gather, (int)(2 * world * segd))) return -1;     // x + 0 + ... + 0: exact
+        hipLaunchKernelGGL(k_med_final, dim3(1), dim3(QD_FIN_BLOCK), 0, c->stream, c->sel_state, c->med_gather, c->sel_ccount, bpred, x,
+                           0ull, transform, tparam, dflt, c->dscal + slot, c->dcount, world, cap, c->dscal + QD_S_TMP1);
+        QD_HIP(c, hipMemcpyAsync(c->hpin + 32, c->dscal + QD_S_TMP1, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        QD_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->hpin[32] == 0.0) return 0;
+    }
     for (int p = 0; p < 6; ++p) {
         if (c->geo.full) {
             hipLaunchKernelGGL(k_sel_pass, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, c->sel_state,
@@ -724,5 +790,9 @@ int qd_median_positive_dev(qd_ctx* c, const double* x, double dflt, int slot, in
         }
     }
     hipLaunchKernelGGL(k_sel_finish, dim3(1), dim3(64), 0, c->stream, c->sel_state, dflt, c->dscal + slot, c->dcount);
+    if (band_window) {                                        // (re-)centre the window of this call site on the exact result
+        hipLaunchKernelGGL(k_med_seed, dim3(1), dim3(64), 0, c->stream, bpred, c->dscal + slot, c->dcount);
+        c->med_seen[site] = 1;
+    }
     return 0;
 }
