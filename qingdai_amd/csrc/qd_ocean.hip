@@ -769,27 +769,13 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
             qd_mark(c, {T1, F[QD_F_ETA]}, m1);
             double*& T1s = c->scratch[0];
             double* T2 = qd_scratch(c, 1);
-            if (false) {
-                const int m2 = qd_plan(c, {QD_IN(T1s, 2), QD_IN(F[QD_F_QNET], 0), QD_IN8(c->icemask, 0), QD_IN(F[QD_F_UO], 1),
-                                           QD_IN(F[QD_F_VO], 1), QD_IN(F[QD_F_ETA], 0)});
-                if (m2 < 0) return -1;
-                double* u2 = qd_scratch(c, 2); double* v2 = qd_scratch(c, 3);
-                QD_ROWS(c, m2, G, hipLaunchKernelGGL(k_sst_outlier_fused, qd_grid2d(G), blk, 0, c->stream, G, c->tabs, c->dlat,
-                                                     c->dlon, p.a, HP, c->scratch[0], T2, F[QD_F_QNET], c->land, c->icemask,
-                                                     F[QD_F_UO], F[QD_F_VO], u2, v2, F[QD_F_ETA], p.ocean_max_u, p.eta_cap,
-                                                     p.ocean_outlier == 0 ? 1 : 0, (const double*)nullptr, (const double*)nullptr, 0,
-                                                     0.0, (double*)nullptr));
-                qd_mark(c, {T2, u2, v2, F[QD_F_ETA]}, m2);
-                qd_swap(c, QD_F_SST, 1); qd_swap(c, QD_F_UO, 2); qd_swap(c, QD_F_VO, 3);
-            } else {
-                const int m2 = qd_plan(c, {QD_IN(T1s, 2), QD_IN(F[QD_F_QNET], 0), QD_IN8(c->icemask, 0)});
-                if (m2 < 0) return -1;
-                QD_ROWS(c, m2, G, hipLaunchKernelGGL(k_sst_diffuse_heat, qd_grid2d(G), blk, 0, c->stream, G, c->tabs.cos05,
-                                                     c->dlat, c->dlon, p.a, HP, c->scratch[0], T2, F[QD_F_QNET], c->land,
-                                                     c->icemask));
-                qd_mark(c, {T2}, m2);
-                qd_swap(c, QD_F_SST, 1);
-            }
+            const int m2 = qd_plan(c, {QD_IN(T1s, 2), QD_IN(F[QD_F_QNET], 0), QD_IN8(c->icemask, 0)});
+            if (m2 < 0) return -1;
+            QD_ROWS(c, m2, G, hipLaunchKernelGGL(k_sst_diffuse_heat, qd_grid2d(G), blk, 0, c->stream, G, c->tabs.cos05,
+                                                 c->dlat, c->dlon, p.a, HP, c->scratch[0], T2, F[QD_F_QNET], c->land,
+                                                 c->icemask));
+            qd_mark(c, {T2}, m2);
+            qd_swap(c, QD_F_SST, 1);
         }
         }
         if (!c->use_fused) {
