@@ -222,6 +222,8 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
         return qd_fail(nullptr, "qd_create: bad latitude band");
     const bool full = (d->row0 == 0 && d->n_rows == d->n_lat);
     if (full && d->halo != 0) return qd_fail(nullptr, "qd_create: a whole-globe handle takes halo = 0");
+    // (a band must be shorter than the globe by at least its two halos: halo rows alias owned rows with period n_lat otherwise)
+    if (!full && d->n_rows + 2 * d->halo > d->n_lat) return qd_fail(nullptr, "qd_create: band + 2 halos taller than the grid");
     if (!full && d->halo < 5) return qd_fail(nullptr, "qd_create: band handles need halo >= 5 rows");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return qd_fail(nullptr, "qd_create: no HIP device visible");

@@ -204,7 +204,7 @@ extern "C" int qd_comm_init(qd_handle c, const void* id128, size_t bytes) {
 
 // handles[] ordered by rank, all on one device, each driven by its own host thread
 extern "C" int qd_comm_init_local(qd_handle* handles, int n) {
-    if (!handles || n < 2) return -1;
+    if (!handles || n < 1) return -1;
     QdLocalGroup* g = new QdLocalGroup();
     g->peers.assign(handles, handles + n);
     pthread_barrier_init(&g->bar, nullptr, (unsigned)n);

@@ -202,3 +202,43 @@ def test_bands_ecology_substep(gpu, monkeypatch):
         e = relerr(np.nan_to_num(got[k]), np.nan_to_num(ref[k]))
         assert e < 1e-12, (k, e)
     assert np.array_equal(np.isnan(got["ECO_ALPHA"]), np.isnan(ref["ECO_ALPHA"]))
+
+
+def test_rccl_transport_equals_in_process_transport(gpu, monkeypatch):
+    """The RCCL transport itself, on ONE GPU: a communicator of one rank whose ring neighbours are the rank itself
+    (grouped ncclSend / ncclRecv to self, ncclAllReduce of f64 scalars, of the 2050-counter histogram and of the 65 k-word gathered
+    median segments) must move exactly the bytes the in-process transport moves.  The band covers 41 of 91 rows, so its halos are
+    refreshed with its OWN edge rows -- not a physical configuration, but every collective of the band code runs (halo exchanges,
+    eta sums, CFL maxima, precipitation sums, both median paths), and both transports must agree bit for bit on every field."""
+    import ctypes
+    from qingdai_amd.bands import init_rccl
+    from qingdai_amd.device import Device
+    monkeypatch.setenv("MASTER_PORT", "29731")
+    nlat, nlon, nsteps = 91, 144, 5
+    qa, grid, mask, alb, fric, p = _setup(nlat, nlon, dict(energy_w=1.0))
+    forcing = qa.ThermalForcing(qa.SphericalGrid(nlat, nlon), qa.OrbitalSystem())
+    stars = forcing.star_table([i * 300.0 for i in range(nsteps)])
+    st = _seed_state(nlat, nlon, 21)
+    static = {"LAND_MASK": mask, "FRICTION": fric, "BASE_ALBEDO": alb}
+    names = ["U", "V", "H", "TS", "Q", "CLOUD", "UO", "VO", "ETA", "SST", "ALBEDO", "PRECIP"]
+    out, counts = {}, {}
+    for transport in ("local", "rccl"):
+        dev = Device(qa.SphericalGrid(nlat, nlon), p, row0=25, n_rows=41, halo=12, rank=0, world=1)
+        if transport == "local":
+            arr = (ctypes.c_void_p * 1)(dev.h)
+            assert dev.lib.qd_comm_init_local(arr, 1) == 0
+        else:
+            init_rccl(dev, 0, 1, tag="self")
+        for k, v in {**static, **st}.items():
+            dev.upload_now(k, v)
+        dev.step_n(stars, 300.0, with_ocean=True, with_physics=True, pass_albedo=True)
+        out[transport] = {k: dev.get(k)[25:66].copy() for k in names}
+        ne, na = ctypes.c_int(0), ctypes.c_int(0)
+        dev.lib.qd_comm_stats(dev.h, ctypes.byref(ne)); dev.lib.qd_comm_allreduce_count(dev.h, ctypes.byref(na))
+        counts[transport] = (ne.value, na.value)
+        dev.close()
+    print("halo exchanges, all-reduces:", counts)
+    assert counts["local"] == counts["rccl"] and counts["rccl"][0] > 10 and counts["rccl"][1] > 20
+    for k in names:
+        assert np.array_equal(out["local"][k], out["rccl"][k], equal_nan=True), k
+        assert np.isfinite(out["rccl"][k]).all(), k
