@@ -181,9 +181,9 @@ def main():
     dt = 300.0
     band = None
     if world > 1:
-        from qingdai_amd.bands import band_ranges, required_halo
+        from qingdai_amd.bands import band_ranges, preferred_halo
         r0, n = band_ranges(args.nlat, world)[rank]
-        band = (r0, n, required_halo(args.nlat, dt))
+        band = (r0, n, preferred_halo(args.nlat, world, dt))
     grid, m, oc, forcing, mask, base_albedo, friction = build_case(args.nlat, args.nlon, with_ocean, device=local_rank,
                                                                    band=band, rank=rank, world=world)
     dev = m._dev

@@ -44,6 +44,23 @@ def required_halo(n_lat, dt=300.0):
     return max(12, 2 * R + 4 + 2 + 2)
 
 
+def preferred_halo(n_lat, world, dt=300.0):
+    """Halo used by multi-rank runs: at least `required_halo`, and deep enough (32 rows where the bands are tall enough) that
+    the ocean sub-step loop exchanges once per ~3 sub-steps instead of every sub-step -- a halo exchange costs a collective's
+    latency (~30 us) whatever its size.  Measured on the RCCL self-ring, 721x1440: a 1/8 band runs at 1.08 / 1.03 / 0.96 ms per
+    step with 16 / 32 / 48 halo rows; the self-ring moves halos at HBM speed, over xGMI (~50 GB/s per direction) the 4.4 MB that
+    a 48-row exchange of the eight ocean slabs carries would cost more than the latency it saves, hence 32.  QD_BAND_HALO
+    overrides."""
+    import os
+    env = os.environ.get("QD_BAND_HALO")
+    req = required_halo(n_lat, dt)
+    if env:
+        return max(req, int(env))
+    rows = min(n for _, n in band_ranges(n_lat, world))
+    deep = min(32, rows, (int(n_lat) - rows - 1) // 2)     # a band is at least as tall as its halo; slab rows stay <= n_lat
+    return max(req, deep)
+
+
 class BandGroup:
     """N band handles of one grid in one process (threads); test vehicle for the band logic."""
 

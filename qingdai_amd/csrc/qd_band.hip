@@ -69,6 +69,14 @@ int qd_plan(qd_ctx* c, std::initializer_list<QdUse> in, int want) {
         // refresh every listed slab that is not already at full margin in the same grouped exchange
         std::vector<QdUse> ex;
         for (const QdUse& u : in) if (*u.slot && qd_vm_get(c, *u.slot) < H) ex.push_back(u);
+        // slabs of the enclosing loop that will run out of margin soon ride on the same grouped exchange: one collective
+        // instead of several out-of-phase ones (an exchange is latency, not bandwidth)
+        for (const QdUse& u : c->corefresh) {
+            if (!*u.slot || qd_vm_get(c, *u.slot) >= H) continue;
+            bool dup = false;
+            for (const QdUse& e : ex) dup |= (*e.slot == *u.slot);
+            if (!dup) ex.push_back(u);
+        }
         if (qd_exchange(c, ex.data(), (int)ex.size())) return -1;
     }
     int out = INT_MAX;

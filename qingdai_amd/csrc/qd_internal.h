@@ -120,6 +120,7 @@ __device__ __forceinline__ QdTile qd_tile() {
 }
 
 // ---------------------------------------------------------------- host context
+struct QdUse { void** slot; int radius; int u8; };
 // ecology sub-step: clocks and cache flags of PopulationManager / EcologyAdapter / IndividualPool (qd_eco.hip)
 #define QD_MAXBANDS 32
 struct QdEco {
@@ -197,6 +198,7 @@ struct qd_ctx {
     // comm
     void* comm = nullptr;          // RCCL communicator (one process per GPU)
     struct QdLocalGroup* lgroup = nullptr;   // in-process peers on one device (tests of the band logic)
+    std::vector<struct QdUse> corefresh;   // slabs refreshed along with any halo exchange that happens anyway (set around loops)
     int exchanges = 0;             // statistics
     int allreduces = 0;
     // timing
@@ -228,7 +230,6 @@ struct QdScope {               // optional per-kernel-group timing with hipEvent
 };
 
 // ---- latitude-band planning (qd_band.hip) ----------------------------------------------------
-struct QdUse { void** slot; int radius; int u8; };
 #define QD_IN(ptr, r) QdUse{(void**)&(ptr), (r), 0}
 #define QD_IN8(ptr, r) QdUse{(void**)&(ptr), (r), 1}
 // makes sure every input slab is valid `radius` rows beyond what the launch will compute; exchanges

@@ -621,6 +621,10 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
     // whole-globe handles on the fused path defer "eta -= mean; nan_to_num; clip" of a sub-step to the load of the next
     // momentum kernel (and to k_eta_finalize after the last one): no k_eta_mean launch, no eta pass in the SST kernel
     const bool defer_eta = !band && do_diff && c->use_fused && p.ocean_k4_nsub == 1 && !do_shap && c->wsum_ocean > 0.0;
+    // latitude bands: whenever a sub-step has to exchange halos, every slab of the sub-step loop is refreshed in the same group
+    struct CoRefresh { qd_ctx* c; ~CoRefresh() { c->corefresh.clear(); } } corefresh_guard{c};
+    if (band) c->corefresh = {QD_IN(F[QD_F_UO], 0), QD_IN(F[QD_F_VO], 0), QD_IN(F[QD_F_ETA], 0), QD_IN(F[QD_F_SST], 0), QD_IN(taux, 0),
+                              QD_IN(tauy, 0), QD_IN(F[QD_F_QNET], 0), QD_IN8(c->icemask, 0)};
     for (int s = 0; s < n_sub; ++s) {
         if (do_diff && c->use_fused && p.ocean_k4_nsub == 1) {
             const int m = qd_plan(c, {QD_IN(F[QD_F_ETA], 5), QD_IN(F[QD_F_UO], 4), QD_IN(F[QD_F_VO], 4), QD_IN(taux, 4),
