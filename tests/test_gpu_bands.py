@@ -232,6 +232,10 @@ def test_rccl_transport_equals_in_process_transport(gpu, monkeypatch):
         for k, v in {**static, **st}.items():
             dev.upload_now(k, v)
         dev.step_n(stars, 300.0, with_ocean=True, with_physics=True, pass_albedo=True)
+        # what bench.py does around its timed region on every rank: barrier, max over ranks
+        assert dev.lib.qd_comm_barrier(dev.h) == 0
+        v = (ctypes.c_double * 2)(1.5, -2.0)
+        assert dev.lib.qd_comm_allreduce_max(dev.h, v, 2) == 0 and list(v) == [1.5, -2.0]
         out[transport] = {k: dev.get(k)[25:66].copy() for k in names}
         ne, na = ctypes.c_int(0), ctypes.c_int(0)
         dev.lib.qd_comm_stats(dev.h, ctypes.byref(ne)); dev.lib.qd_comm_allreduce_count(dev.h, ctypes.byref(na))
