@@ -75,6 +75,23 @@ def test_band_ranges_and_halo_sizing():
     assert required_halo(721) >= 2 * adv_reach(721, 300.0) + 8
 
 
+def test_preferred_halo_keeps_bands_valid(monkeypatch):
+    """The halo bench.py gives its ranks: never below the one-exchange-per-atmosphere-step minimum, never taller than a band,
+    never so tall that band + 2 halos exceed the globe (qd_create refuses that: halo rows would alias owned rows)."""
+    from qingdai_amd.bands import band_ranges, preferred_halo, required_halo
+    monkeypatch.delenv("QD_BAND_HALO", raising=False)
+    for nlat, world in ((721, 2), (721, 4), (721, 8), (1441, 8), (181, 2), (91, 4), (61, 2), (61, 3)):
+        h = preferred_halo(nlat, world)
+        assert h >= required_halo(nlat)
+        for _, n in band_ranges(nlat, world):
+            assert n >= h and n + 2 * h <= nlat, (nlat, world, h, n)
+    assert preferred_halo(721, 8) == 32 and preferred_halo(61, 2) == required_halo(61) + 3
+    monkeypatch.setenv("QD_BAND_HALO", "40")
+    assert preferred_halo(721, 8) == 40
+    monkeypatch.setenv("QD_BAND_HALO", "4")
+    assert preferred_halo(721, 8) == required_halo(721)
+
+
 @pytest.mark.timeout(240)
 def test_ring_halo_exchange_two_ranks_gloo(tmp_path):
     # Each rank is its own interpreter (torch + gloo live only there): the pytest process itself never
