@@ -249,6 +249,15 @@ int qd_comm_init(qd_handle h, const void* id128, size_t bytes);   /* all ranks: 
 int qd_comm_init_local(qd_handle* handles, int n);
 int qd_comm_stats(qd_handle h, int* halo_exchanges);
 int qd_comm_allreduce_count(qd_handle h, int* allreduces);        /* all-reduce collectives issued so far (statistics) */
+/* host ring: the ranks of ONE node all-reduce the few host-visible scalars of a step (eta sum per ocean sub-step, CFL maxima)
+ * through a POSIX shared-memory segment instead of an RCCL launch each; every rank passes the same `name` (unique per launch).
+ * Optional: without it those scalars go through RCCL like everything else. */
+int qd_comm_init_shm(qd_handle h, const char* name);
+int qd_comm_host_allreduce_count(qd_handle h, int* n);
+/* the ring by itself (no handle, no GPU): what tests/test_bands_cpu.py drives from several processes */
+int qd_hostring_open(const char* name, int rank, int world, void** ring_out);
+int qd_hostring_allreduce(void* ring, double* vals, int n, int op_max);   /* n <= 8; op_max 0 = sum in rank order, 1 = max */
+int qd_hostring_close(void* ring);
 int qd_comm_barrier(qd_handle h);
 int qd_comm_allreduce_max(qd_handle h, double* inout, int n);     /* bench timing: max over ranks */
 

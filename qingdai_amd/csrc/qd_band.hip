@@ -18,13 +18,106 @@
 #include <pthread.h>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+// ------------------------------------------------------------------ host ring: scalar all-reduce in shared memory
+// The eta sum between two ocean sub-steps and the CFL maxima are a handful of doubles that the host of every rank can read
+// (one event wait that the next launch needs anyway).  An RCCL all-reduce costs ~30 us for them, and the sub-step loop
+// needs one per sub-step; ranks of one node instead meet in a POSIX shared-memory segment (threads of an in-process group:
+// in plain memory): every rank publishes its values under a sequence number, waits until all ranks have published that
+// sequence, and reduces the slots in rank order -- the same sum on every rank, bit for bit, in ~1-2 us.  Two buffers by
+// sequence parity: a rank can only be one call ahead of the slowest one, because call s + 1 needs everybody's s + 1.
+#define QD_RING_MAXRANKS 64
+#define QD_RING_MAXVALS 8
+struct QdRingSeg {
+    std::atomic<unsigned long long> seq[QD_RING_MAXRANKS];
+    double vals[2][QD_RING_MAXRANKS][QD_RING_MAXVALS];
+};
+struct QdHostRing {
+    QdRingSeg* seg = nullptr;
+    int rank = 0, world = 1;
+    unsigned long long my_seq = 0;
+    bool mapped = false, owner = false;
+    std::string name;
+};
+static_assert(std::atomic<unsigned long long>::is_always_lock_free, "the ring needs lock-free 64-bit atomics");
+
+static int ring_allreduce(QdHostRing* r, double* v, int n, int op, double timeout_s) {
+    if (!r || !r->seg || n < 1 || n > QD_RING_MAXVALS) return -1;
+    QdRingSeg* g = r->seg;
+    const unsigned long long s = ++r->my_seq;
+    const int buf = (int)(s & 1ull);
+    for (int k = 0; k < n; ++k) g->vals[buf][r->rank][k] = v[k];
+    g->seq[r->rank].store(s, std::memory_order_release);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int q = 0; q < r->world; ++q) {
+        unsigned spins = 0;
+        while (g->seq[q].load(std::memory_order_acquire) < s) {
+            if ((++spins & 0x3FFu) == 0) {
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return -2;
+                sched_yield();
+            }
+        }
+    }
+    for (int k = 0; k < n; ++k) {
+        double a = g->vals[buf][0][k];
+        for (int q = 1; q < r->world; ++q) { const double b = g->vals[buf][q][k]; a = op ? (b > a ? b : a) : a + b; }
+        v[k] = a;
+    }
+    return 0;
+}
+
+// handle-free entry points (tests/test_bands_cpu.py drives them from several processes without a GPU)
+extern "C" int qd_hostring_open(const char* name, int rank, int world, void** out) {
+    if (!name || !out || world < 1 || world > QD_RING_MAXRANKS || rank < 0 || rank >= world) return -1;
+    QdHostRing* r = new QdHostRing();
+    r->rank = rank; r->world = world; r->name = name;
+    int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
+    if (fd < 0) { delete r; return -2; }
+    if (ftruncate(fd, sizeof(QdRingSeg)) != 0) { close(fd); delete r; return -3; }     // new pages read as zero: sequence 0
+    void* m = mmap(nullptr, sizeof(QdRingSeg), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) { delete r; return -4; }
+    r->seg = (QdRingSeg*)m; r->mapped = true; r->owner = (rank == 0);
+    *out = r;
+    return 0;
+}
+extern "C" int qd_hostring_allreduce(void* ring, double* vals, int n, int op_max) {
+    return ring_allreduce((QdHostRing*)ring, vals, n, op_max, 60.0);
+}
+extern "C" int qd_hostring_close(void* ring) {
+    QdHostRing* r = (QdHostRing*)ring;
+    if (!r) return 0;
+    if (r->mapped && r->seg) munmap(r->seg, sizeof(QdRingSeg));
+    if (r->mapped && r->owner) shm_unlink(r->name.c_str());
+    delete r;
+    return 0;
+}
 
 struct QdLocalGroup {
     std::vector<qd_ctx*> peers;
     pthread_barrier_t bar;
     std::vector<double> stage_d;        // [world][64]
     std::vector<unsigned int> stage_u;  // [world][4096]
+    QdRingSeg ring;                     // the host ring of an in-process group lives in ordinary memory
 };
+
+// all-reduce of a few HOST doubles across the ranks of this handle's communicator; -1 when no host ring is attached
+int qd_host_allreduce(qd_ctx* c, double* v, int n, int op) {
+    if (c->geo.full) return 0;
+    QdHostRing* r = (QdHostRing*)c->hring;
+    if (!r) return -1;
+    c->host_allreduces++;
+    const int rc = ring_allreduce(r, v, n, op, 120.0);
+    if (rc == -2) return qd_fail(c, "host ring: a rank did not arrive within 120 s");
+    return rc ? qd_fail(c, "host ring: bad call") : 0;
+}
+bool qd_has_host_ring(const qd_ctx* c) { return c->hring != nullptr; }
 
 int qd_vm_get(qd_ctx* c, const void* slab) {
     if (c->geo.full) return INT_MAX / 2;
@@ -222,8 +315,29 @@ extern "C" int qd_comm_init_local(qd_handle* handles, int n) {
         if (!handles[k] || handles[k]->desc.rank != k || handles[k]->desc.world != n) { delete g; return -1; }
         handles[k]->lgroup = g;
     }
+    for (int q = 0; q < QD_RING_MAXRANKS; ++q) g->ring.seq[q].store(0ull);
+    if (!std::getenv("QD_NO_HOST_RING"))
+        for (int k = 0; k < n; ++k) {
+            QdHostRing* r = new QdHostRing();
+            r->seg = &g->ring; r->rank = k; r->world = n;
+            handles[k]->hring = r;
+        }
     return 0;
 }
+
+// one process per GPU: the ranks of a node meet in the POSIX shared-memory segment `name` (qingdai_amd.bands.init_rccl picks a
+// name unique to the launch; rank 0 creates it before it publishes the RCCL id, so it exists when the others open it)
+extern "C" int qd_comm_init_shm(qd_handle c, const char* name) {
+    if (!c || !name) return -1;
+    if (c->geo.full) return 0;
+    void* r = nullptr;
+    const int rc = qd_hostring_open(name, c->desc.rank, c->desc.world, &r);
+    if (rc) return qd_fail(c, "qd_comm_init_shm: shm_open / mmap failed");
+    if (c->hring) qd_hostring_close(c->hring);
+    c->hring = r;
+    return 0;
+}
+extern "C" int qd_comm_host_allreduce_count(qd_handle c, int* n) { if (!c || !n) return -1; *n = c->host_allreduces; return 0; }
 
 extern "C" int qd_comm_allreduce_max(qd_handle c, double* inout, int n) {
     if (!c || !inout || n < 1 || n > 8) return -1;

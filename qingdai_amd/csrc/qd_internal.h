@@ -201,6 +201,9 @@ struct qd_ctx {
     std::vector<struct QdUse> corefresh;   // slabs refreshed along with any halo exchange that happens anyway (set around loops)
     int exchanges = 0;             // statistics
     int allreduces = 0;
+    double eta_seq = 0.0;          // sequence number of the eta sum the host is waiting for (bands with a host ring)
+    void* hring = nullptr;         // host ring (shared-memory scalar all-reduce), see qd_band.hip
+    int host_allreduces = 0;
     // timing
     const char* lap_tag = "k_laplacian";       // timing-group names of the two del^4 kernels
     const char* hyp_tag = "k_hyper_apply";     // (the ocean switches them to ocean_* around its calls)
@@ -242,6 +245,9 @@ QdSegs qd_segments(qd_ctx* c, int margin);
 int qd_exchange(qd_ctx* c, const QdUse* slots, int n);
 int qd_allreduce_f64(qd_ctx* c, double* dptr, int n, int op);          // op 0 sum, 1 max (device scalars)
 int qd_allreduce_u32(qd_ctx* c, unsigned int* dptr, int n);            // sum
+int qd_host_allreduce(qd_ctx* c, double* host_vals, int n, int op);    // op 0 sum, 1 max; HOST scalars through the host ring
+bool qd_has_host_ring(const qd_ctx* c);
+extern "C" int qd_hostring_close(void* ring);
 #define QD_ROWS(c, margin, G, ...) do { QdSegs _sg = qd_segments((c), (margin)); for (int _k = 0; _k < _sg.n; ++_k) { const QdGeom& G = _sg.g[_k]; __VA_ARGS__; } } while (0)
 
 static inline dim3 qd_grid2d(const QdGeom& G, int fields = 1) {

@@ -12,6 +12,8 @@
 //                   k_outlier                                     ocean.py:409-444
 // After:            k_polar_fill (2 workgroups), clamp + SST write-back   ocean.py:519-533
 #include <cstdlib>
+#include <atomic>
+#include <chrono>
 #include "qd_internal.h"
 #include "qd_device.h"
 
@@ -240,7 +242,7 @@ k_continuity(QdGeom G, QdTabs T, double a, double dlat, double dlon, double msdt
 }
 
 __global__ void __launch_bounds__(QD_BLOCK)
-k_eta_mean(const double* __restrict__ partial, int n, double wsum, double* __restrict__ out) {
+k_eta_mean(const double* __restrict__ partial, int n, double wsum, double* __restrict__ out, double seq = 0.0) {
     __shared__ double sm[QD_BLOCK / 64];
     double acc = 0.0;
     for (int k = threadIdx.x; k < n; k += QD_BLOCK) acc += partial[k];
@@ -252,6 +254,9 @@ k_eta_mean(const double* __restrict__ partial, int n, double wsum, double* __res
         double r = sm[0];
         for (int k = 1; k < QD_BLOCK / 64; ++k) r += sm[k];
         *out = (wsum < 0.0) ? r : r / (wsum + 1e-15);      // wsum < 0: raw sum (bands all-reduce it first)
+        // seq != 0: `out` is pinned host memory and the host polls out[1] for this sequence number (system-scope release: the
+        // sum is visible before the flag)
+        if (seq != 0.0) __hip_atomic_store(&out[1], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -591,10 +596,17 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
                                c->dscal + QD_S_TMP0 + 2 * k);
         }
         qd_mark(c, {taux, tauy}, m);
+        if (qd_has_host_ring(c)) {
+            // the host waits for these six maxima anyway: reduce them across the ranks in the host ring, no RCCL launch
+            QD_HIP(c, hipMemcpyAsync(c->hpin, c->dscal + QD_S_TMP0, 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            QD_HIP(c, hipStreamSynchronize(c->stream));
+            if (qd_host_allreduce(c, c->hpin, 6, 1)) return -1;
+        } else {
         // ONE collective of fixed size on every band (polar bands have more segments than interior ones)
         if (qd_allreduce_f64(c, c->dscal + QD_S_TMP0, 6, 1)) return -1;
         QD_HIP(c, hipMemcpyAsync(c->hpin, c->dscal + QD_S_TMP0, 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         QD_HIP(c, hipStreamSynchronize(c->stream));
+        }
         for (int k = 0; k < 3; ++k) { maxVa = std::max(maxVa, c->hpin[2 * k]); maxUo = std::max(maxUo, c->hpin[2 * k + 1]); }
         }
         // ocean.py:293-303
@@ -620,7 +632,12 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
 
     // whole-globe handles on the fused path defer "eta -= mean; nan_to_num; clip" of a sub-step to the load of the next
     // momentum kernel (and to k_eta_finalize after the last one): no k_eta_mean launch, no eta pass in the SST kernel
-    const bool defer_eta = !band && do_diff && c->use_fused && p.ocean_k4_nsub == 1 && !do_shap && c->wsum_ocean > 0.0;
+    const bool can_defer = do_diff && c->use_fused && p.ocean_k4_nsub == 1 && !do_shap && c->wsum_ocean > 0.0;
+    // latitude bands with a host ring defer the same way; their mean is reduced on the HOST between the ranks (event wait on the
+    // continuity kernel while the SST kernel is already queued) and handed to the next momentum kernel in pinned host memory
+    const bool band_defer = band && can_defer && qd_has_host_ring(c);
+    const bool defer_eta = (!band && can_defer) || band_defer;
+    double* const mean_ptr = band_defer ? c->hpin + 42 : c->dscal + QD_S_ETA_MEAN;
     // latitude bands: whenever a sub-step has to exchange halos, every slab of the sub-step loop is refreshed in the same group
     struct CoRefresh { qd_ctx* c; ~CoRefresh() { c->corefresh.clear(); } } corefresh_guard{c};
     if (band) c->corefresh = {QD_IN(F[QD_F_UO], 0), QD_IN(F[QD_F_VO], 0), QD_IN(F[QD_F_ETA], 0), QD_IN(F[QD_F_SST], 0), QD_IN(taux, 0),
@@ -641,7 +658,7 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
             }
             O.a = p.a; O.g = p.g_ocean; O.dlat = c->dlat; O.dlon = c->dlon; O.sub_dt = sub_dt; O.rhoH = p.rho_w * H; O.r_bot = p.r_bot;
             O.inv_2dlon = 1.0 / (2.0 * c->dlon); O.inv_2dlat = 1.0 / (2.0 * c->dlat); O.inv_a = 1.0 / p.a; O.inv_rhoH = 1.0 / (p.rho_w * H);
-            O.eta_mean = (defer_eta && s > 0) ? c->dscal + QD_S_ETA_MEAN : nullptr;
+            O.eta_mean = (defer_eta && s > 0) ? mean_ptr : nullptr;
             O.eta_cap = p.eta_cap;
             if (qd_launch_ocn_hyper(c, O, m)) return -1;
             qd_mark(c, {O.uo_out, O.vo_out, O.eta_out}, m);
@@ -704,9 +721,15 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
                                        (double*)nullptr);
                     off += (size_t)S.g[k].nrows * qd_grid2d(S.g[k]).x;
                 }
+                if (band_defer) {
+                    // raw sum of the owned rows straight into pinned host memory; the host picks it up after the SST launch
+                    c->eta_seq += 1.0;
+                    hipLaunchKernelGGL(k_eta_mean, dim3(1), blk, 0, c->stream, c->red_partial, (int)off, -1.0, c->hpin + 40, c->eta_seq);
+                } else {
                 hipLaunchKernelGGL(k_eta_mean, dim3(1), blk, 0, c->stream, c->red_partial, (int)off, -1.0, c->dscal + QD_S_ETA_MEAN);
                 if (qd_allreduce_f64(c, c->dscal + QD_S_ETA_MEAN, 1, 0)) return -1;
                 hipLaunchKernelGGL(k_eta_mean_post, dim3(1), dim3(64), 0, c->stream, c->dscal + QD_S_ETA_MEAN, c->wsum_ocean);
+                }
             }
             qd_mark(c, {T1, F[QD_F_ETA]}, m);
             double*& T1s = c->scratch[0];
@@ -720,9 +743,29 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
                                                  F[QD_F_UO], F[QD_F_VO], u2, v2, F[QD_F_ETA], p.ocean_max_u, p.eta_cap,
                                                  p.ocean_outlier == 0 ? 1 : 0,
                                                  has_ocean ? c->dscal + QD_S_ETA_MEAN : (const double*)nullptr,
-                                                 c->red_partial, (int)(qd_grid2d(Gown).x * qd_grid2d(Gown).y), c->wsum_ocean,
-                                                 defer_eta ? c->dscal + QD_S_ETA_MEAN : (double*)nullptr));
+                                                 c->red_partial, band_defer ? 0 : (int)(qd_grid2d(Gown).x * qd_grid2d(Gown).y), c->wsum_ocean,
+                                                 band_defer ? c->dscal + QD_S_TMP1 : (defer_eta ? c->dscal + QD_S_ETA_MEAN : (double*)nullptr)));
             qd_mark(c, {T2, u2, v2, F[QD_F_ETA]}, m2);
+            if (band_defer) {
+                // the SST kernel is queued; meanwhile: wait for the continuity kernel's sum (the flag it writes into pinned host
+                // memory: no HIP call on the wait path), reduce it between the ranks, publish
+                {
+                    volatile double* flag = c->hpin + 41;
+                    const auto t0 = std::chrono::steady_clock::now();
+                    unsigned spins = 0;
+                    while (*flag != c->eta_seq) {
+                        if ((++spins & 0xFFFFu) == 0) {
+                            if (hipStreamQuery(c->stream) == hipSuccess && *flag != c->eta_seq) return qd_fail(c, "ocean sub-step: eta sum never arrived");
+                            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 60.0)
+                                return qd_fail(c, "ocean sub-step: timeout waiting for the eta sum");
+                        }
+                    }
+                    std::atomic_thread_fence(std::memory_order_acquire);
+                }
+                double sum = c->hpin[40];
+                if (qd_host_allreduce(c, &sum, 1, 0)) return -1;
+                c->hpin[42] = sum / (c->wsum_ocean + 1e-15);
+            }
             qd_swap(c, QD_F_SST, 1); qd_swap(c, QD_F_UO, 2); qd_swap(c, QD_F_VO, 3);
         } else {
         {
@@ -806,9 +849,10 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
         if (m < 0) return -1;
         QD_ROWS(c, m, G, hipLaunchKernelGGL(k_sst_clamp_inject, qd_grid2d(G), blk, 0, c->stream, G, F[QD_F_SST], p.ts_min, p.ts_max,
                                             inject_sst, c->land, c->icemask, use_ice_mask ? 1 : 0, F[QD_F_TS],
-                                            (defer_eta && n_sub > 0) ? F[QD_F_ETA] : (double*)nullptr, c->dscal + QD_S_ETA_MEAN, p.eta_cap));
+                                            (defer_eta && n_sub > 0) ? F[QD_F_ETA] : (double*)nullptr, mean_ptr, p.eta_cap));
         qd_mark(c, {F[QD_F_SST]}, m);
         if (inject_sst) qd_mark(c, {F[QD_F_TS]}, m);
+        if (defer_eta && n_sub > 0) qd_mark(c, {F[QD_F_ETA]}, m);     // rows beyond m still hold eta before "- mean, clip"
     }
     return 0;
 }

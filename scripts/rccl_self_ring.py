@@ -49,9 +49,11 @@ for transport in TRANSPORTS:
     dev.step_n(stars[12:], 300.0, with_ocean=True, with_physics=True, pass_albedo=True)
     dev.sync()
     el = time.perf_counter() - t0
-    ne, na = ctypes.c_int(0), ctypes.c_int(0)
+    ne, na, nh = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
     dev.lib.qd_comm_stats(dev.h, ctypes.byref(ne)); dev.lib.qd_comm_allreduce_count(dev.h, ctypes.byref(na))
+    dev.lib.qd_comm_host_allreduce_count(dev.h, ctypes.byref(nh))
     k = nsteps - 12
     print(f"{transport:5s}: band rows {r0}..{r0 + n} of {nlat} (1/{nb}), halo {HALO or required_halo(nlat)}: {el / k * 1e3:.3f} ms/step, "
-          f"{(ne.value - ne0.value) / k:.1f} halo exchanges + {(na.value - na0.value) / k:.1f} all-reduces per step, n_sub {dev.last_ocean_nsub()}")
+          f"{(ne.value - ne0.value) / k:.1f} halo exchanges + {(na.value - na0.value) / k:.1f} RCCL all-reduces per step "
+          f"(+ {nh.value / nsteps:.1f} through the host ring), n_sub {dev.last_ocean_nsub()}")
     dev.close()

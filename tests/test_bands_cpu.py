@@ -120,3 +120,44 @@ def test_ring_halo_exchange_two_ranks_gloo(tmp_path):
         assert ok_halo, f"rank {rank}: ring halo rows wrong"
         assert ok_h4, f"rank {rank}: del^4 on the band differs from the globe"
         assert ok_adv, f"rank {rank}: gather on the band differs from the globe"
+
+
+def _ring_worker(rank, world, name, iters, q):
+    import ctypes
+    sys.path.insert(0, ROOT)
+    from qingdai_amd import _lib
+    lib = _lib.load()
+    ring = ctypes.c_void_p()
+    assert lib.qd_hostring_open(name.encode(), rank, world, ctypes.byref(ring)) == 0
+    bad = 0
+    for it in range(iters):
+        # every rank can rebuild everybody's contribution: the expected reduction is computed independently, in rank order
+        contrib = [np.random.default_rng(1000 * it + r).normal(0, 10.0 ** (it % 7), 3) for r in range(world)]
+        v = (ctypes.c_double * 3)(*contrib[rank])
+        op = it % 2
+        assert lib.qd_hostring_allreduce(ring, v, 3, op) == 0
+        want = contrib[0].copy()
+        for r in range(1, world):
+            want = np.maximum(want, contrib[r]) if op else want + contrib[r]
+        bad += int(not np.array_equal(np.array(list(v)), want))
+    lib.qd_hostring_close(ring)
+    q.put((rank, bad))
+
+
+@pytest.mark.timeout(240)
+def test_host_ring_allreduce_across_processes():
+    """The shared-memory scalar all-reduce of the band transport (qd_hostring_*), 4 processes x 1500 calls, sums and maxima
+    alternating: every rank gets the rank-ordered reduction bit for bit, and nobody overtakes (two buffers by sequence parity)."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    world, iters = 4, 1500
+    name = f"/qd_test_ring_{os.getpid()}"
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_ring_worker, args=(r, world, name, iters, q)) for r in range(world)]
+    for p_ in ps:
+        p_.start()
+    res = sorted(q.get(timeout=200) for _ in ps)
+    for p_ in ps:
+        p_.join(30)
+    assert res == [(r, 0) for r in range(world)]
+    assert not os.path.exists("/dev/shm" + name)                    # rank 0 unlinked the segment
