@@ -162,8 +162,10 @@ def init_rccl(dev: Device, rank, world, tag="id", timeout_s=180.0):
         ctypes.memmove(buf, data, min(128, len(data)))
     if lib.qd_comm_init(dev.h, buf, 128) != 0:
         raise _lib.QdError("qd_comm_init failed: " + (lib.qd_last_error(dev.h) or b"?").decode())
-    # the ranks of one node also meet in a shared-memory ring for the few host-visible scalars of a step (eta sums, CFL maxima);
-    # QD_NO_HOST_RING=1 keeps those on RCCL
-    if not os.environ.get("QD_NO_HOST_RING"):
+    # QD_HOST_RING=1: the ranks of one node also meet in a shared-memory ring for the few host-visible scalars of a step (eta
+    # sums, CFL maxima) instead of one RCCL all-reduce each.  Opt-in: on the one-rank self-ring a host round trip per ocean
+    # sub-step (~33 us) is slower than a queued one-rank ncclAllReduce (~23 us); it can only win where a real N-rank all-reduce
+    # costs more than that, which this pool's 1-GPU boxes cannot tell.
+    if os.environ.get("QD_HOST_RING") == "1":
         if lib.qd_comm_init_shm(dev.h, f"/qd_ring_{key}".encode()) != 0:
             raise _lib.QdError("qd_comm_init_shm failed: " + (lib.qd_last_error(dev.h) or b"?").decode())
