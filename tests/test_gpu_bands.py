@@ -222,27 +222,40 @@ def test_rccl_transport_equals_in_process_transport(gpu, monkeypatch):
     static = {"LAND_MASK": mask, "FRICTION": fric, "BASE_ALBEDO": alb}
     names = ["U", "V", "H", "TS", "Q", "CLOUD", "UO", "VO", "ETA", "SST", "ALBEDO", "PRECIP"]
     out, counts = {}, {}
-    for transport in ("local", "rccl"):
-        dev = Device(qa.SphericalGrid(nlat, nlon), p, row0=25, n_rows=41, halo=12, rank=0, world=1)
-        if transport == "local":
-            arr = (ctypes.c_void_p * 1)(dev.h)
-            assert dev.lib.qd_comm_init_local(arr, 1) == 0
-        else:
-            init_rccl(dev, 0, 1, tag="self")
-        for k, v in {**static, **st}.items():
-            dev.upload_now(k, v)
-        dev.step_n(stars, 300.0, with_ocean=True, with_physics=True, pass_albedo=True)
-        # what bench.py does around its timed region on every rank: barrier, max over ranks
-        assert dev.lib.qd_comm_barrier(dev.h) == 0
-        v = (ctypes.c_double * 2)(1.5, -2.0)
-        assert dev.lib.qd_comm_allreduce_max(dev.h, v, 2) == 0 and list(v) == [1.5, -2.0]
-        out[transport] = {k: dev.get(k)[25:66].copy() for k in names}
-        ne, na = ctypes.c_int(0), ctypes.c_int(0)
-        dev.lib.qd_comm_stats(dev.h, ctypes.byref(ne)); dev.lib.qd_comm_allreduce_count(dev.h, ctypes.byref(na))
-        counts[transport] = (ne.value, na.value)
-        dev.close()
-    print("halo exchanges, all-reduces:", counts)
-    assert counts["local"] == counts["rccl"] and counts["rccl"][0] > 10 and counts["rccl"][1] > 20
-    for k in names:
-        assert np.array_equal(out["local"][k], out["rccl"][k], equal_nan=True), k
-        assert np.isfinite(out["rccl"][k]).all(), k
+    for ring in (False, True):                                   # scalars on RCCL / through the shared-memory host ring
+        for transport in ("local", "rccl"):
+            monkeypatch.delenv("QD_NO_HOST_RING", raising=False); monkeypatch.delenv("QD_HOST_RING", raising=False)
+            if ring:
+                monkeypatch.setenv("QD_HOST_RING", "1")
+            else:
+                monkeypatch.setenv("QD_NO_HOST_RING", "1")
+            dev = Device(qa.SphericalGrid(nlat, nlon), p, row0=25, n_rows=41, halo=12, rank=0, world=1)
+            if transport == "local":
+                arr = (ctypes.c_void_p * 1)(dev.h)
+                assert dev.lib.qd_comm_init_local(arr, 1) == 0
+            else:
+                init_rccl(dev, 0, 1, tag=f"self{int(ring)}")
+            for k, v in {**static, **st}.items():
+                dev.upload_now(k, v)
+            dev.step_n(stars, 300.0, with_ocean=True, with_physics=True, pass_albedo=True)
+            # what bench.py does around its timed region on every rank: barrier, max over ranks
+            assert dev.lib.qd_comm_barrier(dev.h) == 0
+            v = (ctypes.c_double * 2)(1.5, -2.0)
+            assert dev.lib.qd_comm_allreduce_max(dev.h, v, 2) == 0 and list(v) == [1.5, -2.0]
+            key = (transport, ring)
+            out[key] = {k: dev.get(k)[25:66].copy() for k in names}
+            ne, na, nh = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+            dev.lib.qd_comm_stats(dev.h, ctypes.byref(ne)); dev.lib.qd_comm_allreduce_count(dev.h, ctypes.byref(na))
+            dev.lib.qd_comm_host_allreduce_count(dev.h, ctypes.byref(nh))
+            counts[key] = (ne.value, na.value, nh.value)
+            dev.close()
+    print("halo exchanges, RCCL all-reduces, host-ring all-reduces:", counts)
+    for ring in (False, True):
+        assert counts[("local", ring)] == counts[("rccl", ring)], ring
+        for k in names:
+            assert np.array_equal(out[("local", ring)][k], out[("rccl", ring)][k], equal_nan=True), (k, ring)
+            assert np.isfinite(out[("rccl", ring)][k]).all(), k
+    assert counts[("rccl", False)][0] > 10 and counts[("rccl", False)][1] > 20 and counts[("rccl", False)][2] == 0
+    assert counts[("rccl", True)][2] >= 5 and counts[("rccl", True)][1] < counts[("rccl", False)][1]
+    for k in names:                                              # the ring changes where the eta mean is reduced, not its value
+        assert relerr(out[("rccl", True)][k], out[("rccl", False)][k]) < 1e-12, k
