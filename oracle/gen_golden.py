@@ -471,7 +471,7 @@ def case_spectral_bands(nlat, nlon):
     save(f"spectral_{nlat}x{nlon}", dict(kind="spectral", nlat=nlat, nlon=nlon, times=[0.0, 4.1e6]), **out)
 
 
-def case_ecology(nlat, nlon, seed):
+def case_ecology(nlat, nlon, seed, variant="default"):
     """The per-step ecology of BASELINE config 5 run as the REFERENCE's own classes: EcologyAdapter.step_subdaily over
     PopulationManager (pygcm/ecology/adapter.py:140-186, population.py:252-294,831-915), get_surface_albedo_bands
     (population.py:875-893) with the driver's daily reduction (run_simulation.py:1843-1844), the driver's base-albedo blend
@@ -490,6 +490,17 @@ def case_ecology(nlat, nlon, seed):
     env = {"QD_ECO_DIAG": "0", "QD_ECO_NS": "4", "QD_ECO_COHORT_K": "2", "QD_ECO_LIGHT_UPDATE_EVERY_HOURS": "0.5",
            "QD_ECO_SUBSTEP_EVERY_NPHYS": "2", "QD_ECO_LAI_K": "0.6", "QD_ECO_SOIL_REFLECT": "0.18",
            "QD_ECO_INDIV_SAMPLE_FRAC": "0.3", "QD_ECO_INDIV_PER_CELL": "5", "QD_ECO_INDIV_SUBSTEPS_PER_DAY": "10"}
+    NB, LAM, MODE, K_CAN, SOIL, EVERY_N = 16, (380.0, 780.0), "simple", 0.6, 0.18, 2
+    if variant == "rayleigh":
+        # Rayleigh band weighting, 8 bands over 400-700 nm, per-species genes from the environment, default canopy constants,
+        # alpha on every step
+        env = {"QD_ECO_DIAG": "0", "QD_ECO_NS": "3", "QD_ECO_COHORT_K": "1", "QD_ECO_LIGHT_UPDATE_EVERY_HOURS": "0.5",
+               "QD_ECO_TOA_TO_SURF_MODE": "rayleigh", "QD_ECO_SPECTRAL_BANDS": "8", "QD_ECO_SPECTRAL_RANGE_NM": "400,700",
+               "QD_ECO_SPECIES_0_PEAKS": "500:30:0.9", "QD_ECO_SPECIES_1_PEAKS": "440:25:0.5, 660:20:0.7, 550:0:0.4",
+               "QD_ECO_SPECIES_1_DROUGHT_TOL": "0.6", "QD_ECO_SPECIES_WEIGHTS": "0.5,0.3,0.2",
+               "QD_ECO_INDIV_SAMPLE_FRAC": "0.3", "QD_ECO_INDIV_PER_CELL": "5", "QD_ECO_INDIV_SUBSTEPS_PER_DAY": "10"}
+        NB, LAM, MODE, K_CAN, SOIL, EVERY_N = 8, (400.0, 700.0), "rayleigh", 0.5, 0.20, 1
+    RAY = dict(mode="rayleigh") if MODE == "rayleigh" else None
     dt, nsteps = 300.0, 10
     out, meta_steps = {}, []
     with ref_env({}):
@@ -569,16 +580,17 @@ def case_ecology(nlat, nlon, seed):
         os.environ["QD_ECO_USE_LAI"] = "0"
         eco1 = quiet(EcologyAdapter, g, mask)
         m1 = [eco1.step_subdaily(out["insA_0"] + out["insB_0"], 0.3, dt) for _ in range(4)]
-    assert eco1.pop is None and [a is not None for a in m1] == [False, True, False, True]
-    out["ref_alpha_m1"] = m1[1]
-    o1 = oeco.EcoAdapter(None, leaf_s, soil_ref=0.18, substep_every_nphys=2)
+    pat = [(k + 1) % EVERY_N == 0 for k in range(4)]
+    assert eco1.pop is None and [a is not None for a in m1] == pat
+    out["ref_alpha_m1"] = m1[3]
+    o1 = oeco.EcoAdapter(None, leaf_s, soil_ref=SOIL, substep_every_nphys=EVERY_N)
     got1 = [o1.step_subdaily(None, dt, land_mask=mask) for _ in range(4)]
-    assert [a is not None for a in got1] == [False, True, False, True] and np.array_equal(got1[3], m1[3], equal_nan=True)
+    assert [a is not None for a in got1] == pat and np.array_equal(got1[3], m1[3], equal_nan=True)
     # oracle on the same inputs
-    ob = osp.make_bands(16, 380.0, 780.0)
-    opop = oeco.CanopyPopulation(mask, L0, k_canopy=0.6, light_update_every_hours=0.5, recompute_lai_delta=0.05)
-    oad = oeco.EcoAdapter(opop, oeco.leaf_scalar(ob), soil_ref=0.18, substep_every_nphys=2)
-    print(f"    leaf scalar           oracle-vs-ref {abs(oeco.leaf_scalar(ob) - leaf_s):.2e}")
+    ob = osp.make_bands(NB, *LAM)
+    opop = oeco.CanopyPopulation(mask, L0, k_canopy=K_CAN, light_update_every_hours=0.5, recompute_lai_delta=0.05)
+    oad = oeco.EcoAdapter(opop, oeco.leaf_scalar(ob, MODE), soil_ref=SOIL, substep_every_nphys=EVERY_N)
+    print(f"    leaf scalar           oracle-vs-ref {abs(oeco.leaf_scalar(ob, MODE) - leaf_s):.2e}")
     worst = 0.0
     for i in range(nsteps):
         if i == 2:
@@ -593,22 +605,24 @@ def case_ecology(nlat, nlon, seed):
     print(f"    alpha maps            oracle-vs-ref maxrel {worst:.2e}   recomputes {opop.n_recompute}")
     print(f"    E_day / f cache       oracle-vs-ref maxrel {maxrel(opop.E_day, out['ref_E_day']):.2e} / {maxrel(opop.f_cached, out['ref_f_cached']):.2e}")
     R_eff = oeco.effective_leaf_reflectance(out["species_w"], out["R_species"])
-    Ao = opop.surface_albedo_bands(R_eff, 0.18)
+    Ao = opop.surface_albedo_bands(R_eff, SOIL)
     print(f"    A_bands / banded      oracle-vs-ref maxrel {maxrel(np.nan_to_num(Ao), np.nan_to_num(A)):.2e} / "
-          f"{maxrel(oeco.banded_alpha(Ao, oeco.band_weights(ob)), out['ref_alpha_banded']):.2e}")
+          f"{maxrel(oeco.banded_alpha(Ao, oeco.band_weights(ob, MODE)), out['ref_alpha_banded']):.2e}")
     oi = oeco.IndividualSubstep(pool.sample_j, pool.sample_i, pool.indiv_cell_index, pool.indiv_Ab, pool.indiv_tol, 10)
     of = qo.Forcing(qo.Grid(nlat, nlon))
     ofired = []
     for i in range(30):
         a_, b_ = of.insolation_components(i * dti)
-        if oi.try_substep(a_, b_, ob, soil, dti, day):
+        if oi.try_substep(a_, b_, ob, soil, dti, day, rayleigh=RAY):
             ofired.append(i)
     assert ofired == fired, (ofired, fired)
     print(f"    individuals E / stress oracle-vs-ref maxrel {maxrel(oi.E_day, pool.indiv_E_day):.2e} / "
           f"{maxrel(oi.stress_days, pool.indiv_water_stress_days):.2e}   fired {len(fired)}")
-    save(f"eco_{nlat}x{nlon}", dict(kind="ecology", nlat=nlat, nlon=nlon, seed=seed, dt=dt, nsteps=nsteps, steps=meta_steps,
-                                    k_canopy=0.6, soil_ref=0.18, every_h=0.5, delta=0.05, substep_every=2, leaf_scalar=leaf_s,
-                                    w_lai=0.8, alpha_snow=0.70, ind_dt=dti, ind_day=day, ind_fired=fired, ind_k=10),
+    out["ind_species_tol"] = np.asarray([float(getattr(gg, "drought_tolerance", 0.5)) for gg in eco.genes_list])
+    save(f"eco_{nlat}x{nlon}" + ("" if variant == "default" else "_" + variant),
+         dict(kind="ecology", nlat=nlat, nlon=nlon, seed=seed, dt=dt, nsteps=nsteps, steps=meta_steps, k_canopy=K_CAN, soil_ref=SOIL,
+              every_h=0.5, delta=0.05, substep_every=EVERY_N, leaf_scalar=leaf_s, w_lai=0.8, alpha_snow=0.70, ind_dt=dti, ind_day=day,
+              ind_fired=fired, ind_k=10, nb=NB, lam=list(LAM), mode=MODE, env={k: v for k, v in env.items() if k != "QD_ECO_DIAG"}),
          L0=L0, L1=L1, L2=L2, **out)
 
 
@@ -778,6 +792,7 @@ def main():
     if want("eco"):
         print("[ecology canopy + individuals 19x36]")
         case_ecology(19, 36, 81)
+        case_ecology(19, 36, 82, variant="rayleigh")
     if want("phyto"):
         for (a, b, s) in ((19, 36, 61), (37, 72, 62)):
             print(f"[phyto transport {a}x{b}]")

@@ -22,7 +22,8 @@ def _setenv(monkeypatch, extra=None):
     for k in list(os.environ):
         if k.startswith("QD_ECO_") or k.startswith("QD_PHYTO_"):
             monkeypatch.delenv(k)
-    for k, v in {**ECO_ENV, **(extra or {})}.items():
+    full = extra is not None and "QD_ECO_NS" in extra                # a fixture's complete environment replaces the default one
+    for k, v in (extra if full else {**ECO_ENV, **(extra or {})}).items():
         monkeypatch.setenv(k, v)
 
 
@@ -35,16 +36,21 @@ def _device(nlat, nlon, land_mask):
     return dev
 
 
-def test_canopy_alpha_sequence_vs_reference(gpu, monkeypatch):
+ECO_CASES = ["eco_19x36", "eco_19x36_rayleigh"]       # second fixture: Rayleigh band weights, 8 bands, per-species genes from the env
+
+
+@pytest.mark.parametrize("case", ECO_CASES)
+def test_canopy_alpha_sequence_vs_reference(gpu, monkeypatch, case):
     """EcologyAdapter.step_subdaily over PopulationManager (adapter.py:140-186, population.py:252-294,895-915): ten steps with
     the LAI stack replaced twice, so that the first-call, LAI-change and clock triggers of the canopy cache all fire; alpha on
     every second step (QD_ECO_SUBSTEP_EVERY_NPHYS=2)."""
     from qingdai_amd.ecology import EcologyAdapter
-    _setenv(monkeypatch)
-    meta, d = load_golden("eco_19x36")
+    meta, d = load_golden(case)
+    _setenv(monkeypatch, meta["env"])
     dev = _device(meta["nlat"], meta["nlon"], d["land_mask"])
     eco = EcologyAdapter(dev.grid, d["land_mask"], dev=dev, albedo_couple=True)
     assert eco.alpha_leaf_scalar == meta["leaf_scalar"] and eco.pop.LAI_layers_SK.shape == d["L0"].shape
+    assert eco.bands.nbands == meta["nb"]
     eco.pop.push_layers(d["L0"], init=True)
     assert np.array_equal(eco.pop.total_LAI(), np.sum(d["L0"], axis=(0, 1)))          # plane-by-plane sum is numpy's order
     for i, st in enumerate(meta["steps"]):
@@ -91,13 +97,14 @@ def test_adapter_without_population_vs_reference(gpu, monkeypatch):
     dev.close()
 
 
-def test_individual_pool_vs_reference(gpu, monkeypatch):
+@pytest.mark.parametrize("case", ECO_CASES)
+def test_individual_pool_vs_reference(gpu, monkeypatch, case):
     """IndividualPool (individuals.py:37-191): the mirror draws the reference's pool (same cells, species, jitter), and 30 long
     physics steps fire the 12 sub-steps the reference fired, with its energies and stress days."""
     import qd_oracle as qo
     from qingdai_amd.ecology import EcologyAdapter, IndividualPool
-    _setenv(monkeypatch)
-    meta, d = load_golden("eco_19x36")
+    meta, d = load_golden(case)
+    _setenv(monkeypatch, meta["env"])
     nlat, nlon = meta["nlat"], meta["nlon"]
     dev = _device(nlat, nlon, d["land_mask"])
     eco = EcologyAdapter(dev.grid, d["land_mask"], dev=dev, albedo_couple=True)

@@ -146,19 +146,22 @@ def test_spectral_band_insolation_matches_reference():
     assert np.array_equal(specA, d["ref_specA16"]) and np.array_equal(specB, d["ref_specB16"]) and np.all(tray == 1.0)
 
 
-def test_ecology_substep_matches_reference(monkeypatch):
+@pytest.mark.parametrize("case", ["eco_19x36", "eco_19x36_rayleigh"])
+def test_ecology_substep_matches_reference(monkeypatch, case):
     """The per-step ecology (adapter.step_subdaily over PopulationManager, banded alpha, the driver's base-albedo blend,
     IndividualPool.try_substep): oracle against what the reference's own classes produced, bit for bit -- alpha maps on the
     returned steps, the recompute history (first call / LAI-change ratio / clock), E_day, canopy cache, individuals."""
     from qd_oracle import ecology as oeco, spectral as osp
-    meta, d = load_golden("eco_19x36")
+    meta, d = load_golden(case)          # the second fixture: Rayleigh band weights, 8 bands, per-species genes from the env
     nlat, nlon = meta["nlat"], meta["nlon"]
     mask = d["land_mask"].astype(int)
-    ob = osp.make_bands(16, 380.0, 780.0)
-    assert oeco.leaf_scalar(ob) == meta["leaf_scalar"]
+    mode = meta["mode"]
+    ray = dict(mode="rayleigh") if mode == "rayleigh" else None
+    ob = osp.make_bands(meta["nb"], *meta["lam"])
+    assert oeco.leaf_scalar(ob, mode) == meta["leaf_scalar"]
     pop = oeco.CanopyPopulation(mask, d["L0"], k_canopy=meta["k_canopy"], light_update_every_hours=meta["every_h"],
                                 recompute_lai_delta=meta["delta"])
-    ad = oeco.EcoAdapter(pop, oeco.leaf_scalar(ob), soil_ref=meta["soil_ref"], substep_every_nphys=meta["substep_every"])
+    ad = oeco.EcoAdapter(pop, oeco.leaf_scalar(ob, mode), soil_ref=meta["soil_ref"], substep_every_nphys=meta["substep_every"])
     last = None
     for i, st in enumerate(meta["steps"]):
         if i == 2:
@@ -176,8 +179,8 @@ def test_ecology_substep_matches_reference(monkeypatch):
     R_eff = oeco.effective_leaf_reflectance(d["species_w"], d["R_species"])
     A = pop.surface_albedo_bands(R_eff, meta["soil_ref"])
     assert np.array_equal(A, d["ref_A_bands"], equal_nan=True)
-    assert np.array_equal(oeco.band_weights(ob), d["ref_w_b"])
-    assert np.array_equal(oeco.banded_alpha(A, oeco.band_weights(ob)), d["ref_alpha_banded"])
+    assert np.array_equal(oeco.band_weights(ob, mode), d["ref_w_b"])
+    assert np.array_equal(oeco.banded_alpha(A, oeco.band_weights(ob, mode)), d["ref_alpha_banded"])
     # the driver's blend around the reference's calculate_dynamic_albedo
     land = (mask == 1)
     base_in = oeco.blend_base_albedo(d["base_albedo"].copy(), land, d["glacier"].astype(bool), last, meta["w_lai"])
@@ -193,30 +196,33 @@ def test_ecology_substep_matches_reference(monkeypatch):
         a_, b_ = of.insolation_components(i * meta["ind_dt"])
         if i in meta["ind_fired"]:
             assert np.array_equal(a_, d[f"ind_insA_{i}"]) and np.array_equal(b_, d[f"ind_insB_{i}"])
-        if ind.try_substep(a_, b_, ob, d["ind_soil"], meta["ind_dt"], meta["ind_day"]):
+        if ind.try_substep(a_, b_, ob, d["ind_soil"], meta["ind_dt"], meta["ind_day"], rayleigh=ray):
             fired.append(i)
     assert fired == meta["ind_fired"]
     assert np.array_equal(ind.E_day, d["ref_ind_E_day"]) and np.array_equal(ind.stress_days, d["ref_ind_stress"])
     assert ind.E_day.max() > 0 and ind.stress_days.max() > 0
-    # the product's host-side tables (qingdai_amd.spectral) equal the reference's
-    from qingdai_amd import spectral as psp
-    pb = psp.make_bands(16, 380.0, 780.0)
-    monkeypatch.delenv("QD_ECO_TOA_TO_SURF_MODE", raising=False)
-    assert np.array_equal(psp.band_weights_from_mode(pb), d["ref_w_b"])
-    assert float(np.sum(psp.default_leaf_reflectance(pb) * psp.band_weights_from_mode(pb))) == meta["leaf_scalar"]
-    R0 = np.clip(1.0 - psp.absorbance_from_peaks(pb, [(450.0, 40.0, 0.6), (680.0, 30.0, 0.8)]), 0.0, 1.0)
-    assert np.array_equal(np.tile(R0, (d["R_species"].shape[0], 1)), d["R_species"])
-    # the adapter without a population (QD_ECO_USE_LAI=0): scalar leaf alpha on land, every 2nd call
-    o1 = oeco.EcoAdapter(None, meta["leaf_scalar"], soil_ref=meta["soil_ref"], substep_every_nphys=2)
-    got1 = [o1.step_subdaily(None, meta["dt"], land_mask=mask) for _ in range(2)]
-    assert got1[0] is None and np.array_equal(got1[1], d["ref_alpha_m1"], equal_nan=True)
-    # the product's host-side pool sampling draws the reference's pool (same generator calls in the same order)
-    from qingdai_amd import ecology as peco
-    for k in [k for k in os.environ if k.startswith("QD_ECO_SPECIES_")]:
+    # the product's host-side tables (qingdai_amd.spectral / ecology) under the fixture's environment equal the reference's
+    from qingdai_amd import ecology as peco, spectral as psp
+    for k in [k for k in os.environ if k.startswith("QD_ECO_")]:
         monkeypatch.delenv(k)
+    for k, v in meta["env"].items():
+        monkeypatch.setenv(k, v)
+    pb = psp.make_bands()
+    assert pb.nbands == meta["nb"] and np.array_equal(psp.band_weights_from_mode(pb), d["ref_w_b"])
+    assert float(np.sum(psp.default_leaf_reflectance(pb) * psp.band_weights_from_mode(pb))) == meta["leaf_scalar"]
     R, tol = peco.species_tables(pb, d["R_species"].shape[0])
-    assert np.array_equal(R, d["R_species"])
-    arr = peco.sample_pool(mask, d["species_w"], R, tol, 16, 0.3, 5)
+    assert np.array_equal(R, d["R_species"]) and np.array_equal(tol, d["ind_species_tol"])
+    if case == "eco_19x36":
+        R0 = np.clip(1.0 - psp.absorbance_from_peaks(pb, [(450.0, 40.0, 0.6), (680.0, 30.0, 0.8)]), 0.0, 1.0)
+        assert np.array_equal(np.tile(R0, (R.shape[0], 1)), R)
+    else:
+        assert not np.array_equal(R[0], R[2]) and tol[1] == 0.6        # the per-species overrides really took effect
+    # the adapter without a population (QD_ECO_USE_LAI=0): scalar leaf alpha on land on the sub-step boundaries
+    o1 = oeco.EcoAdapter(None, meta["leaf_scalar"], soil_ref=meta["soil_ref"], substep_every_nphys=meta["substep_every"])
+    got1 = [o1.step_subdaily(None, meta["dt"], land_mask=mask) for _ in range(4)]
+    assert np.array_equal(got1[3], d["ref_alpha_m1"], equal_nan=True) and (got1[0] is None) == (meta["substep_every"] == 2)
+    # the product's host-side pool sampling draws the reference's pool (same generator calls in the same order)
+    arr = peco.sample_pool(mask, d["species_w"], R, tol, meta["nb"], 0.3, 5)
     for key, ref in (("sample_j", "ind_sample_j"), ("sample_i", "ind_sample_i"), ("indiv_cell_index", "ind_cell"),
                      ("indiv_Ab", "ind_Ab"), ("indiv_tol", "ind_tol")):
         assert np.array_equal(arr[key], d[ref]), key
