@@ -414,6 +414,19 @@ __device__ __forceinline__ void qd_ocn_exact(const QdGeom& G, const QdTabs& T, c
 //   * POLE = false: interior tiles, straight-line code.  POLE = true: tiles holding a pole row, rows
 //     beyond a pole or rows off the slab: same code plus per-row (wave-uniform) patches -- literal
 //     one-sided np.gradient expressions for rows 0,1,n-2,n-1, zero for rows outside the domain.
+// Per-field launch arguments (output pointer, k4 row / scalar, skip flag) are read from the KERNARG segment at the point of use,
+// through a laundered pointer, instead of through the by-value parameter: as parameters all ~75 dwords of the argument struct are
+// live in SGPRs from the first instruction on, most of them get spilled into VGPR lanes, and every later use costs a v_readlane
+// on the (binding) VALU pipe.  A scalar load of a few dwords right before a field's del^4 costs nothing there.
+struct QdKargDyn { QdGeom G; QdTabs T; QdDynArgs P; };
+struct QdKargOcn { QdGeom G; QdTabs T; QdOcnArgs P; };
+#define QD_CONST __attribute__((address_space(4)))
+template <typename A>
+__device__ __forceinline__ const A QD_CONST* qd_kargs(unsigned off) {
+    const char QD_CONST* p = (const char QD_CONST*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));                             // opaque: the loads below cannot be hoisted to the kernel entry
+    return (const A QD_CONST*)(p + off);
+}
 typedef const double __attribute__((address_space(4)))* qd_cptr;
 __device__ __forceinline__ double qd_sload(const double* p, int idx) { return ((qd_cptr)(unsigned long long)p)[idx]; }
 __device__ __forceinline__ bool qd_nonfinite(double x) { return __builtin_amdgcn_class(x, 0x207); }   // sNaN|qNaN|-inf|+inf
@@ -639,17 +652,27 @@ __device__ __forceinline__ bool qd_dyn_fast(const QdGeom& G, const QdTabs& T, co
     }
     const QdPoleC C{n, T.lapPoleA[0]};
 #define QD_FIELD(ARR, OUT, FI)                                                                              \
-    if (P.skip[FI]) qd_store_fast<TR>(ARR, OUT, G, t, jraw, lane, rho0);                                    \
-    else qd_del4_fast<TR, POLE>(ARR, Bp, Dp, OUT, G, t, jraw, lane, rho0, LT, P.k4row[FI], P.k4s[FI], P.dt, C, bad);
-    QD_FIELD(ru, P.uo, 0)
+    {                                                                                                       \
+        const QdDynArgs QD_CONST* Pk = qd_kargs<QdDynArgs>((unsigned)offsetof(QdKargDyn, P));               \
+        double* const outp = Pk->OUT;                                                                       \
+        if (Pk->skip[FI]) qd_store_fast<TR>(ARR, outp, G, t, jraw, lane, rho0);                             \
+        else qd_del4_fast<TR, POLE>(ARR, Bp, Dp, outp, G, t, jraw, lane, rho0, LT, Pk->k4row[FI], Pk->k4s[FI], Pk->dt, C, bad); \
+    }
+    QD_FIELD(ru, uo, 0)
+    {
+        const double* const qp = qd_kargs<QdDynArgs>((unsigned)offsetof(QdKargDyn, P))->q;
 #pragma unroll
-    for (int k = 0; k < K; ++k) rq[k] = P.q[o0 + (unsigned)k * (unsigned)mlon];
-    QD_FIELD(rv, P.vo, 1)
+        for (int k = 0; k < K; ++k) rq[k] = qp[o0 + (unsigned)k * (unsigned)mlon];
+    }
+    QD_FIELD(rv, vo, 1)
+    {
+        const double* const cp = qd_kargs<QdDynArgs>((unsigned)offsetof(QdKargDyn, P))->cloud;
 #pragma unroll
-    for (int k = 0; k < K; ++k) rc[k] = P.cloud[o0 + (unsigned)k * (unsigned)mlon];
-    QD_FIELD(ah, P.ho, 2)
-    QD_FIELD(rq, P.qo, 3)
-    QD_FIELD(rc, P.co, 4)
+        for (int k = 0; k < K; ++k) rc[k] = cp[o0 + (unsigned)k * (unsigned)mlon];
+    }
+    QD_FIELD(ah, ho, 2)
+    QD_FIELD(rq, qo, 3)
+    QD_FIELD(rc, co, 4)
 #undef QD_FIELD
     return bad;
 }
@@ -721,11 +744,15 @@ __device__ __forceinline__ bool qd_ocn_fast(const QdGeom& G, const QdTabs& T, co
     }
     const QdPoleC C{n, T.lapPoleA[1]};
 #define QD_FIELD(ARR, OUT, FI)                                                                              \
-    if (P.skip[FI]) qd_store_fast<TR>(ARR, OUT, G, t, jraw, lane, rho0);                                    \
-    else qd_del4_fast<TR, POLE>(ARR, Bp, Dp, OUT, G, t, jraw, lane, rho0, LT, P.k4row[FI], P.k4s[FI], P.sub_dt, C, bad);
-    QD_FIELD(ru, P.uo_out, 0)
-    QD_FIELD(rv, P.vo_out, 1)
-    QD_FIELD(ae, P.eta_out, 2)
+    {                                                                                                       \
+        const QdOcnArgs QD_CONST* Pk = qd_kargs<QdOcnArgs>((unsigned)offsetof(QdKargOcn, P));               \
+        double* const outp = Pk->OUT;                                                                       \
+        if (Pk->skip[FI]) qd_store_fast<TR>(ARR, outp, G, t, jraw, lane, rho0);                             \
+        else qd_del4_fast<TR, POLE>(ARR, Bp, Dp, outp, G, t, jraw, lane, rho0, LT, Pk->k4row[FI], Pk->k4s[FI], Pk->sub_dt, C, bad); \
+    }
+    QD_FIELD(ru, uo_out, 0)
+    QD_FIELD(rv, vo_out, 1)
+    QD_FIELD(ae, eta_out, 2)
 #undef QD_FIELD
     return bad;
 }
