@@ -537,6 +537,24 @@ k_sst_clamp_inject(QdGeom G, double* __restrict__ sst, double tmin, double tmax,
 // device scalars after a reduction: raw sums/maxima are all-reduced across latitude bands first
 __global__ void k_eta_mean_post(double* s, double wsum) { if (threadIdx.x == 0 && blockIdx.x == 0) *s = *s / (wsum + 1e-15); }
 
+// a later kernel of the stream publishes "everything before me has reached host memory" (system-scope release at its end)
+__global__ void k_host_flag(double* flag, double seq) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// spin on a flag in pinned host memory: no HIP call on the wait path, the stream keeps executing what is queued behind
+static int qd_wait_host_flag(qd_ctx* c, volatile double* flag, double seq, const char* what) {
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (*flag != seq) {
+        if ((++spins & 0xFFFFu) == 0) {
+            if (hipStreamQuery(c->stream) == hipSuccess && *flag != seq) return qd_fail(c, what);
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 60.0) return qd_fail(c, what);
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return 0;
+}
+
 int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask, int inject_sst) {
     const qd_params& p = c->p;
     const QdGeom& G0 = c->geo;
@@ -549,7 +567,9 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
     const QdGeom Gown = qd_segments(c, 0).g[0];        // owned rows: reductions never count halo rows
     const dim3 rows(1, Gown.nrows);
 
-    if (compute_qnet) {
+    // whole-globe handles launch Q_net AFTER the stress kernel (the two are independent): it runs while the host waits for the
+    // CFL maxima, and the first sub-step is queued before it has drained
+    auto launch_qnet = [&]() -> int {
         QdScope sc(c, "ocean_qnet");
         QdColP P = qd_make_colp_driver(c, dt);
         // cloud optical field: cloud_eff_last when time_step produced one, else cloud_cover
@@ -563,7 +583,9 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
                                             F[QD_F_QNET], c->icemask));
         qd_mark(c, {F[QD_F_QNET], c->icemask}, m);
         use_ice_mask = 1;
-    }
+        return 0;
+    };
+    if (compute_qnet && band && launch_qnet()) return -1;
     double*& taux = c->scratch[14];
     double*& tauy = c->scratch[15];
     int n_sub;
@@ -582,7 +604,10 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
             hipLaunchKernelGGL(k_stress_max, dim3(1, G.nrows), blk, 0, c->stream, G, F[QD_F_U], F[QD_F_V], F[QD_F_UO],
                                F[QD_F_VO], p.vcap, p.rho_a_ocean * p.CD, p.tau_scale, taux, tauy, c->hpin_rows);
             qd_mark(c, {taux, tauy}, m);
-            QD_HIP(c, hipStreamSynchronize(c->stream));
+            c->eta_seq += 1.0;
+            hipLaunchKernelGGL(k_host_flag, dim3(1), dim3(64), 0, c->stream, c->hpin + 43, c->eta_seq);
+            if (compute_qnet && launch_qnet()) return -1;
+            if (qd_wait_host_flag(c, c->hpin + 43, c->eta_seq, "ocean step: the CFL maxima never arrived")) return -1;
             for (int k = 0; k < G.nrows; ++k) { maxVa = std::max(maxVa, c->hpin_rows[k]); maxUo = std::max(maxUo, c->hpin_rows[G.nrows + k]); }
         } else {
         QD_HIP(c, hipMemsetAsync(c->dscal + QD_S_TMP0, 0, 6 * sizeof(double), c->stream));
@@ -749,19 +774,7 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
             if (band_defer) {
                 // the SST kernel is queued; meanwhile: wait for the continuity kernel's sum (the flag it writes into pinned host
                 // memory: no HIP call on the wait path), reduce it between the ranks, publish
-                {
-                    volatile double* flag = c->hpin + 41;
-                    const auto t0 = std::chrono::steady_clock::now();
-                    unsigned spins = 0;
-                    while (*flag != c->eta_seq) {
-                        if ((++spins & 0xFFFFu) == 0) {
-                            if (hipStreamQuery(c->stream) == hipSuccess && *flag != c->eta_seq) return qd_fail(c, "ocean sub-step: eta sum never arrived");
-                            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 60.0)
-                                return qd_fail(c, "ocean sub-step: timeout waiting for the eta sum");
-                        }
-                    }
-                    std::atomic_thread_fence(std::memory_order_acquire);
-                }
+                if (qd_wait_host_flag(c, c->hpin + 41, c->eta_seq, "ocean sub-step: the eta sum never arrived")) return -1;
                 double sum = c->hpin[40];
                 if (qd_host_allreduce(c, &sum, 1, 0)) return -1;
                 c->hpin[42] = sum / (c->wsum_ocean + 1e-15);
