@@ -202,6 +202,13 @@ def main():
     if W > 0:
         dev.step_n(stars_w, dt, with_ocean=with_ocean, with_physics=with_phys, pass_albedo=True)
     barrier()
+    comm0 = (0, 0, 0)
+    if world > 1:
+        import ctypes as _ct
+        ne, na, nh = _ct.c_int(0), _ct.c_int(0), _ct.c_int(0)
+        dev.lib.qd_comm_stats(dev.h, _ct.byref(ne)); dev.lib.qd_comm_allreduce_count(dev.h, _ct.byref(na))
+        dev.lib.qd_comm_host_allreduce_count(dev.h, _ct.byref(nh))
+        comm0 = (ne.value, na.value, nh.value)
     also = "k_ocn_hyper" if (with_ocean and args.profile_kernel != "k_ocn_hyper") else None
     dev.timing(select=args.profile_kernel + ("," + also if also else ""))
     t0 = time.perf_counter()
@@ -213,6 +220,14 @@ def main():
         v = (ctypes.c_double * 1)(el)
         dev._chk(dev.lib.qd_comm_allreduce_max(dev.h, v, 1), "qd_comm_allreduce_max")
         el = v[0]
+    comm = None
+    if world > 1:                                  # collectives this rank issued inside the timed region, per step
+        import ctypes as _ct
+        ne, na, nh = _ct.c_int(0), _ct.c_int(0), _ct.c_int(0)
+        dev.lib.qd_comm_stats(dev.h, _ct.byref(ne)); dev.lib.qd_comm_allreduce_count(dev.h, _ct.byref(na))
+        dev.lib.qd_comm_host_allreduce_count(dev.h, _ct.byref(nh))
+        comm = {"band_rows": band[1], "halo_rows": band[2], "halo_exchanges_per_step": (ne.value - comm0[0]) / K,
+                "rccl_allreduces_per_step": (na.value - comm0[1]) / K, "host_ring_allreduces_per_step": (nh.value - comm0[2]) / K}
     kern_ms, kern_n = dev.timing_get(args.profile_kernel)
     also_ms, also_n = dev.timing_get(also) if also else (0.0, 0)
     dev.timing(on=False)
@@ -236,6 +251,8 @@ def main():
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "bytes_per_cell": bpc, "cells": cells, "avg_kernel_ms": kern_ms, "launches": kern_n},
     }
+    if comm:
+        out["config"]["collectives"] = comm
     if also and also_ms > 0:     # the kernel with the largest share of the step (ocean sub-steps), same accounting
         a2 = (BYTES_PER_CELL[also] * cells / 1e9) / (also_ms / 1e3)
         out["roofline_ocean_substep"] = {"bound": "hbm", "kernel": also, "achieved": a2, "peak": HBM_PEAK_GBS, "unit": "GB/s",
