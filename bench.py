@@ -180,14 +180,22 @@ def main():
     with_phys = not args.no_driver_physics
     dt = 300.0
     band = None
+    # QD_BENCH_SELF_RING=N (developer rehearsal on ONE GPU, never a reported number): run the multi-rank code path of this script as
+    # the middle band of an N-band decomposition over a one-rank RCCL communicator whose ring neighbours are the rank itself
+    ring = int(os.environ.get("QD_BENCH_SELF_RING", "0")) if world == 1 else 0
+    banded = world > 1 or ring > 1
     if world > 1:
         from qingdai_amd.bands import band_ranges, preferred_halo
         r0, n = band_ranges(args.nlat, world)[rank]
         band = (r0, n, preferred_halo(args.nlat, world, dt))
+    elif ring > 1:
+        from qingdai_amd.bands import band_ranges, preferred_halo
+        r0, n = band_ranges(args.nlat, ring)[ring // 2]
+        band = (r0, n, preferred_halo(args.nlat, ring, dt))
     grid, m, oc, forcing, mask, base_albedo, friction = build_case(args.nlat, args.nlon, with_ocean, device=local_rank,
                                                                    band=band, rank=rank, world=world)
     dev = m._dev
-    if world > 1:
+    if banded:
         from qingdai_amd.bands import init_rccl
         init_rccl(dev, rank, world)
     K, W = args.steps, args.warmup
@@ -196,14 +204,14 @@ def main():
 
     def barrier():
         dev.sync()
-        if world > 1:
+        if banded:
             dev._chk(dev.lib.qd_comm_barrier(dev.h), "qd_comm_barrier")
 
     if W > 0:
         dev.step_n(stars_w, dt, with_ocean=with_ocean, with_physics=with_phys, pass_albedo=True)
     barrier()
     comm0 = (0, 0, 0)
-    if world > 1:
+    if banded:
         import ctypes as _ct
         ne, na, nh = _ct.c_int(0), _ct.c_int(0), _ct.c_int(0)
         dev.lib.qd_comm_stats(dev.h, _ct.byref(ne)); dev.lib.qd_comm_allreduce_count(dev.h, _ct.byref(na))
@@ -215,13 +223,13 @@ def main():
     dev.step_n(stars_k, dt, with_ocean=with_ocean, with_physics=with_phys, pass_albedo=True)
     barrier()
     el = time.perf_counter() - t0
-    if world > 1:                                  # MAX over ranks
+    if banded:                                     # MAX over ranks
         import ctypes
         v = (ctypes.c_double * 1)(el)
         dev._chk(dev.lib.qd_comm_allreduce_max(dev.h, v, 1), "qd_comm_allreduce_max")
         el = v[0]
     comm = None
-    if world > 1:                                  # collectives this rank issued inside the timed region, per step
+    if banded:                                     # collectives this rank issued inside the timed region, per step
         import ctypes as _ct
         ne, na, nh = _ct.c_int(0), _ct.c_int(0), _ct.c_int(0)
         dev.lib.qd_comm_stats(dev.h, _ct.byref(ne)); dev.lib.qd_comm_allreduce_count(dev.h, _ct.byref(na))
@@ -253,6 +261,8 @@ def main():
     }
     if comm:
         out["config"]["collectives"] = comm
+    if ring > 1:
+        out["rehearsal"] = f"self-ring: ONE band of {ring} on one GPU, halos refreshed from the band itself -- not a benchmark result"
     if also and also_ms > 0:     # the kernel with the largest share of the step (ocean sub-steps), same accounting
         a2 = (BYTES_PER_CELL[also] * cells / 1e9) / (also_ms / 1e3)
         out["roofline_ocean_substep"] = {"bound": "hbm", "kernel": also, "achieved": a2, "peak": HBM_PEAK_GBS, "unit": "GB/s",
