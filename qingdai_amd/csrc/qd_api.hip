@@ -108,6 +108,13 @@ static int build_tables(qd_ctx* c) {
             }
             c->tabs.lapA[k] = dev_table(c, A); c->tabs.lapP[k] = dev_table(c, P); c->tabs.lapQ[k] = dev_table(c, Q);
             c->tabs.lapPoleA[k] = dev_table(c, PA);
+            std::vector<double> K4((size_t)nlat * 4);
+            for (int i = 0; i < nlat; ++i) {
+                K4[4 * i + 0] = A[i > 0 ? i - 1 : 0]; K4[4 * i + 1] = A[i < nlat - 1 ? i + 1 : nlat - 1];
+                K4[4 * i + 2] = P[i]; K4[4 * i + 3] = Q[i];
+            }
+            c->tabs.lapK[k] = dev_table(c, K4);
+            c->h_lapK[k] = K4;
         }
         std::vector<double> cu(nlat), cv(nlat), px(nlat), igx(nlat);
         for (int i = 0; i < nlat; ++i) {
@@ -168,6 +175,7 @@ int qd_build_k4_tables(qd_ctx* c, double dt, bool ocean, double sub_dt) {
             c->k4_atm_skip[f] = apply ? 0 : 1;
         }
         QD_HIP(c, hipMemcpy(c->k4_atm, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+        c->h_k4[0] = tab; c->qs_key[0][0] = NAN;
         c->k4_atm_dt = dt;
     } else {
         if (c->k4_ocn_dt == sub_dt) return 0;
@@ -184,6 +192,7 @@ int qd_build_k4_tables(qd_ctx* c, double dt, bool ocean, double sub_dt) {
         }
         for (int f = 0; f < 3; ++f) c->k4_ocn_skip[f] = (isset(ov[f]) ? (ov[f] > 0.0) : anypos[f]) ? 0 : 1;
         QD_HIP(c, hipMemcpy(c->k4_ocn, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+        c->h_k4[1] = tab; c->qs_key[1][0] = NAN;
         c->k4_ocn_dt = sub_dt;
     }
     return 0;
@@ -232,13 +241,16 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
     c->desc = *d; c->p = *params;
     { const char* ef = std::getenv("QD_FUSED"); if (ef && ef[0] == '0') c->use_fused = 0; }
     { const char* ef = std::getenv("QD_FUSED_FAST"); if (ef) c->fused_fast = std::atoi(ef); }
+    { const char* ef = std::getenv("QD_STREAM_R"); if (ef) c->stream_rows = std::max(1, std::atoi(ef)); }
     c->geo = QdGeom{d->n_lat, d->n_lon, d->row0, d->n_rows, d->halo, full ? 1 : 0, d->row0 - d->halo, d->n_rows + 2 * d->halo};
     c->own_row0 = d->row0; c->own_nrows = d->n_rows;
     auto bail = [&](const char* w, hipError_t e) { qd_fail(nullptr, w, e); qd_destroy(c); return -1; };
     hipError_t e;
     if ((e = hipSetDevice(d->device)) != hipSuccess) return bail("hipSetDevice", e);
     if ((e = hipStreamCreate(&c->stream)) != hipSuccess) return bail("hipStreamCreate", e);
-    const size_t cells = c->geo.cells();
+    // every slab is allocated with QD_PAD_ROWS rows of slack behind its last row: the row-streaming kernels prefetch a few rows
+    // ahead of the row they work on without clamping (what they read there is never used)
+    const size_t cells = c->geo.cells() + (size_t)QD_PAD_ROWS * c->geo.nlon;
     for (int f = 0; f < QD_F_COUNT_F64; ++f) {
         if ((e = hipMalloc(&c->f[f], cells * sizeof(double))) != hipSuccess) return bail("hipMalloc field", e);
         hipMemsetAsync(c->f[f], 0, cells * sizeof(double), c->stream);
@@ -311,7 +323,7 @@ extern "C" int qd_destroy(qd_handle c) {
     for (int s = 0; s < QD_NSCRATCH; ++s) if (c->scratch[s]) hipFree(c->scratch[s]);
     for (double* t : c->tab_alloc) hipFree(t);
     if (c->land) hipFree(c->land); if (c->icemask) hipFree(c->icemask);
-    if (c->k4_atm) hipFree(c->k4_atm); if (c->k4_ocn) hipFree(c->k4_ocn);
+    if (c->k4_atm) hipFree(c->k4_atm); if (c->k4_ocn) hipFree(c->k4_ocn); for (int k = 0; k < 2; ++k) if (c->qs_tab[k]) hipFree(c->qs_tab[k]);
     if (c->red_partial) hipFree(c->red_partial); if (c->dscal) hipFree(c->dscal);
     if (c->dcount) hipFree(c->dcount); if (c->hist) hipFree(c->hist); if (c->sel_state) hipFree(c->sel_state);
     if (c->zonal_tw) hipFree(c->zonal_tw);

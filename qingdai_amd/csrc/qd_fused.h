@@ -37,3 +37,9 @@ struct QdOcnArgs {
 QdTileShape qd_pick_tile(const QdGeom& G);
 int qd_launch_dyn_hyper(qd_ctx* c, QdDynArgs& P, int margin);
 int qd_launch_ocn_hyper(qd_ctx* c, QdOcnArgs& P, int margin);
+
+// qd_stream.hip: the row-streaming form of the same two kernels (default on grids of >= 64 columns)
+bool qd_stream_ok(const qd_ctx* c, int margin);
+bool qd_ocn_stream_ok(const qd_ctx* c, int margin);
+int qd_launch_dyn_stream(qd_ctx* c, const QdDynArgs& P, int margin);
+int qd_launch_ocn_stream(qd_ctx* c, const QdOcnArgs& P, int margin);

@@ -28,6 +28,7 @@
 #include "qd_internal.h"
 #include "qd_device.h"
 #include "qd_fused.h"
+#include "qd_wave.h"
 #include <cstdlib>
 #include <algorithm>
 
@@ -35,13 +36,6 @@
 #define QD_S 64                  // plane row stride (doubles) = one wavefront
 #define QD_FBLOCK 512             // threads per fused-kernel workgroup
 #define QD_NW (QD_FBLOCK / 64)   // wavefronts per workgroup
-
-// np.nan_to_num in 5 VALU ops instead of 12: clamp with max/min (which also map NaN to a bound), then
-// send NaN to 0 with one compare + select
-__device__ __forceinline__ double qd_nnf(double x) {
-    const double c = fmin(fmax(x, -DBL_MAX), DBL_MAX);
-    return (x == x) ? c : 0.0;
-}
 
 struct QdLapC {                  // scalars + reciprocal row tables of the spherical Laplacian
     double dphi, dlam, a;
@@ -420,30 +414,12 @@ __device__ __forceinline__ void qd_ocn_exact(const QdGeom& G, const QdTabs& T, c
 // on the (binding) VALU pipe.  A scalar load of a few dwords right before a field's del^4 costs nothing there.
 struct QdKargDyn { QdGeom G; QdTabs T; QdDynArgs P; };
 struct QdKargOcn { QdGeom G; QdTabs T; QdOcnArgs P; };
-#define QD_CONST __attribute__((address_space(4)))
 template <typename A>
 __device__ __forceinline__ const A QD_CONST* qd_kargs(unsigned off) {
     const char QD_CONST* p = (const char QD_CONST*)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(p));                             // opaque: the loads below cannot be hoisted to the kernel entry
     return (const A QD_CONST*)(p + off);
 }
-typedef const double __attribute__((address_space(4)))* qd_cptr;
-__device__ __forceinline__ double qd_sload(const double* p, int idx) { return ((qd_cptr)(unsigned long long)p)[idx]; }
-__device__ __forceinline__ bool qd_nonfinite(double x) { return __builtin_amdgcn_class(x, 0x207); }   // sNaN|qNaN|-inf|+inf
-// value held by lane+1 / lane-1.  bound_ctrl:1 (the lane without a neighbour reads 0) lets the move stand alone: with
-// bound_ctrl:0 the destination must first be initialised with the old value, one extra v_mov per DPP move.  Lanes 0 and
-// 63 are halo columns whose results never reach an owned cell.
-__device__ __forceinline__ double qd_east(double x) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x130, 0xf, 0xf, true);     // wave_shl:1
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x130, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double qd_west(double x) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x138, 0xf, 0xf, true);     // wave_shr:1
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x138, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-
 template <int TR> struct QdFast {
     static constexpr int RA = TR + 10;
     static constexpr int K = RA / QD_NW;                   // consecutive rows per wave
@@ -454,7 +430,6 @@ template <int TR> struct QdFast {
 // plane rows [p0, p0+RA).  Normally p0 = o0-5; next to a pole (or to the end of the row segment) the plane is
 // shifted so that it never leaves [0, n) (or the segment +-5 rows): there are no out-of-domain rows, hence no
 // masks.  An owned row needs 4 plane rows on each side except towards a pole, where the stencils stop anyway.
-__device__ __forceinline__ int qd_clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
 struct QdFastTile { int p0, o0, o1; bool fits, interior; };
 template <int TR>
@@ -860,9 +835,10 @@ template <int TR> static void launch_ocn(qd_ctx* c, const QdOcnArgs& P, int marg
     }
 
 int qd_launch_dyn_hyper(qd_ctx* c, QdDynArgs& P, int margin) {
+    if (qd_stream_ok(c, margin)) return qd_launch_dyn_stream(c, P, margin);
     qd_tile_init(c);
     P.ts = c->tile;
-    P.fast = c->fused_fast;
+    P.fast = c->fused_fast != 0;
     QdScope sc(c, "k_dyn_hyper");
 #define QD_CALL_DYN(N) launch_dyn<N>(c, P, margin)
     QD_DISPATCH_TR(P.ts.tr, QD_CALL_DYN)
@@ -870,9 +846,10 @@ int qd_launch_dyn_hyper(qd_ctx* c, QdDynArgs& P, int margin) {
 }
 
 int qd_launch_ocn_hyper(qd_ctx* c, QdOcnArgs& P, int margin) {
+    if (qd_ocn_stream_ok(c, margin)) return qd_launch_ocn_stream(c, P, margin);
     qd_tile_init(c);
     P.ts = c->tile;
-    P.fast = c->fused_fast;
+    P.fast = c->fused_fast != 0;
     QdScope sc(c, "k_ocn_hyper");
 #define QD_CALL_OCN(N) launch_ocn<N>(c, P, margin)
     QD_DISPATCH_TR(P.ts.tr, QD_CALL_OCN)

@@ -21,6 +21,7 @@
 #include "../../include/qingdai_hip.h"
 
 #define QD_NSCRATCH 16
+#define QD_PAD_ROWS 8        // rows of slack behind every slab (see qd_create)
 #define QD_BLOCK 256
 #define QD_MAXF 5            // fields per batched stencil launch
 #define QD_HIST_BINS 2048    // 11-bit radix-select digit
@@ -52,6 +53,7 @@ struct QdTabs {
     const double* lapP[2];
     const double* lapQ[2];
     const double* lapPoleA[2];   // [8]: (Aa, Ab) of the pole-row types g = 0, 1, n-2, n-1; lapP holds their P
+    const double* lapK[2];       // [nlat][4] packed per row: lapA[r-1], lapA[r+1], lapP[r], lapQ[r] (one s_load_dwordx8; qd_stream.hip)
     const double* mom_cu;    // -(g / (f_safe a cos6))   geostrophic u_g coefficient
     const double* mom_cv;    //   g / (f_safe a)         geostrophic v_g coefficient
     const double* mom_px;    // -(g / (a cos6))          primitive PGF_x coefficient
@@ -187,7 +189,16 @@ struct qd_ctx {
     int64_t atm_counter = 0, ocn_counter = 0;
     QdTileShape tile{0, 0, 0, 0};   // fused-kernel tile (qd_pick_tile)
     int use_fused = 1;              // QD_FUSED=0 selects the unfused reference-order kernels
-    int fused_fast = 1;             // QD_FUSED_FAST=0: every tile of the LDS-tiled kernels takes the EXACT path
+    int fused_fast = 1;             // QD_FUSED_FAST: 1 row-streaming kernels (qd_stream.hip), FAST variant with per-wave EXACT fallback; 2 the same kernels,
+                                    // every wave EXACT; 0 LDS-tiled kernels (qd_fused.hip), every tile EXACT; 3 LDS-tiled kernels with their FAST path
+    int stream_rows = 0;            // QD_STREAM_R: strip height of the row-streaming kernels (0 = pick per launch)
+    // row-streaming kernels (qd_stream.hip): per-field packed row tables {lapA[r+1], lapP[r], lapQ[r], k4[r]}, [0] atmosphere
+    // (5 fields), [1] ocean (3); rebuilt when the k4 tables or the scalar overrides change (qs_key remembers what they hold)
+    double* qs_tab[2] = {nullptr, nullptr};
+    double qs_key[2][8] = {{NAN, 0, 0, 0, 0, 0, 0, 0}, {NAN, 0, 0, 0, 0, 0, 0, 0}};
+    std::vector<double> h_lapK[2];  // host copies of QdTabs::lapK
+    std::vector<double> h_k4[2];    // host copies of k4_atm / k4_ocn
+    int qs_wgs_per_cu[3] = {0, 0, 0};   // resident workgroups per CU of k_dyn_stream<false>, <true>, k_ocn_stream (occupancy query, cached)
     int cloud_eff_valid = 0;
     int last_nsub = 0;
     // host staging

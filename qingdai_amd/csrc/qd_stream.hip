@@ -1,0 +1,696 @@
+// qd_stream.hip -- row-streaming form of the fused momentum + del^4 kernels (gfx950): the hot stencil of the path.
+//
+//   k_dyn_stream   atmosphere: np.gradient(h) -> geostrophic-relaxation | primitive momentum (dynamics.py:482-530)
+//                  -> del^4 hyperdiffusion of u, v, h, q, cloud (dynamics.py:533-594, 144-212), ONE launch.
+//   k_ocn_stream   ocean sub-step: grad(eta) + Coriolis + wind stress + drag + land mask + polar sponge
+//                  (ocean.py:306-336) -> del^4 of uo, vo, eta (ocean.py:341-356).
+//
+// Same arithmetic, bit for bit, as the LDS-tiled kernels of qd_fused.hip (which stay as the EXACT reference path and
+// for grids narrower than one wavefront); different machine mapping:
+//   * A WAVEFRONT owns one field of one strip: 58 owned columns (64 lanes, 3 halo lanes each side; lane l is global
+//     column 58*cs-3+l, so every global access is one coalesced 512-byte row segment) x R owned rows, and marches down
+//     the rows.  The latitude part of the spherical Laplacian, gradient(cos*gradient(F)), only touches rows r-2, r, r+2,
+//     so del^4 is a two-stage pipeline over the row stream (see "del^4 of a row stream" below): 10 doubles of state per
+//     lane, no LDS, no barrier.  Waves are independent: the loads of the next rows are in flight while a row is being
+//     worked on, and the waves of a SIMD cover each other's latencies.  East / west neighbours are DPP wave shifts.
+//   * Memory access is through buffer instructions: wave-uniform row offset in an SGPR, constant per-lane column offset
+//     in a VGPR (no per-access address arithmetic), and the hardware range check drops the stores of the halo lanes
+//     (their offset is out of range) -- no exec masking, no branch: the row loop is straight-line code, which is what
+//     lets the compiler's s_waitcnt placement keep several rows of loads and stores in flight.
+//   * The workgroup is the set of fields of one strip (5 waves: u, v, h, q, cloud; 3: uo, vo, eta) so that the rows of h
+//     / eta the momentum waves re-read come from the CU's L1.  Halo rows (4 above, 4 below; 5 for h) are recomputed.
+//   * Per-row coefficients {A[r-1], A[r+1], P[r], Q[r]} are packed so that one scalar load fetches a row's set.
+//   * nan_to_num is the identity on finite values: the FAST variant omits it and tests every stored value (and every
+//     clip input) with one v_cmp_class; a WAVE that saw a non-finite value re-runs its strip with the EXACT variant
+//     (literal nan_to_num / np.clip at the reference's places; outputs go to separate buffers, so that is safe).
+//   * Strips next to a pole take the POLE variant: the one-sided np.gradient rows are two extra differences.
+#include "qd_internal.h"
+#include "qd_device.h"
+#include "qd_fused.h"
+#include "qd_wave.h"
+#include <cstdlib>
+#include <algorithm>
+
+#define QS_TC 58                 // owned columns per strip (lanes 3..60)
+
+// what ONE wave needs of its field; read from the kernarg segment with the wave's (uniform) field index, so that the
+// records of the other fields never occupy SGPRs.  tab: packed rows {lapA[r+1], lapP[r], lapQ[r], k4[r]} of the field.
+struct QsRec { const double* in; const double* aux; double* out; const double* tab; int skip; int pad_; };
+
+struct QsDynArgs {
+    QdGeom G;
+    const double *poleA, *c8, *c9;             // c8 / c9: mom_cu, mom_cv (geostrophic) | mom_px, fcor (primitive)
+    const double *h, *fric;
+    double dt, inv_dlon, inv_2dlon, inv_dlat, inv_2dlat, pgf_y;
+    int R, ntc, nrs, exact;
+    QsRec rec[5];                              // u v h q cloud; aux = the other momentum component (primitive scheme)
+};
+
+struct QsOcnArgs {
+    QdGeom G;
+    const double *poleA, *fcor, *igx, *rx;
+    const double *uo, *vo, *eta;
+    const uint8_t* land;
+    const double* eta_mean;                    // deferred end of the previous sub-step (see QdOcnArgs)
+    double eta_cap, sub_dt, g, r_bot, inv_2dlon, inv_2dlat, inv_a, inv_rhoH;
+    int R, ntc, nrs, exact;
+    QsRec rec[3];                              // uo vo eta; aux = taux | tauy
+};
+
+// ---------------------------------------------------------------- buffer access
+typedef unsigned int qs_u32x2 __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t qs_rsrc;
+#define QS_RSRC_FLAGS 0x00020000               // raw buffer, 32-bit data format (the word-3 encoding of gfx90a / gfx94x / gfx950)
+#define QS_OOB 0x80000000u                     // a lane offset the range check always rejects
+
+__device__ __forceinline__ qs_rsrc qs_make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, QS_RSRC_FLAGS);
+}
+// row: ELEMENT offset of the row (wave-uniform, goes to the SGPR offset); vo: the lane's byte offset inside the row
+__device__ __forceinline__ double qs_ld(qs_rsrc r, unsigned row, unsigned vo) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, vo, row * 8u, 0));
+}
+__device__ __forceinline__ void qs_st(qs_rsrc r, unsigned row, unsigned vo, double v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(qs_u32x2, v), r, vo, row * 8u, 0);
+}
+__device__ __forceinline__ int qs_ld8(qs_rsrc r, unsigned row, unsigned vo8) {
+    return (int)__builtin_amdgcn_raw_buffer_load_b8(r, vo8, row, 0);
+}
+
+// ---------------------------------------------------------------- row addressing (wave-uniform)
+// Element offset of global row g.  Inside a strip local rows are consecutive, and every slab has QD_PAD_ROWS rows of slack
+// behind it, so the row loop just adds the row stride; only the rows next to a pole need care:
+// atmosphere rows never wrap (a row beyond a pole is never used: clamp), np.roll(axis=0) rows of the ocean's eta do
+// (row -1 is row n-1, row n is row 0; band handles find them in their ring halo).
+__device__ __forceinline__ unsigned qs_off(const QdGeom& G, int g) {
+    g = qd_clampi(g, 0, G.nlat - 1);
+    int l = qd_lrow(G, g);
+    l = l < G.lrows_ ? l : G.lrows_ - 1;
+    return (unsigned)l * (unsigned)G.nlon;
+}
+__device__ __forceinline__ unsigned qs_off_roll(const QdGeom& G, int g) {
+    if (g < 0) g += G.nlat; else if (g >= G.nlat) g -= G.nlat;
+    return qs_off(G, g);
+}
+
+// rows of every input a wave keeps in flight ahead of the row it is working on: plain fields (1 load per row) / momentum
+// sources (3-5 loads per row)
+#ifndef QS_PDP
+#define QS_PDP 3
+#endif
+#ifndef QS_PDM
+#define QS_PDM 2
+#endif
+
+struct QsW {                      // what a wave knows about its strip (everything but lane / v* is wave-uniform)
+    int n, nlon, lane, j, o0, o1;
+    unsigned vo, vs, vo8;         // lane byte offset inside a row: loads (wrapped column) / stores (QS_OOB on halo lanes) / u8 loads
+    unsigned slab_bytes;          // size of one f64 slab incl. its slack rows (the range of every buffer)
+    bool west_edge, east_edge;
+};
+
+// Code variants of a wave's pass over its strip:
+//   QS_FAST   finite values: no nan_to_num, non-finite values only detected (one v_cmp_class per stored value / clip input)
+//   QS_EXACT  literal nan_to_num / np.clip at the reference's places (re-run of a wave that saw a non-finite value, or
+//             QD_FUSED_FAST=2)
+enum { QS_FAST = 0, QS_EXACT = 2 };
+
+template <int V> __device__ __forceinline__ double qs_clip200(double x, bool& bad) {
+    if (V == QS_EXACT) return qd_clip(x, -200.0, 200.0);
+    bad |= qd_nonfinite(x);
+    return fmin(fmax(x, -200.0), 200.0);
+}
+
+// ---------------------------------------------------------------- row sources: F[g] of one field, one row per call
+// A source holds the inputs of rows g .. g+PD-1 in registers (the later ones still in flight); get(g) turns row g into
+// F[g], shifts, and issues the loads of row g+PD at the running row offset `ro`.  In the unrolled row loop the shifts are
+// register renames.  get_edge(g) is get(g) for a pole row (one-sided np.gradient / np.roll across the pole).
+template <int V> struct QsSrcPlain {                  // h, q, cloud: the field itself
+    qs_rsrc p; const QdGeom& G; const QsW& W; double q[QS_PDP]; unsigned ro;
+    __device__ __forceinline__ void start(int g0, bool&) {
+        ro = qs_off(G, g0);
+#pragma unroll
+        for (int k = 0; k < QS_PDP; ++k) { q[k] = qs_ld(p, ro, W.vo); ro += W.nlon; }
+    }
+    __device__ __forceinline__ double get(int, bool&) {
+        const double c = q[0];
+#pragma unroll
+        for (int k = 0; k + 1 < QS_PDP; ++k) q[k] = q[k + 1];
+        q[QS_PDP - 1] = qs_ld(p, ro, W.vo); ro += W.nlon;
+        return c;
+    }
+    __device__ __forceinline__ double get_edge(int g, bool& bad) { return get(g, bad); }
+};
+
+// momentum component that needs dh/dphi: u of the geostrophic scheme, v of the primitive one (dynamics.py:488-530)
+template <bool PRIM, int V> struct QsSrcLat {
+    const QsDynArgs& A; const QsW& W;
+    qs_rsrc H, FR, X, Y;                                              // h, friction, own component, the other one (PRIM)
+    double hh[QS_PDM + 2], x[QS_PDM], y[QS_PDM], fr[QS_PDM];          // hh: h rows g-1 .. g+PD
+    unsigned ro;                                                      // row g+PD
+    __device__ __forceinline__ void start(int g0, bool&) {
+        hh[0] = qs_ld(H, qs_off(A.G, g0 - 1), W.vo);                  // row -1 does not exist: clamped, never used
+        ro = qs_off(A.G, g0);
+#pragma unroll
+        for (int k = 0; k < QS_PDM; ++k) {
+            hh[k + 1] = qs_ld(H, ro, W.vo); x[k] = qs_ld(X, ro, W.vo); fr[k] = qs_ld(FR, ro, W.vo); y[k] = PRIM ? qs_ld(Y, ro, W.vo) : 0.0;
+            ro += W.nlon;
+        }
+        hh[QS_PDM + 1] = qs_ld(H, ro, W.vo);
+    }
+    template <int EDGE> __device__ __forceinline__ double step(int g, bool& bad) {
+        const double hm = hh[0], hc = hh[1], hn = hh[2], x0 = x[0], y0 = y[0], f0 = fr[0];
+        double dh = (hn - hm) * A.inv_2dlat;
+        if (EDGE) { if (g == 0) dh = (hn - hc) * A.inv_dlat; if (g == W.n - 1) dh = (hc - hm) * A.inv_dlat; }
+        double val;
+        if (PRIM) {
+            const double vx = x0 + (A.pgf_y * dh - qd_sload(A.c9, g) * y0 - f0 * x0) * A.dt;
+            val = qs_clip200<V>(vx, bad);
+        } else {
+            const double u_g = qs_clip200<V>(qd_sload(A.c8, g) * dh, bad);
+            const double ur = x0 * 0.8 + u_g * 0.2;
+            val = ur + (-f0 * ur) * A.dt;
+        }
+        // lanes 0 and 63 have no east / west neighbour: the reference path zeroes them, keep the planes identical
+        if (W.lane == 0 || W.lane == 63) val = 0.0;
+#pragma unroll
+        for (int k = 0; k + 1 < QS_PDM + 2; ++k) hh[k] = hh[k + 1];
+#pragma unroll
+        for (int k = 0; k + 1 < QS_PDM; ++k) { x[k] = x[k + 1]; fr[k] = fr[k + 1]; y[k] = y[k + 1]; }
+        x[QS_PDM - 1] = qs_ld(X, ro, W.vo); fr[QS_PDM - 1] = qs_ld(FR, ro, W.vo); if (PRIM) y[QS_PDM - 1] = qs_ld(Y, ro, W.vo);
+        ro += W.nlon;
+        hh[QS_PDM + 1] = qs_ld(H, ro, W.vo);
+        return val;
+    }
+    __device__ __forceinline__ double get(int g, bool& bad) { return step<0>(g, bad); }
+    __device__ __forceinline__ double get_edge(int g, bool& bad) { return step<1>(g, bad); }
+};
+
+// momentum component that needs dh/dlambda: v of the geostrophic scheme, u of the primitive one
+template <bool PRIM, int V> struct QsSrcLon {
+    const QsDynArgs& A; const QsW& W;
+    qs_rsrc H, FR, X, Y;
+    double hh[QS_PDM], x[QS_PDM], y[QS_PDM], fr[QS_PDM];
+    unsigned ro;
+    __device__ __forceinline__ void load(int k) {
+        hh[k] = qs_ld(H, ro, W.vo); x[k] = qs_ld(X, ro, W.vo); fr[k] = qs_ld(FR, ro, W.vo); y[k] = PRIM ? qs_ld(Y, ro, W.vo) : 0.0;
+        ro += W.nlon;
+    }
+    __device__ __forceinline__ void start(int g0, bool&) {
+        ro = qs_off(A.G, g0);
+#pragma unroll
+        for (int k = 0; k < QS_PDM; ++k) load(k);
+    }
+    __device__ __forceinline__ double get(int g, bool& bad) {
+        const double hc = hh[0], x0 = x[0], y0 = y[0], f0 = fr[0];
+        const double hw = qd_west(hc), he = qd_east(hc);
+        // np.gradient is one-sided at both ends of the longitude axis (not periodic: SURVEY 0.6)
+        const double inv_lon = (W.west_edge || W.east_edge) ? A.inv_dlon : A.inv_2dlon;
+        const double dh = ((W.east_edge ? hc : he) - (W.west_edge ? hc : hw)) * inv_lon;
+        double val;
+        if (PRIM) {
+            const double ux = x0 + (qd_sload(A.c8, g) * dh + qd_sload(A.c9, g) * y0 - f0 * x0) * A.dt;
+            val = qs_clip200<V>(ux, bad);
+        } else {
+            const double v_g = qs_clip200<V>(qd_sload(A.c9, g) * dh, bad);
+            const double vr = x0 * 0.8 + v_g * 0.2;
+            val = vr + (-f0 * vr) * A.dt;
+        }
+        if (W.lane == 0 || W.lane == 63) val = 0.0;
+#pragma unroll
+        for (int k = 0; k + 1 < QS_PDM; ++k) { hh[k] = hh[k + 1]; x[k] = x[k + 1]; fr[k] = fr[k + 1]; y[k] = y[k + 1]; }
+        load(QS_PDM - 1);
+        return val;
+    }
+    __device__ __forceinline__ double get_edge(int g, bool& bad) { return get(g, bad); }
+};
+
+// ocean: eta as the kernel sees it = the deferred "eta -= mean; nan_to_num; clip" of the previous sub-step applied on load
+template <int V> __device__ __forceinline__ double qs_eta(double raw, bool defer, double em, double cap, bool& bad) {
+    if (!defer) return raw;
+    const double e = raw - em;
+    if (V == QS_EXACT) return qd_clip(qd_nn(e), -cap, cap);
+    bad |= qd_nonfinite(e);
+    return fmin(fmax(e, -cap), cap);
+}
+
+template <int V> struct QsSrcEta {
+    const QsOcnArgs& A; const QsW& W; qs_rsrc E; bool defer; double em; double q[QS_PDP]; unsigned ro;
+    __device__ __forceinline__ void start(int g0, bool&) {
+        ro = qs_off(A.G, g0);
+#pragma unroll
+        for (int k = 0; k < QS_PDP; ++k) { q[k] = qs_ld(E, ro, W.vo); ro += W.nlon; }
+    }
+    __device__ __forceinline__ double get(int, bool& bad) {
+        const double c = qs_eta<V>(q[0], defer, em, A.eta_cap, bad);
+#pragma unroll
+        for (int k = 0; k + 1 < QS_PDP; ++k) q[k] = q[k + 1];
+        q[QS_PDP - 1] = qs_ld(E, ro, W.vo); ro += W.nlon;
+        return c;
+    }
+    __device__ __forceinline__ double get_edge(int g, bool& bad) { return get(g, bad); }
+};
+
+// uo: zonal pressure gradient (ocean.py:306-336)
+template <int V> struct QsSrcOcnU {
+    const QsOcnArgs& A; const QsW& W; qs_rsrc E, U, Vv, T, L; bool defer; double em;
+    double e[QS_PDM], u0[QS_PDM], v0[QS_PDM], tx[QS_PDM]; int ld[QS_PDM]; unsigned ro;
+    __device__ __forceinline__ void load(int k) {
+        e[k] = qs_ld(E, ro, W.vo); u0[k] = qs_ld(U, ro, W.vo); v0[k] = qs_ld(Vv, ro, W.vo); tx[k] = qs_ld(T, ro, W.vo);
+        ld[k] = qs_ld8(L, ro, W.vo8);
+        ro += W.nlon;
+    }
+    __device__ __forceinline__ void start(int g0, bool&) {
+        ro = qs_off(A.G, g0);
+#pragma unroll
+        for (int k = 0; k < QS_PDM; ++k) load(k);
+    }
+    __device__ __forceinline__ double get(int g, bool& bad) {
+        const double ec = qs_eta<V>(e[0], defer, em, A.eta_cap, bad);
+        const double f = qd_sload(A.fcor, g);
+        const double gx = ((qd_east(ec) - qd_west(ec)) * A.inv_2dlon) * qd_sload(A.igx, g);
+        const double du = (f * v0[0] - A.g * gx + tx[0] * A.inv_rhoH - A.r_bot * u0[0]);
+        double un = u0[0] + A.sub_dt * du;
+        if (ld[0] == 1) un = 0.0;
+        const double sx = A.sub_dt * qd_sload(A.rx, g);
+        double val = un - sx * un;
+        if (W.lane == 0 || W.lane == 63) val = 0.0;
+#pragma unroll
+        for (int k = 0; k + 1 < QS_PDM; ++k) { e[k] = e[k + 1]; u0[k] = u0[k + 1]; v0[k] = v0[k + 1]; tx[k] = tx[k + 1]; ld[k] = ld[k + 1]; }
+        load(QS_PDM - 1);
+        return val;
+    }
+    __device__ __forceinline__ double get_edge(int g, bool& bad) { return get(g, bad); }
+};
+
+// vo: meridional pressure gradient; eta rows wrap across the poles (np.roll(axis=0), ocean.py:308)
+template <int V> struct QsSrcOcnV {
+    const QsOcnArgs& A; const QsW& W; qs_rsrc E, U, Vv, T, L; bool defer; double em;
+    double es, ec, en[QS_PDM], u0[QS_PDM], v0[QS_PDM], ty[QS_PDM]; int ld[QS_PDM];  // es, ec: eta rows g-1, g (as the kernel sees them); en: raw rows g+1 ..
+    unsigned ro;                                                                   // row g+PD
+    __device__ __forceinline__ void load(int k) {
+        u0[k] = qs_ld(U, ro, W.vo); v0[k] = qs_ld(Vv, ro, W.vo); ty[k] = qs_ld(T, ro, W.vo);
+        ld[k] = qs_ld8(L, ro, W.vo8);
+        ro += W.nlon;
+        en[k] = qs_ld(E, ro, W.vo);
+    }
+    __device__ __forceinline__ void start(int g0, bool& bad) {
+        es = qs_eta<V>(qs_ld(E, qs_off_roll(A.G, g0 - 1), W.vo), defer, em, A.eta_cap, bad);      // g0 = 0: the other pole's row
+        ro = qs_off(A.G, g0);
+        ec = qs_eta<V>(qs_ld(E, ro, W.vo), defer, em, A.eta_cap, bad);
+#pragma unroll
+        for (int k = 0; k < QS_PDM; ++k) load(k);
+    }
+    template <int EDGE> __device__ __forceinline__ double step(int g, bool& bad) {
+        double enr = en[0];
+        if (EDGE) { if (g == W.n - 1) enr = qs_ld(E, qs_off_roll(A.G, g + 1), W.vo); }            // row n is row 0
+        const double enc = qs_eta<V>(enr, defer, em, A.eta_cap, bad);
+        const double f = qd_sload(A.fcor, g);
+        const double gy = ((enc - es) * A.inv_2dlat) * A.inv_a;
+        const double dv = (-f * u0[0] - A.g * gy + ty[0] * A.inv_rhoH - A.r_bot * v0[0]);
+        double vn = v0[0] + A.sub_dt * dv;
+        if (ld[0] == 1) vn = 0.0;
+        const double sx = A.sub_dt * qd_sload(A.rx, g);
+        double val = vn - sx * vn;
+        if (W.lane == 0 || W.lane == 63) val = 0.0;
+        es = ec; ec = enc;
+#pragma unroll
+        for (int k = 0; k + 1 < QS_PDM; ++k) { en[k] = en[k + 1]; u0[k] = u0[k + 1]; v0[k] = v0[k + 1]; ty[k] = ty[k + 1]; ld[k] = ld[k + 1]; }
+        load(QS_PDM - 1);
+        return val;
+    }
+    __device__ __forceinline__ double get(int g, bool& bad) { return step<0>(g, bad); }
+    __device__ __forceinline__ double get_edge(int g, bool& bad) { return step<1>(g, bad); }
+};
+
+// ---------------------------------------------------------------- del^4 of a row stream
+// The spherical Laplacian in the reciprocal form of the fused kernels (qd_fused.hip, QdTabs::lapA/P/Q):
+//   L_r = P_r (Gb_r - Ga_r) + Q_r ((X_{j+1} - 2 X) + X_{j-1}),   Gb_r = A_{r+1} (X_{r+2} - X_r),   Ga_r = A_{r-1} (X_r - X_{r-2})
+// Ga_r IS Gb_{r-2} -- the same product of the same operands -- so a row stream needs ONE new difference per row and stage:
+// when row gg of F arrives the wave forms Gb(gg-2), then D[gg-2] = lap(F)[gg-2], then the same for D two rows later, and stores
+// out[gg-4] = F[gg-4] - (k4 lap(D)[gg-4]) dt.  Registers carried from row to row: F rows gg-4..gg-1, D rows gg-4, gg-3, the
+// last two Gb of each stage (10 doubles), and the packed coefficient rows {A[r+1], P[r], Q[r], k4[r]} of rows gg-2, gg-3,
+// gg-4 in SGPRs (the row a step needs first was loaded one step earlier).
+// Next to a pole np.gradient is one-sided (grid.py:41-88; coefficients QdTabs::lapPoleA, row types 0, 1, n-2, n-1):
+//   Ga_0 = Ga_1 = pA0 (X_1 - X_0),   Gb_{n-2} = Gb_{n-1} = pA5 (X_{n-1} - X_{n-2}),   everything else as above
+// (pA1 = A_1, pA3 = A_2, pA4 = A_{n-3}, pA6 = A_{n-2}; pA2 = pA0, pA7 = pA5), and lapP holds the pole rows' own P.
+// So a strip at the south pole has its own four first steps, a strip at the north pole its own five last ones, and
+// every strip runs the same row loop in between.
+template <int V> __device__ __forceinline__ double qs_d2(double c) {
+    // e - 2c in one fma: 2c is exact, so fma(-2, c, e) rounds exactly like (e - 2.0 * c) -- unless 2c overflows, which only
+    // values that went through nan_to_num can do: the EXACT variant keeps the reference's two operations
+    return (V == QS_EXACT ? (qd_east(c) - 2.0 * c) : __builtin_fma(-2.0, c, qd_east(c))) + qd_west(c);
+}
+template <int V> __device__ __forceinline__ double qs_nn(double x) { return V == QS_EXACT ? qd_nnf(x) : x; }
+
+struct QsCoef { double a, p, q, k; };           // A[r+1], P[r], Q[r], k4[r]
+__device__ __forceinline__ QsCoef qs_coef(const double* tab, int r, int n) {
+    r = qd_clampi(r, 0, n - 1);
+    const qd_cptr t = (qd_cptr)(unsigned long long)tab + 4u * (unsigned)r;
+    return QsCoef{t[0], t[1], t[2], t[3]};
+}
+
+struct QsPipe {                   // what a wave carries from row to row
+    double f1, f2, f3, f4;        // F rows gg-1 .. gg-4
+    double gf1, gf2;              // Gb of F for rows gg-3, gg-4
+    double d1, d2;                // D rows gg-3, gg-4
+    double gd1, gd2;              // Gb of D for rows gg-5, gg-6
+    unsigned so;                  // element offset of the row the next store goes to
+};
+
+// one row step.  STAGE: 0 F only; 1 + Gb(F); 2 + D; 3 + Gb(D); 4 + lap(D) and the store
+template <int STAGE, int V, class SRC>
+__device__ __forceinline__ void qs_step(SRC& S, QsPipe& p, int gg, const QsW& W, const double* tab, double dt, qs_rsrc out, bool& bad) {
+    const QsCoef k0 = qs_coef(tab, STAGE >= 1 ? gg - 2 : 0, W.n), k2 = qs_coef(tab, STAGE >= 3 ? gg - 4 : 0, W.n);
+    const double x = qs_nn<V>(S.get(gg, bad));                           // _hyperdiffuse starts from nan_to_num(F)
+    double gb = 0.0, dn = 0.0, gb2 = 0.0;
+    if (STAGE >= 1) {
+        gb = k0.a * (x - p.f2);                                          // Gb(gg-2) = A[gg-1] (F[gg] - F[gg-2])
+        if (STAGE >= 2) dn = qs_nn<V>(k0.p * (gb - p.gf2) + k0.q * qs_d2<V>(p.f2));             // D[gg-2]
+    }
+    if (STAGE >= 3) {
+        gb2 = k2.a * (dn - p.d2);                                        // Gb2(gg-4) = A[gg-3] (D[gg-2] - D[gg-4])
+        if (STAGE >= 4) {
+            const double L2 = k2.p * (gb2 - p.gd2) + k2.q * qs_d2<V>(p.d2);
+            double val = p.f4 - (k2.k * L2) * dt;
+            if (V == QS_EXACT) val = qd_nnf(val); else bad |= qd_nonfinite(val);
+            qs_st(out, p.so, W.vs, val);                                 // halo lanes: offset out of range, dropped by the hardware
+            p.so += W.nlon;
+        }
+    }
+    p.f4 = p.f3; p.f3 = p.f2; p.f2 = p.f1; p.f1 = x;
+    if (STAGE >= 1) { p.gf2 = p.gf1; p.gf1 = gb; }
+    if (STAGE >= 2) { p.d2 = p.d1; p.d1 = dn; }
+    if (STAGE >= 3) { p.gd2 = p.gd1; p.gd1 = gb2; }
+}
+
+template <int V, class SRC>
+__device__ __forceinline__ bool qs_del4_stream(SRC& S, const QdGeom& G, const QsW& W, const double* poleA,
+                                               const QsRec QD_CONST* fp, double dt) {
+    const int n = W.n, o0 = W.o0, o1 = W.o1;
+    bool bad = false;
+    const qs_rsrc out = qs_make_rsrc(fp->out, W.slab_bytes);
+    if (fp->skip) {                                          // k4 <= 0 early-out of _hyperdiffuse: the field passes through
+        unsigned so = qs_off(G, o0);
+        S.start(o0, bad);
+        for (int g = o0; g < o1; ++g) {
+            const double x = (g == 0 || g == n - 1) ? S.get_edge(g, bad) : S.get(g, bad);
+            qs_st(out, so, W.vs, x); so += W.nlon;
+        }
+        return bad;
+    }
+    const double* __restrict__ tab = fp->tab;
+    const bool top = o0 == 0, bot = o1 == n;
+    QsPipe p{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, qs_off(G, o0)};
+    if (!top) {
+        // rows o0-4 .. o0+3: four rows of F, then two with Gb, two with D, two with Gb(D)
+        S.start(o0 - 4, bad);
+        qs_step<0, V>(S, p, o0 - 4, W, tab, dt, out, bad);
+        qs_step<0, V>(S, p, o0 - 3, W, tab, dt, out, bad);
+        qs_step<1, V>(S, p, o0 - 2, W, tab, dt, out, bad);
+        qs_step<1, V>(S, p, o0 - 1, W, tab, dt, out, bad);
+        qs_step<2, V>(S, p, o0, W, tab, dt, out, bad);
+        qs_step<2, V>(S, p, o0 + 1, W, tab, dt, out, bad);
+        qs_step<3, V>(S, p, o0 + 2, W, tab, dt, out, bad);
+        qs_step<3, V>(S, p, o0 + 3, W, tab, dt, out, bad);
+    } else {
+        // south pole: rows 0 .. 3; the one-sided difference pA0 (X_1 - X_0) stands in for Ga of rows 0 and 1, in both stages
+        const double pA0 = qd_sload(poleA, 0);
+        S.start(0, bad);
+        const double x0 = qs_nn<V>(S.get_edge(0, bad));
+        const double x1 = qs_nn<V>(S.get(1, bad));
+        p.f2 = x0; p.f1 = x1;
+        p.gf1 = pA0 * (x1 - x0); p.gf2 = p.gf1;
+        qs_step<2, V>(S, p, 2, W, tab, dt, out, bad);       // D[0]
+        const double dd0 = p.d1;
+        qs_step<2, V>(S, p, 3, W, tab, dt, out, bad);       // D[1]
+        p.gd1 = pA0 * (p.d1 - dd0); p.gd2 = p.gd1;
+    }
+    const int gEnd = bot ? n - 1 : o1 + 4;                   // north pole: the loop stops before row n-1
+    int g = o0 + 4;
+    for (; g + 4 <= gEnd; g += 4) {                          // 4 = period of the F shift register: the shifts are renames; straight-line body
+        qs_step<4, V>(S, p, g, W, tab, dt, out, bad);
+        qs_step<4, V>(S, p, g + 1, W, tab, dt, out, bad);
+        qs_step<4, V>(S, p, g + 2, W, tab, dt, out, bad);
+        qs_step<4, V>(S, p, g + 3, W, tab, dt, out, bad);
+    }
+    for (; g < gEnd; ++g) qs_step<4, V>(S, p, g, W, tab, dt, out, bad);
+    if (bot) {
+        // north pole: rows n-1 (last row of F) .. n+3; pA5 (X_{n-1} - X_{n-2}) stands in for Gb of rows n-2 and n-1
+        const double pA5 = qd_sload(poleA, 5);
+        {   // gg = n-1
+            const QsCoef k0 = qs_coef(tab, n - 3, n), k2 = qs_coef(tab, n - 5, n);
+            const double x = qs_nn<V>(S.get_edge(n - 1, bad));
+            const double e1 = pA5 * (x - p.f1);
+            const double gb = k0.a * (x - p.f2);
+            const double dn = qs_nn<V>(k0.p * (gb - p.gf2) + k0.q * qs_d2<V>(p.f2));          // D[n-3]
+            const double gb2 = k2.a * (dn - p.d2);
+            const double L2 = k2.p * (gb2 - p.gd2) + k2.q * qs_d2<V>(p.d2);                   // lap(D)[n-5]
+            double val = p.f4 - (k2.k * L2) * dt;
+            if (V == QS_EXACT) val = qd_nnf(val); else bad |= qd_nonfinite(val);
+            qs_st(out, p.so, W.vs, val); p.so += W.nlon;
+            p.f4 = p.f3; p.f3 = p.f2; p.f2 = p.f1; p.f1 = x;
+            p.gf2 = p.gf1; p.gf1 = gb; p.d2 = p.d1; p.d1 = dn; p.gd2 = p.gd1; p.gd1 = gb2;
+            // ---- gg = n, n+1: D[n-2], D[n-1] with Gb = e1
+            double e1d = 0.0;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const QsCoef k0 = qs_coef(tab, n - 2 + t, n), k2 = qs_coef(tab, n - 4 + t, n);
+                const double dq = qs_nn<V>(k0.p * (e1 - p.gf2) + k0.q * qs_d2<V>(p.f2));      // D[n-2+t]
+                if (t == 1) e1d = pA5 * (dq - p.d1);                                          // pA5 (D[n-1] - D[n-2])
+                const double g2 = k2.a * (dq - p.d2);
+                const double M2 = k2.p * (g2 - p.gd2) + k2.q * qs_d2<V>(p.d2);                // lap(D)[n-4+t]
+                double v2 = p.f4 - (k2.k * M2) * dt;
+                if (V == QS_EXACT) v2 = qd_nnf(v2); else bad |= qd_nonfinite(v2);
+                qs_st(out, p.so, W.vs, v2); p.so += W.nlon;
+                p.f4 = p.f3; p.f3 = p.f2; p.f2 = p.f1; p.f1 = 0.0;
+                p.gf2 = p.gf1; p.gf1 = e1; p.d2 = p.d1; p.d1 = dq; p.gd2 = p.gd1; p.gd1 = g2;
+            }
+            // ---- gg = n+2, n+3: lap(D)[n-2], lap(D)[n-1] with Gb(D) = e1d
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const QsCoef k2 = qs_coef(tab, n - 2 + t, n);
+                const double M2 = k2.p * (e1d - p.gd2) + k2.q * qs_d2<V>(p.d2);
+                double v2 = p.f4 - (k2.k * M2) * dt;
+                if (V == QS_EXACT) v2 = qd_nnf(v2); else bad |= qd_nonfinite(v2);
+                qs_st(out, p.so, W.vs, v2); p.so += W.nlon;
+                p.f4 = p.f3; p.f3 = p.f2; p.f2 = p.f1; p.f1 = 0.0;
+                p.d2 = p.d1; p.d1 = 0.0; p.gd2 = p.gd1; p.gd1 = e1d;
+            }
+        }
+    }
+    return bad;
+}
+
+// strip of this workgroup -> wave context.  Strips have R rows; the last one of a row segment also takes the remainder
+// (so that no strip ends within four rows of a pole without holding it).
+__device__ __forceinline__ void qs_strip(const QdGeom& G, int R, int ntc, int nrs, QsW& W) {
+    const unsigned w = qd_xcd_chunk(blockIdx.x, gridDim.x);
+    const int rs = (int)(w / (unsigned)ntc), cs = (int)(w % (unsigned)ntc);
+    W.n = G.nlat; W.nlon = G.nlon;
+    W.lane = threadIdx.x & 63;
+    const int jraw = cs * QS_TC - 3 + W.lane;
+    W.j = jraw < 0 ? jraw + G.nlon : (jraw >= G.nlon ? jraw - G.nlon : jraw);
+    const bool col_ok = W.lane >= 3 && W.lane <= 60 && jraw < G.nlon;
+    W.vo = (unsigned)W.j * 8u; W.vo8 = (unsigned)W.j; W.vs = col_ok ? (unsigned)jraw * 8u : QS_OOB;
+    W.slab_bytes = (unsigned)(G.lrows_ + QD_PAD_ROWS) * (unsigned)G.nlon * 8u;
+    W.west_edge = W.j == 0; W.east_edge = W.j == G.nlon - 1;
+    W.o0 = G.row0 + rs * R;
+    W.o1 = rs == nrs - 1 ? G.row0 + G.nrows : W.o0 + R;
+}
+
+template <bool PRIM, int V>
+__device__ __forceinline__ bool qs_dyn_wave(const QsDynArgs& A, const QsW& W, int wv) {
+    const QsDynArgs QD_CONST* Ak = (const QsDynArgs QD_CONST*)__builtin_amdgcn_kernarg_segment_ptr();
+    const QsRec QD_CONST* fp = &Ak->rec[wv];
+    const unsigned sb = W.slab_bytes;
+    if (wv <= 1) {
+        const qs_rsrc H = qs_make_rsrc(A.h, sb), FR = qs_make_rsrc(A.fric, sb), X = qs_make_rsrc(fp->in, sb), Y = qs_make_rsrc(fp->aux, sb);
+        if ((wv == 0) == PRIM) { QsSrcLon<PRIM, V> S{A, W, H, FR, X, Y}; return qs_del4_stream<V>(S, A.G, W, A.poleA, fp, A.dt); }
+        QsSrcLat<PRIM, V> S{A, W, H, FR, X, Y};
+        return qs_del4_stream<V>(S, A.G, W, A.poleA, fp, A.dt);
+    }
+    QsSrcPlain<V> S{qs_make_rsrc(fp->in, sb), A.G, W};
+    return qs_del4_stream<V>(S, A.G, W, A.poleA, fp, A.dt);
+}
+
+template <int V>
+__device__ __forceinline__ bool qs_ocn_wave(const QsOcnArgs& A, const QsW& W, int wv) {
+    const QsOcnArgs QD_CONST* Ak = (const QsOcnArgs QD_CONST*)__builtin_amdgcn_kernarg_segment_ptr();
+    const QsRec QD_CONST* fp = &Ak->rec[wv];
+    const bool defer = A.eta_mean != nullptr;
+    const double em = defer ? *A.eta_mean : 0.0;
+    const unsigned sb = W.slab_bytes;
+    const qs_rsrc E = qs_make_rsrc(A.eta, sb);
+    if (wv <= 1) {
+        const qs_rsrc U = qs_make_rsrc(A.uo, sb), Vv = qs_make_rsrc(A.vo, sb), T = qs_make_rsrc(fp->aux, sb), L = qs_make_rsrc(A.land, sb / 8u);
+        if (wv == 0) { QsSrcOcnU<V> S{A, W, E, U, Vv, T, L, defer, em}; return qs_del4_stream<V>(S, A.G, W, A.poleA, fp, A.sub_dt); }
+        QsSrcOcnV<V> S{A, W, E, U, Vv, T, L, defer, em};
+        return qs_del4_stream<V>(S, A.G, W, A.poleA, fp, A.sub_dt);
+    }
+    QsSrcEta<V> S{A, W, E, defer, em};
+    return qs_del4_stream<V>(S, A.G, W, A.poleA, fp, A.sub_dt);
+}
+
+// FAST pass; a wave that met a non-finite value repeats its strip with the EXACT arithmetic
+template <bool PRIM>
+__global__ void __launch_bounds__(320)
+k_dyn_stream(QsDynArgs A) {
+    QsW W;
+    qs_strip(A.G, A.R, A.ntc, A.nrs, W);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (!A.exact) {
+        const bool bad = qs_dyn_wave<PRIM, QS_FAST>(A, W, wv);
+        if (__builtin_amdgcn_ballot_w64(bad) == 0ull) return;
+    }
+    qs_dyn_wave<PRIM, QS_EXACT>(A, W, wv);
+}
+
+__global__ void __launch_bounds__(192)
+k_ocn_stream(QsOcnArgs A) {
+    QsW W;
+    qs_strip(A.G, A.R, A.ntc, A.nrs, W);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (!A.exact) {
+        const bool bad = qs_ocn_wave<QS_FAST>(A, W, wv);
+        if (__builtin_amdgcn_ballot_w64(bad) == 0ull) return;
+    }
+    qs_ocn_wave<QS_EXACT>(A, W, wv);
+}
+
+// =========================================================================================
+// host side
+// =========================================================================================
+static int qs_wgs_per_cu(qd_ctx* c, int which) {
+    if (c->qs_wgs_per_cu[which] > 0) return c->qs_wgs_per_cu[which];
+    int nb = 0;
+    hipError_t e = hipSuccess;
+    if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_dyn_stream<false>, 320, 0);
+    else if (which == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_dyn_stream<true>, 320, 0);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_ocn_stream, 192, 0);
+    if (e != hipSuccess || nb < 1) nb = which == 2 ? 6 : 4;
+    c->qs_wgs_per_cu[which] = nb;
+    return nb;
+}
+
+// Strip height (a multiple of 4: the row loop is unrolled by the period of its shift registers): every wave of the launch
+// should be resident at once (one round, no tail), with as many waves per SIMD as the registers allow -- the halo rows a
+// strip recomputes (8) cost less than a second round or an idle SIMD.
+struct QsShape { int R, nrs; };
+static QsShape qs_shape(qd_ctx* c, int nrows, int nlon, int which) {
+    const int ntc = (nlon + QS_TC - 1) / QS_TC;
+    int R = 0;
+    if (const char* e = std::getenv("QD_STREAM_R")) R = std::atoi(e);          // tuning override, read per launch
+    if (R <= 0) R = c->stream_rows;
+    if (R <= 0) {
+        const long slots = 256L * qs_wgs_per_cu(c, which);
+        R = 64;
+        for (int r = 8; r <= 64; r += 4) { if ((long)std::max(1, nrows / r) * ntc <= slots) { R = r; break; } }
+    }
+    R = std::max(R, 5);
+    return QsShape{R, std::max(1, nrows / R)};
+}
+
+static int host_lrow(const QdGeom& G, int g) {
+    int l = g - G.lbase;
+    if (l < 0) l += G.nlat; else if (l >= G.nlat) l -= G.nlat;
+    return l;
+}
+
+// every row segment of the launch must start / end at a pole or at least five rows away from it
+static bool qs_segments_ok(const qd_ctx* c, int margin) {
+    QdSegs S = qd_segments(const_cast<qd_ctx*>(c), margin);
+    for (int k = 0; k < S.n; ++k) {
+        const QdGeom& G = S.g[k];
+        const int s0 = G.row0, s1 = G.row0 + G.nrows;
+        if ((s0 > 0 && s0 < 5) || (s1 < G.nlat && s1 > G.nlat - 5) || G.nrows < 10) return false;
+    }
+    return true;
+}
+
+bool qd_stream_ok(const qd_ctx* c, int margin) {
+    return c->fused_fast >= 1 && c->fused_fast <= 2 && c->geo.nlon >= 64 && c->geo.nlat >= 12 &&
+           (size_t)(c->geo.lrows_ + QD_PAD_ROWS) * (size_t)c->geo.nlon * 8u < 0x7fffffffull &&          // buffer range: 31-bit byte counts
+           qs_segments_ok(c, margin);
+}
+
+// packed row tables {lapA[r+1], lapP[r], lapQ[r], k4[r]} per field; a scalar k4 override (QD_K4_U, ...) fills the column
+static const double* qs_tables(qd_ctx* c, int kind, int nf, const double* const* k4row, const double* k4s, const int* skip) {
+    const int nlat = c->geo.nlat;
+    double key[8] = {1.0, 0, 0, 0, 0, 0, 0, 0};
+    for (int f = 0; f < nf; ++f) key[1 + f] = (k4row[f] || skip[f]) ? 0.0 : k4s[f];
+    bool same = c->qs_tab[kind] != nullptr && c->qs_key[kind][0] == 1.0;
+    for (int f = 0; same && f < nf; ++f) same = c->qs_key[kind][1 + f] == key[1 + f] || (key[1 + f] != key[1 + f] && c->qs_key[kind][1 + f] != c->qs_key[kind][1 + f]);
+    if (same) return c->qs_tab[kind];
+    if (c->h_lapK[kind].size() != (size_t)nlat * 4) return nullptr;
+    std::vector<double> t((size_t)nf * nlat * 4);
+    for (int f = 0; f < nf; ++f)
+        for (int r = 0; r < nlat; ++r) {
+            double* o = &t[((size_t)f * nlat + r) * 4];
+            o[0] = c->h_lapK[kind][4 * r + 1]; o[1] = c->h_lapK[kind][4 * r + 2]; o[2] = c->h_lapK[kind][4 * r + 3];
+            o[3] = k4row[f] ? (c->h_k4[kind].size() == (size_t)nf * nlat ? c->h_k4[kind][(size_t)f * nlat + r] : 0.0) : k4s[f];
+        }
+    if (!c->qs_tab[kind] && hipMalloc(&c->qs_tab[kind], (size_t)5 * nlat * 4 * sizeof(double)) != hipSuccess) return nullptr;
+    if (hipMemcpyAsync(c->qs_tab[kind], t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) return nullptr;
+    hipStreamSynchronize(c->stream);                         // `t` is pageable and about to go away
+    for (int k = 0; k < 8; ++k) c->qs_key[kind][k] = key[k];
+    return c->qs_tab[kind];
+}
+
+int qd_launch_dyn_stream(qd_ctx* c, const QdDynArgs& P, int margin) {
+    QsDynArgs A;
+    A.poleA = c->tabs.lapPoleA[0];
+    A.c8 = P.primitive ? c->tabs.mom_px : c->tabs.mom_cu;
+    A.c9 = P.primitive ? c->tabs.fcor : c->tabs.mom_cv;
+    A.h = P.h; A.fric = P.fric;
+    const double* tab = qs_tables(c, 0, 5, P.k4row, P.k4s, P.skip);
+    if (!tab) return qd_fail(c, "fused kernel: coefficient row tables");
+    const double* in[5] = {P.u, P.v, P.h, P.q, P.cloud};
+    const double* aux[5] = {P.v, P.u, nullptr, nullptr, nullptr};
+    double* out[5] = {P.uo, P.vo, P.ho, P.qo, P.co};
+    for (int f = 0; f < 5; ++f) A.rec[f] = QsRec{in[f], aux[f], out[f], tab + (size_t)f * c->geo.nlat * 4, P.skip[f], 0};
+    A.dt = P.dt; A.inv_dlon = P.inv_dlon; A.inv_2dlon = P.inv_2dlon; A.inv_dlat = P.inv_dlat; A.inv_2dlat = P.inv_2dlat; A.pgf_y = P.pgf_y;
+    A.exact = c->fused_fast == 2;
+    QdScope sc(c, "k_dyn_hyper");
+    QD_ROWS(c, margin, G,
+            const QsShape sh = qs_shape(c, G.nrows, G.nlon, P.primitive ? 1 : 0);
+            A.G = G; A.R = sh.R; A.nrs = sh.nrs; A.ntc = (G.nlon + QS_TC - 1) / QS_TC;
+            if (P.primitive) hipLaunchKernelGGL(k_dyn_stream<true>, dim3(A.nrs * A.ntc), dim3(320), 0, c->stream, A);
+            else hipLaunchKernelGGL(k_dyn_stream<false>, dim3(A.nrs * A.ntc), dim3(320), 0, c->stream, A));
+    return 0;
+}
+
+// a segment that holds a pole row also reads the other pole's eta row (np.roll): it must be on this slab
+bool qd_ocn_stream_ok(const qd_ctx* c, int margin) {
+    if (!qd_stream_ok(c, margin)) return false;
+    if (c->geo.full) return true;
+    QdSegs S = qd_segments(const_cast<qd_ctx*>(c), margin);
+    for (int k = 0; k < S.n; ++k) {
+        const QdGeom& G = S.g[k];
+        const bool pole = G.row0 == 0 || G.row0 + G.nrows == G.nlat;
+        if (pole && !(host_lrow(G, 0) < G.lrows_ && host_lrow(G, G.nlat - 1) < G.lrows_)) return false;
+    }
+    return true;
+}
+
+int qd_launch_ocn_stream(qd_ctx* c, const QdOcnArgs& P, int margin) {
+    QsOcnArgs A;
+    A.poleA = c->tabs.lapPoleA[1];
+    A.fcor = c->tabs.fcor; A.igx = c->tabs.ocn_igx; A.rx = c->tabs.r_extra;
+    A.uo = P.uo; A.vo = P.vo; A.eta = P.eta; A.land = P.land;
+    const double* tab = qs_tables(c, 1, 3, P.k4row, P.k4s, P.skip);
+    if (!tab) return qd_fail(c, "fused kernel: coefficient row tables");
+    const double* in[3] = {P.uo, P.vo, P.eta};
+    const double* aux[3] = {P.taux, P.tauy, nullptr};
+    double* out[3] = {P.uo_out, P.vo_out, P.eta_out};
+    for (int f = 0; f < 3; ++f) A.rec[f] = QsRec{in[f], aux[f], out[f], tab + (size_t)f * c->geo.nlat * 4, P.skip[f], 0};
+    A.eta_mean = P.eta_mean; A.eta_cap = P.eta_cap; A.sub_dt = P.sub_dt; A.g = P.g; A.r_bot = P.r_bot;
+    A.inv_2dlon = P.inv_2dlon; A.inv_2dlat = P.inv_2dlat; A.inv_a = P.inv_a; A.inv_rhoH = P.inv_rhoH;
+    A.exact = c->fused_fast == 2;
+    QdScope sc(c, "k_ocn_hyper");
+    QD_ROWS(c, margin, G,
+            const QsShape sh = qs_shape(c, G.nrows, G.nlon, 2);
+            A.G = G; A.R = sh.R; A.nrs = sh.nrs; A.ntc = (G.nlon + QS_TC - 1) / QS_TC;
+            hipLaunchKernelGGL(k_ocn_stream, dim3(A.nrs * A.ntc), dim3(192), 0, c->stream, A));
+    return 0;
+}

@@ -1,0 +1,41 @@
+// qd_wave.h -- wavefront-level building blocks shared by the fused kernels (qd_fused.hip, qd_stream.hip, qd_ocnstep.hip):
+// scalar-cache loads of per-row tables, DPP lane shifts for the longitude neighbours, nan_to_num in 5 VALU ops,
+// non-finite detection with one v_cmp_class.  gfx950 only.
+#pragma once
+#include "qd_internal.h"
+
+// np.nan_to_num in 5 VALU ops instead of 12: clamp with max/min (which also map NaN to a bound), then
+// send NaN to 0 with one compare + select
+__device__ __forceinline__ double qd_nnf(double x) {
+    const double c = fmin(fmax(x, -DBL_MAX), DBL_MAX);
+    return (x == x) ? c : 0.0;
+}
+
+#define QD_CONST __attribute__((address_space(4)))
+typedef const double __attribute__((address_space(4)))* qd_cptr;
+// wave-uniform table read through the scalar cache (constant address space -> s_load into SGPRs)
+__device__ __forceinline__ double qd_sload(const double* p, int idx) { return ((qd_cptr)(unsigned long long)p)[idx]; }
+__device__ __forceinline__ bool qd_nonfinite(double x) { return __builtin_amdgcn_class(x, 0x207); }   // sNaN|qNaN|-inf|+inf
+
+// value held by lane+1 / lane-1.  bound_ctrl:1 (the lane without a neighbour reads 0) lets the move stand alone: with
+// bound_ctrl:0 the destination must first be initialised with the old value, one extra v_mov per DPP move.  Lanes 0 and
+// 63 are halo columns whose results never reach an owned cell.
+__device__ __forceinline__ double qd_east(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x130, 0xf, 0xf, true);     // wave_shl:1
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x130, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double qd_west(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x138, 0xf, 0xf, true);     // wave_shr:1
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x138, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int qd_clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+// XCD-contiguous dealing of a 1-D grid: workgroups are dealt round-robin over the 8 XCDs (block b and b+8 share an L2),
+// so the linear id is remapped such that every XCD walks one contiguous chunk of work items (rows re-read by vertically
+// adjacent strips then come from the same L2).  Pure performance: any placement gives the same result.
+__device__ __forceinline__ unsigned qd_xcd_chunk(unsigned L, unsigned nb) {
+    const unsigned per = nb >> 3, rem = nb & 7u, x = L & 7u;
+    return x * per + (x < rem ? x : rem) + (L >> 3);
+}
