@@ -573,19 +573,22 @@ static int qs_wgs_per_cu(qd_ctx* c, int which) {
     return nb;
 }
 
-// Strip height (a multiple of 4: the row loop is unrolled by the period of its shift registers): every wave of the launch
-// should be resident at once (one round, no tail), with as many waves per SIMD as the registers allow -- the halo rows a
-// strip recomputes (8) cost less than a second round or an idle SIMD.
+// Strip height.  Measured on MI355X (rocprofv3 kernel trace, 721 x 1440): the launch is fastest with about three waves per
+// SIMD (k_dyn_stream: R = 24 -> 750 workgroups, 24 us; 16 -> 27 us; 32 -> 33 us; k_ocn_stream: R = 16 -> 1125 workgroups,
+// 19.4 us) -- fewer waves leave the memory pipeline idle between a wave's rows, more waves recompute more halo rows (8 per
+// strip) and evict each other's rows from L2.  Larger grids keep the cap and run several rounds.
 struct QsShape { int R, nrs; };
 static QsShape qs_shape(qd_ctx* c, int nrows, int nlon, int which) {
     const int ntc = (nlon + QS_TC - 1) / QS_TC;
     int R = 0;
-    if (const char* e = std::getenv("QD_STREAM_R")) R = std::atoi(e);          // tuning override, read per launch
+    if (const char* e = std::getenv(which == 2 ? "QD_STREAM_R_OCN" : "QD_STREAM_R_DYN")) R = std::atoi(e);    // tuning overrides, read per launch
+    if (R <= 0) if (const char* e = std::getenv("QD_STREAM_R")) R = std::atoi(e);
     if (R <= 0) R = c->stream_rows;
     if (R <= 0) {
-        const long slots = 256L * qs_wgs_per_cu(c, which);
-        R = 64;
-        for (int r = 8; r <= 64; r += 4) { if ((long)std::max(1, nrows / r) * ntc <= slots) { R = r; break; } }
+        const long target = which == 2 ? 1150 : 760;         // workgroups in flight
+        const int rmax = which == 2 ? 24 : 32;
+        R = rmax;
+        for (int r = 12; r <= rmax; r += 4) { if ((long)std::max(1, nrows / r) * ntc <= target) { R = r; break; } }
     }
     R = std::max(R, 5);
     return QsShape{R, std::max(1, nrows / R)};

@@ -16,6 +16,9 @@ def main():
     nlat, nlon = int(os.environ.get("QD_TUNE_NLAT", "721")), int(os.environ.get("QD_TUNE_NLON", "1440"))
     grid, m, oc, forcing, mask, base_albedo, friction = bench.build_case(nlat, nlon, True)
     dev = m._dev
+    if os.environ.get("QD_TUNE_COPYONLY") == "1":           # k4 <= 0: every field passes through (loads + momentum + stores only)
+        dev.params.sigma4 = 0.0; dev.params.sigma4_ocean = 0.0
+        dev.push_params()
     dt = 300.0
     stars = forcing.star_table([i * dt for i in range(400)])
     dev.step_n(stars[:24], dt, with_ocean=True, with_physics=True, pass_albedo=True)
