@@ -242,6 +242,7 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
     { const char* ef = std::getenv("QD_FUSED"); if (ef && ef[0] == '0') c->use_fused = 0; }
     { const char* ef = std::getenv("QD_FUSED_FAST"); if (ef) c->fused_fast = std::atoi(ef); }
     { const char* ef = std::getenv("QD_STREAM_R"); if (ef) c->stream_rows = std::max(1, std::atoi(ef)); }
+    { const char* ef = std::getenv("QD_OCN_TAIL"); if (ef && ef[0] == '0') c->ocn_tail = 0; }
     c->geo = QdGeom{d->n_lat, d->n_lon, d->row0, d->n_rows, d->halo, full ? 1 : 0, d->row0 - d->halo, d->n_rows + 2 * d->halo};
     c->own_row0 = d->row0; c->own_nrows = d->n_rows;
     auto bail = [&](const char* w, hipError_t e) { qd_fail(nullptr, w, e); qd_destroy(c); return -1; };

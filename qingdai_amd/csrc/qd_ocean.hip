@@ -19,6 +19,7 @@
 
 #include "qd_fluxes.h"
 #include "qd_fused.h"
+#include "qd_ocntail.h"
 
 QdColP qd_make_colp(const qd_ctx* c, double dt);   // qd_atmos.hip
 
@@ -718,7 +719,19 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
             qd_shapiro_fields(c, fl, 3, np_, m);
             F[QD_F_UO] = fl[0]; F[QD_F_VO] = fl[1]; F[QD_F_ETA] = fl[2];
         }
-        if (c->use_fused) {
+        if (c->use_fused && !band && defer_eta && G0.nlon >= 64 && c->ocn_tail) {
+            // whole globe, deferred mean: the rest of the sub-step is ONE launch (qd_ocntail.hip) + the mean of its tile sums
+            QdTailArgs A;
+            A.uo = F[QD_F_UO]; A.vo = F[QD_F_VO]; A.Ts = F[QD_F_SST]; A.qnet = F[QD_F_QNET]; A.land = c->land; A.ice = c->icemask;
+            A.eta = F[QD_F_ETA]; A.Ts_out = qd_scratch(c, 1); A.uo_out = qd_scratch(c, 2); A.vo_out = qd_scratch(c, 3); A.partial = c->red_partial;
+            A.a = p.a; A.dlat = c->dlat; A.dlon = c->dlon; A.sub_dt = sub_dt; A.msdtH = -sub_dt * H; A.alpha = p.ocean_adv_alpha;
+            A.K_h = HP.K_h; A.rcH = HP.rcH; A.ice_qfac = HP.ice_qfac; A.cap = p.ocean_max_u;
+            A.use_q = HP.use_q; A.has_ice = HP.has_ice; A.mean4 = p.ocean_outlier == 0 ? 1 : 0;
+            if (qd_launch_ocn_tail(c, Gown, A)) return -1;
+            hipLaunchKernelGGL(k_eta_mean, dim3(1), blk, 0, c->stream, c->red_partial, qd_ocn_tail_tiles(Gown), c->wsum_ocean,
+                               c->dscal + QD_S_ETA_MEAN);
+            qd_swap(c, QD_F_SST, 1); qd_swap(c, QD_F_UO, 2); qd_swap(c, QD_F_VO, 3);
+        } else if (c->use_fused) {
             QdScope sc(c, "ocean_cont_sst");
             const int m = qd_plan(c, {QD_IN(F[QD_F_UO], 1), QD_IN(F[QD_F_VO], 1), QD_IN(F[QD_F_ETA], 0), QD_IN(F[QD_F_SST], Ro)});
             if (m < 0) return -1;

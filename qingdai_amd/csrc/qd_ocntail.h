@@ -1,0 +1,14 @@
+// qd_ocntail.h -- argument block of k_ocn_tail (qd_ocntail.hip): the second half of an ocean sub-step in one launch
+#pragma once
+#include "qd_internal.h"
+
+struct QdTailArgs {
+    const double *uo, *vo, *Ts, *qnet;
+    const uint8_t *land, *ice;
+    double *eta, *Ts_out, *uo_out, *vo_out, *partial;
+    double a, dlat, dlon, sub_dt, msdtH, alpha, K_h, rcH, ice_qfac, cap;
+    int use_q, has_ice, mean4, ntc;
+};
+
+int qd_ocn_tail_tiles(const QdGeom& G);
+int qd_launch_ocn_tail(qd_ctx* c, const QdGeom& G, QdTailArgs& P);

@@ -102,6 +102,23 @@ def test_fused_kernel_paths_agree(gpu, shape, monkeypatch):
         assert e < (1e-7 if k in ("UO", "VO", "ETA") else 1e-9), (k, e)
 
 
+@pytest.mark.parametrize("shape", [(181, 360), (91, 144)])
+def test_ocean_tail_kernel_matches_the_two_launch_form(gpu, shape, monkeypatch):
+    """k_ocn_tail (continuity + SST blend / diffusion / heating + outlier filter of an ocean sub-step in one launch, the advected
+    SST staged in LDS) against k_cont_sstadv + k_sst_outlier_fused (QD_OCN_TAIL=0): same device functions in the same order;
+    only the order of the area-weighted eta sum differs (per 16 x 62 tile instead of per row)."""
+    nlat, nlon = shape
+    over = dict(energy_w=1.0, ocean_cfl=0.05)
+    monkeypatch.setenv("QD_OCN_TAIL", "0")
+    two, _ = _run(1, nlat, nlon, 3, over, True, True)
+    monkeypatch.setenv("QD_OCN_TAIL", "1")
+    one, _ = _run(1, nlat, nlon, 3, over, True, True)
+    errs = {k: relerr(one[k], two[k]) for k in one}
+    print(errs)
+    for k, e in errs.items():
+        assert e < 1e-12, (k, e)
+
+
 def test_nonfinite_values_fall_back_to_the_exact_path(gpu, monkeypatch):
     """The FAST path of the fused kernels omits nan_to_num and instead detects non-finite values (one v_cmp_class per
     owned output / clip input); a workgroup that sees one recomputes its tile on the EXACT path.  Poison interior, pole and
