@@ -135,7 +135,9 @@ class DriverOracle:
         self.indiv_day = None
         self.soil_cap = 50.0
 
-    def step(self, t, dt):
+    def step(self, t, dt, pass_albedo=False, commit=True):
+        """pass_albedo: call time_step(Teq, dt, albedo=albedo) -- the call shape of scripts/benchmark_jax.py:96,132 (BASELINE
+        configs[2]; the reference driver itself never passes it).  commit=False leaves S_snow / W_land untouched (no hydrology block)."""
         from . import column as col
         P, m, g = self.P, self.atm, self.grid
         land = (self.land_mask == 1)
@@ -205,7 +207,10 @@ class DriverOracle:
                                              land_mask=self.land_mask, ice_frac=ice_frac)
         # --- Teq + dynamics (the driver does NOT pass albedo: run_simulation.py:2194)
         Teq = self.forcing.equilibrium_temp(t, albedo)
-        m.time_step(Teq, dt)
+        if pass_albedo:
+            m.time_step(Teq, dt, albedo=albedo)
+        else:
+            m.time_step(Teq, dt)
         # --- ocean coupling (run_simulation.py:2197-2253)
         if self.ocean is not None:
             ice_mask = m.h_ice > 0.0
@@ -221,6 +226,10 @@ class DriverOracle:
             Q_net = SW_sfc - LW_sfc - SH - m.LH_last
             self.ocean.step(dt, m.u, m.v, Q_net=Q_net, ice_mask=ice_mask)
             m.T_s = np.where((self.land_mask == 0) & (~ice_mask), self.ocean.Ts, m.T_s)
+        self.C_snow, self.precip, self.albedo = C_snow, precip, albedo
+        self.glacier = glacier
+        if not commit:
+            return
         # --- hydrology commit (run_simulation.py:2290-2339)
         E_land = m.E_flux_last * land
         self.S_snow = S_next

@@ -116,7 +116,7 @@ static int build_tables(qd_ctx* c) {
             c->tabs.lapK[k] = dev_table(c, K4);
             c->h_lapK[k] = K4;
         }
-        std::vector<double> cu(nlat), cv(nlat), px(nlat), igx(nlat);
+        std::vector<double> cu(nlat), cv(nlat), px(nlat), igx(nlat), ia6(nlat);
         for (int i = 0; i < nlat; ++i) {
             const double f = fc[i];
             const double sgn = f >= 0.0 ? 1.0 : -1.0;
@@ -125,9 +125,11 @@ static int build_tables(qd_ctx* c) {
             cv[i] = p.g / (f_safe * a);
             px[i] = -(p.g / (a * c6[i]));
             igx[i] = 1.0 / (a * c05[i]);
+            ia6[i] = 1 / (a * c6[i]);
         }
         c->tabs.mom_cu = dev_table(c, cu); c->tabs.mom_cv = dev_table(c, cv); c->tabs.mom_px = dev_table(c, px);
         c->tabs.ocn_igx = dev_table(c, igx);
+        c->tabs.inv_acos6 = dev_table(c, ia6);
     }
     std::vector<double> lr(nlon), sl(nlon), cl(nlon);
     for (int j = 0; j < nlon; ++j) { lr[j] = lon[j] * d2r; sl[j] = std::sin(lr[j]); cl[j] = std::cos(lr[j]); }

@@ -58,6 +58,7 @@ struct QdTabs {
     const double* mom_cv;    //   g / (f_safe a)         geostrophic v_g coefficient
     const double* mom_px;    // -(g / (a cos6))          primitive PGF_x coefficient
     const double* ocn_igx;   // 1 / (a cos05)
+    const double* inv_acos6; // 1 / (a cos6)   (the `pre` factor of grid.py:41-88 divergence / vorticity)
     const double* lat_deg;   // np.linspace(-90, 90, n_lat)
     const double* lon_rad;   // deg2rad(lon) [n_lon]
     const double* sin_lon;   // [n_lon]

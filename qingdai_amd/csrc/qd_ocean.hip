@@ -727,6 +727,8 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
             A.a = p.a; A.dlat = c->dlat; A.dlon = c->dlon; A.sub_dt = sub_dt; A.msdtH = -sub_dt * H; A.alpha = p.ocean_adv_alpha;
             A.K_h = HP.K_h; A.rcH = HP.rcH; A.ice_qfac = HP.ice_qfac; A.cap = p.ocean_max_u;
             A.use_q = HP.use_q; A.has_ice = HP.has_ice; A.mean4 = p.ocean_outlier == 0 ? 1 : 0;
+            A.r_a = 1.0 / p.a; A.r_dlon = 1.0 / c->dlon; A.r_dlat = 1.0 / c->dlat; A.r_2dlon = 1.0 / (2 * c->dlon); A.r_2dlat = 1.0 / (2 * c->dlat);
+            A.r_rcH = 1.0 / HP.rcH;
             if (qd_launch_ocn_tail(c, Gown, A)) return -1;
             hipLaunchKernelGGL(k_eta_mean, dim3(1), blk, 0, c->stream, c->red_partial, qd_ocn_tail_tiles(Gown), c->wsum_ocean,
                                c->dscal + QD_S_ETA_MEAN);

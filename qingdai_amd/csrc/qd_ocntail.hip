@@ -19,6 +19,57 @@
 #define QT_TC 62                  // owned columns per tile (lanes 1..62)
 #define QT_RA (QT_TR + 4)
 
+// x / c for a divisor whose correctly rounded reciprocal rc = RN(1/c) is known (host-computed constants and row tables): one
+// multiplication and two fused corrections instead of the ~25-instruction f64 division sequence.  q0 = RN(x rc) is a faithful
+// quotient, e = x - c q0 is exact in one fma, and RN(q0 + e rc) is the correctly rounded quotient (Markstein's theorem; it can
+// miss by one ulp only in rare boundary cases, well inside the stated tolerances, and never for 0, inf or NaN operands
+// differently from a division: those propagate through the same products).
+__device__ __forceinline__ double qt_div(double x, double c, double rc) {
+    const double q0 = x * rc;
+    const double e = __builtin_fma(-c, q0, x);
+    const double q1 = __builtin_fma(e, rc, q0);
+    return (q0 - q0 == 0.0) ? q1 : q0;                      // non-finite quotient: the correction would turn inf into NaN
+}
+
+// qd_departure (qd_device.h) with the four divisions by row / grid constants taken through qt_div
+__device__ __forceinline__ QdBilin qt_departure(const QdGeom& G, int gi, int j, double u, double v, double dt,
+                                                double acos, double r_acos, const QdTailArgs& P) {
+    const double dl = qt_div(u * dt, acos, r_acos);
+    const double dp = qt_div(v * dt, P.a, P.r_a);
+    const double dx = qt_div(dl, P.dlon, P.r_dlon);
+    const double dy = qt_div(dp, P.dlat, P.r_dlat);
+    double r = qd_fold((double)gi - dy, G.nlat);
+    double cc = qd_fold((double)j - dx, G.nlon);
+    const bool nan_coord = (dx != dx) || (dy != dy);
+    r = fmin(fmax(r, 0.0), (double)(G.nlat - 1));
+    cc = fmin(fmax(cc, 0.0), (double)(G.nlon - 1));
+    const double r0f = floor(r), c0f = floor(cc);
+    QdBilin b;
+    const int r0 = (int)r0f, c0 = (int)c0f;
+    const int r1 = r0 + 1 < G.nlat ? r0 + 1 : G.nlat - 1;
+    b.c0 = c0; b.c1 = c0 + 1 < G.nlon ? c0 + 1 : G.nlon - 1;
+    b.l0 = qd_lrow_far(G, r0); b.l1 = qd_lrow_far(G, r1);
+    const double tr = r - r0f, tc = cc - c0f;
+    b.wr0 = 1.0 - tr; b.wr1 = tr; b.wc0 = 1.0 - tc; b.wc1 = tc;
+    b.nan_coord = nan_coord;
+    return b;
+}
+
+// qd_divvort_point (divergence form) with the same treatment; 1 / (a cos6) is a row table
+__device__ __forceinline__ double qt_div_point(const QdGeom& G, const QdTabs& T, const double* __restrict__ p,
+                                               const double* __restrict__ q, int i, int j, const QdTailArgs& P) {
+    const size_t b = (size_t)qd_lrow(G, i) * G.nlon;
+    const int jp = qd_wrapc(j + 1, G.nlon), jm = qd_wrapc(j - 1, G.nlon);
+    const double dp = qt_div(p[b + jp] - p[b + jm], 2 * P.dlon, P.r_2dlon);
+    double dq = 0.0;
+    if (i != 0 && i != G.nlat - 1) {
+        const double qn = q[(size_t)qd_lrow(G, i + 1) * G.nlon + j] * T.cos_raw[i + 1];
+        const double qs = q[(size_t)qd_lrow(G, i - 1) * G.nlon + j] * T.cos_raw[i - 1];
+        dq = qt_div(qn - qs, 2 * P.dlat, P.r_2dlat);
+    }
+    return T.inv_acos6[i] * (dp + dq);
+}
+
 __device__ __forceinline__ double qt_wave_sum(double x) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
@@ -79,7 +130,7 @@ k_ocn_tail(QdGeom G, QdTabs T, QdTailArgs P) {
         double t1 = 0.0;
         if (i >= 0 && i < n && i < i1 + 2) {
             const size_t o = (size_t)qd_lrow(G, i) * m + j;
-            const QdBilin bl = qd_departure(G, i, j, P.uo[o], P.vo[o], P.sub_dt, P.a, T.cos05[i], P.dlat, P.dlon);
+            const QdBilin bl = qt_departure(G, i, j, P.uo[o], P.vo[o], P.sub_dt, P.a * T.cos05[i], T.ocn_igx[i], P);
             t1 = qd_nn((1.0 - P.alpha) * P.Ts[o] + P.alpha * qd_gather(P.Ts, G, bl));
         }
         sT[p][lane] = t1;
@@ -94,7 +145,7 @@ k_ocn_tail(QdGeom G, QdTabs T, QdTailArgs P) {
         const size_t o = b + j;
         // continuity (ocean.py:365-374): eta += -dt H div, land zero, area-weighted sum
         {
-            const double div = qd_divvort_point(G, T, P.uo, P.vo, i, j, P.a, P.dlat, P.dlon, 0);
+            const double div = qt_div_point(G, T, P.uo, P.vo, i, j, P);
             double e = P.eta[o] + P.msdtH * div;
             const bool island = P.land[o] == 1;
             if (island) e = 0.0;
@@ -106,7 +157,7 @@ k_ocn_tail(QdGeom G, QdTabs T, QdTailArgs P) {
             double Tv = sT[r + 2][lane];
             if (P.K_h > 0.0) Tv = Tv + P.sub_dt * P.K_h * qt_lap(sT, ib, G, T, i, lane, P.dlat, P.dlon, P.a);
             if (P.use_q) {
-                const double heat = P.qnet[o] / P.rcH;
+                const double heat = qt_div(P.qnet[o], P.rcH, P.r_rcH);
                 const bool ocean = P.land[o] == 0;
                 if (P.has_ice) {
                     const bool ic = P.ice[o] != 0;
@@ -119,21 +170,25 @@ k_ocn_tail(QdGeom G, QdTabs T, QdTailArgs P) {
         // outliers + caps (ocean.py:409-434)
         {
             double u = qd_nn(P.uo[o]), v = qd_nn(P.vo[o]);
-            const double speed = sqrt(u * u + v * v);
-            const double cap = P.cap;
-            if (P.mean4) {
-                if (speed > cap) {
-                    const size_t bn = (size_t)qd_lrow(G, i + 1) * m, bs = (size_t)qd_lrow(G, i - 1) * m;
-                    const int je = qd_wrapc(j + 1, m), jw = qd_wrapc(j - 1, m);
-                    u = 0.25 * (qd_nn(P.uo[bn + j]) + qd_nn(P.uo[bs + j]) + qd_nn(P.uo[b + je]) + qd_nn(P.uo[b + jw]));
-                    v = 0.25 * (qd_nn(P.vo[bn + j]) + qd_nn(P.vo[bs + j]) + qd_nn(P.vo[b + je]) + qd_nn(P.vo[b + jw]));
+            const double cap = P.cap, s2 = u * u + v * v;
+            // speed = sqrt(s2) is only compared with the cap: far below it (the usual case) nothing changes and no square root,
+            // neighbour mean or division is needed; the reference arithmetic runs for the lanes near or above the cap
+            if (!(s2 < 0.81 * (cap * cap))) {
+                const double speed = sqrt(s2);
+                if (P.mean4) {
+                    if (speed > cap) {
+                        const size_t bn = (size_t)qd_lrow(G, i + 1) * m, bs = (size_t)qd_lrow(G, i - 1) * m;
+                        const int je = qd_wrapc(j + 1, m), jw = qd_wrapc(j - 1, m);
+                        u = 0.25 * (qd_nn(P.uo[bn + j]) + qd_nn(P.uo[bs + j]) + qd_nn(P.uo[b + je]) + qd_nn(P.uo[b + jw]));
+                        v = 0.25 * (qd_nn(P.vo[bn + j]) + qd_nn(P.vo[bs + j]) + qd_nn(P.vo[b + je]) + qd_nn(P.vo[b + jw]));
+                    }
+                    const double sp2 = sqrt(u * u + v * v);
+                    const double sc2 = (sp2 > cap) ? cap / (sp2 + 1e-12) : 1.0;
+                    u = u * sc2; v = v * sc2;
+                } else {
+                    const double sc = (speed > cap) ? cap / (speed + 1e-12) : 1.0;
+                    u = u * sc; v = v * sc;
                 }
-                const double sp2 = sqrt(u * u + v * v);
-                const double sc2 = (sp2 > cap) ? cap / (sp2 + 1e-12) : 1.0;
-                u = u * sc2; v = v * sc2;
-            } else {
-                const double sc = (speed > cap) ? cap / (speed + 1e-12) : 1.0;
-                u = u * sc; v = v * sc;
             }
             P.uo_out[o] = u; P.vo_out[o] = v;
         }
