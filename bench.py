@@ -58,13 +58,14 @@ def build_case(nlat, nlon, with_ocean, device=0, band=None, rank=0, world=1):
     return grid, m, oc, forcing, mask, base_albedo, friction
 
 
-def cpu_baseline(nlat, nlon, with_ocean, budget_s=20.0):
-    """The oracle (NumPy restatement, proven equal to the reference in the authoring container)
-    timed on this box's host cores with the benchmark_jax.py loop: 1 warm-up step, then as many
-    steps as fit in ~budget_s (at least 2)."""
+def cpu_baseline(nlat, nlon, with_ocean, with_phys=True, budget_s=20.0):
+    """The oracle (NumPy restatement, proven equal to the reference in the authoring container, speed ratio to the real reference
+    in BASELINE.md) timed on this box's host cores on the SAME loop as the GPU leg -- driver physics (precipitation / cloud /
+    albedo diagnostics) -> forcing -> time_step(Teq, dt, albedo) -> ocean coupling: 1 warm-up step, then as many steps as fit in
+    ~budget_s (at least 2)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import qd_oracle as qo
-    from qd_oracle import column as col
+    from qd_oracle.driver import DriverOracle
     from qingdai_amd.topography import create_land_sea_mask, generate_base_properties
     g = qo.Grid(nlat, nlon)
     mask = create_land_sea_mask(g)
@@ -73,24 +74,31 @@ def cpu_baseline(nlat, nlon, with_ocean, budget_s=20.0):
     m = qo.AtmosOracle(g, fric, mask, P, C_s_map=np.where(mask == 1, 3e6, P.Cs_ocean).astype(float))
     oc = qo.OceanOracle(g, mask, P, init_Ts=np.full((nlat, nlon), 288.0)) if with_ocean else None
     f = qo.Forcing(g)
-    albedo = np.where(mask == 0, 0.08, alb)
     dt = 300.0
+    if with_phys:
+        d = DriverOracle(g, m, oc, f, mask, alb, P)
 
-    def one(i):
-        t = i * dt
-        a_, b_ = f.insolation_components(t)
-        m.isr_A, m.isr_B, m.isr = a_, b_, a_ + b_
-        Teq = f.equilibrium_temp(t, albedo)
-        m.time_step(Teq, dt, albedo=albedo)
-        if oc is not None:
-            T_a = 288.0 + (9.81 / 1004.0) * m.h
-            _, SW_sfc, _ = col.shortwave(m.isr, albedo, m.cloud_eff_last, P)
-            ice_frac = 1.0 - np.exp(-np.maximum(m.h_ice, 0.0) / 0.5)
-            _, LW_sfc, _, _, _ = col.longwave_v2(m.T_s, T_a, m.cloud_eff_last, col.surface_emissivity_map(mask, ice_frac, P), P)
-            SH = col.sensible_heat(m.T_s, T_a, m.u, m.v, P)
-            ice = m.h_ice > 0.0
-            oc.step(dt, m.u, m.v, Q_net=SW_sfc - LW_sfc - SH - m.LH_last, ice_mask=ice)
-            m.T_s = np.where((mask == 0) & (~ice), oc.Ts, m.T_s)
+        def one(i):
+            d.step(i * dt, dt, pass_albedo=True, commit=False)
+    else:
+        from qd_oracle import column as col
+        albedo = np.where(mask == 0, 0.08, alb)
+
+        def one(i):
+            t = i * dt
+            a_, b_ = f.insolation_components(t)
+            m.isr_A, m.isr_B, m.isr = a_, b_, a_ + b_
+            Teq = f.equilibrium_temp(t, albedo)
+            m.time_step(Teq, dt, albedo=albedo)
+            if oc is not None:
+                T_a = 288.0 + (9.81 / 1004.0) * m.h
+                _, SW_sfc, _ = col.shortwave(m.isr, albedo, m.cloud_eff_last, P)
+                ice_frac = 1.0 - np.exp(-np.maximum(m.h_ice, 0.0) / 0.5)
+                _, LW_sfc, _, _, _ = col.longwave_v2(m.T_s, T_a, m.cloud_eff_last, col.surface_emissivity_map(mask, ice_frac, P), P)
+                SH = col.sensible_heat(m.T_s, T_a, m.u, m.v, P)
+                ice = m.h_ice > 0.0
+                oc.step(dt, m.u, m.v, Q_net=SW_sfc - LW_sfc - SH - m.LH_last, ice_mask=ice)
+                m.T_s = np.where((mask == 0) & (~ice), oc.Ts, m.T_s)
     one(0)
     t0 = time.perf_counter()
     n = 0
@@ -102,8 +110,10 @@ def cpu_baseline(nlat, nlon, with_ocean, budget_s=20.0):
             break
     per = el / n
     return {"value": dt / per / PLANET_DAY_S, "unit": "planet-days/s", "cores": 1, "kind": "port",
-            "sample": f"{n} steps of the same {nlat}x{nlon} workload after 1 warm-up ({per * 1e3:.1f} ms/step); "
-                      f"NumPy is single-threaded, {os.cpu_count()} host cores available"}
+            "sample": f"{n} steps of the same {nlat}x{nlon} loop as the GPU leg (driver physics {'on' if with_phys else 'off'}, "
+                      f"ocean {'on' if with_ocean else 'off'}) from a cold start after 1 warm-up ({per * 1e3:.1f} ms/step; the cold ocean "
+                      f"runs {oc.last_n_sub if oc is not None else 0} sub-steps per step against the spun-up GPU leg's ocean_n_sub, so the "
+                      f"ratio is a lower bound); NumPy is single-threaded, {os.cpu_count()} host cores available"}
 
 
 def ecology_leg(dev, grid, mask, forcing, dt, W, K):
@@ -273,19 +283,23 @@ def main():
             out["roofline"]["measured_copy_ceiling_gbs"] = dev.copy_ceiling()
         except Exception:
             pass
-    # HBM-side traffic per launch: PMC counters cannot be collected from inside this process; the committed summary of
-    # the separate rocprofv3 --pmc passes of this same command (profiles/, corrected as MI355X_MICROARCH.md prescribes)
-    # is reported when it covers this kernel and grid, else null
+    # What cannot be measured from inside this process comes from the committed rocprofv3 summaries of this same command
+    # (profiles/, one pass per counter as MI355X_MICROARCH.md prescribes), when they cover this kernel and grid -- else null:
+    #   traffic                 FETCH_SIZE (x2: gfx950 correction) + WRITE_SIZE per launch, bytes
+    #   avg_kernel_ms_rocprof   the kernel-trace duration (the HIP-event pair above also brackets the ~3 us dispatch gap)
     try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_final_pmc_traffic.json")) as fh:
-            pmc = json.load(fh)["kernels"]
-        if args.gpus == 1 and (args.nlat, args.nlon) == (721, 1440):
-            for key, val in pmc.items():
-                if args.profile_kernel in key:
-                    out["roofline"]["traffic"] = val["traffic_bytes"]
-                    out["roofline"]["traffic_source"] = "profiles/r01_final_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
-                if also and also in key and "roofline_ocean_substep" in out:
-                    out["roofline_ocean_substep"]["traffic"] = val["traffic_bytes"]
+        prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_fused_kernels.json")
+        with open(prof) as fh:
+            pj = json.load(fh)
+        if args.gpus == 1 and [args.nlat, args.nlon] == pj.get("grid"):
+            for kname, key in ((args.profile_kernel, "roofline"), (also, "roofline_ocean_substep")):
+                if kname and key in out and kname in pj["kernels"]:
+                    e = pj["kernels"][kname]
+                    out[key]["traffic"] = e.get("traffic_bytes")
+                    out[key]["avg_kernel_ms_rocprof"] = e.get("avg_kernel_ms_rocprof")
+                    if e.get("avg_kernel_ms_rocprof"):
+                        out[key]["frac_rocprof"] = (out[key]["bytes_per_cell"] * cells / 1e9) / (e["avg_kernel_ms_rocprof"] / 1e3) / HBM_PEAK_GBS
+                    out[key]["profile_source"] = "profiles/r02_fused_kernels.json (" + pj.get("source", "") + ")"
     except Exception:
         pass
     # supplementary, outside the timed region: the same grid with the driver's full iteration (+ hydrology commit) and the
@@ -296,7 +310,7 @@ def main():
         except Exception as e:       # noqa: BLE001  (never lose the main line to the supplementary leg)
             out["ecology_config5"] = {"error": str(e)}
     if not args.no_cpu_baseline and rank == 0 and args.gpus == 1:
-        out["cpu_baseline"] = cpu_baseline(args.nlat, args.nlon, with_ocean, args.cpu_budget)
+        out["cpu_baseline"] = cpu_baseline(args.nlat, args.nlon, with_ocean, with_phys, args.cpu_budget)
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(out))

@@ -244,7 +244,7 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
     { const char* ef = std::getenv("QD_FUSED"); if (ef && ef[0] == '0') c->use_fused = 0; }
     { const char* ef = std::getenv("QD_FUSED_FAST"); if (ef) c->fused_fast = std::atoi(ef); }
     { const char* ef = std::getenv("QD_STREAM_R"); if (ef) c->stream_rows = std::max(1, std::atoi(ef)); }
-    { const char* ef = std::getenv("QD_OCN_TAIL"); if (ef && ef[0] == '0') c->ocn_tail = 0; }
+    { const char* ef = std::getenv("QD_OCN_TAIL"); if (ef) c->ocn_tail = std::atoi(ef); }   // 0: two launches (k_cont_sstadv, k_sst_outlier_fused) instead of k_ocn_tail
     c->geo = QdGeom{d->n_lat, d->n_lon, d->row0, d->n_rows, d->halo, full ? 1 : 0, d->row0 - d->halo, d->n_rows + 2 * d->halo};
     c->own_row0 = d->row0; c->own_nrows = d->n_rows;
     auto bail = [&](const char* w, hipError_t e) { qd_fail(nullptr, w, e); qd_destroy(c); return -1; };
@@ -271,11 +271,11 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
     c->red_blocks = (12 + (d->n_lon + QD_BLOCK - 1) / QD_BLOCK) * c->geo.lrows() + 64;   // >= 10 x rows: qd_energy_diagnostics
     if ((e = hipMalloc(&c->red_partial, (size_t)c->red_blocks * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc(&c->dscal, QD_S_COUNT * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
-    if ((e = hipMalloc(&c->dcount, 8 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc(&c->dcount, 32 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc(&c->hist, 2 * QD_HIST_BINS * sizeof(unsigned int))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc(&c->sel_state, 8 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
     hipMemsetAsync(c->dscal, 0, QD_S_COUNT * sizeof(double), c->stream);
-    hipMemsetAsync(c->dcount, 0, 8 * sizeof(unsigned long long), c->stream);
+    hipMemsetAsync(c->dcount, 0, 32 * sizeof(unsigned long long), c->stream);
     hipMemsetAsync(c->hist, 0, 2 * QD_HIST_BINS * sizeof(unsigned int), c->stream);
     hipMemsetAsync(c->sel_state, 0, 8 * sizeof(unsigned long long), c->stream);
     if (!full) {

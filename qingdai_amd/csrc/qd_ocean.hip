@@ -16,6 +16,7 @@
 #include <chrono>
 #include "qd_internal.h"
 #include "qd_device.h"
+#include "qd_wave.h"
 
 #include "qd_fluxes.h"
 #include "qd_fused.h"
@@ -534,6 +535,12 @@ k_sst_clamp_inject(QdGeom G, double* __restrict__ sst, double tmin, double tmax,
     if (inject && land[o] == 0 && !(has_ice && ice[o] != 0)) Ts_atm[o] = t;
 }
 
+// the mean of k_ocn_tail's tile sums as a launch of its own (QD_OCN_TAIL=2), in the order the tail kernel's last workgroup uses
+__global__ void k_eta_mean_tail(const double* __restrict__ partial, int n, double wsum, double* __restrict__ out) {
+    const double m = qd_partial_mean(partial, n, wsum);
+    if (threadIdx.x == 0) *out = m;
+}
+
 // ------------------------------------------------------------------ host orchestration
 // device scalars after a reduction: raw sums/maxima are all-reduced across latitude bands first
 __global__ void k_eta_mean_post(double* s, double wsum) { if (threadIdx.x == 0 && blockIdx.x == 0) *s = *s / (wsum + 1e-15); }
@@ -668,6 +675,11 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
     struct CoRefresh { qd_ctx* c; ~CoRefresh() { c->corefresh.clear(); } } corefresh_guard{c};
     if (band) c->corefresh = {QD_IN(F[QD_F_UO], 0), QD_IN(F[QD_F_VO], 0), QD_IN(F[QD_F_ETA], 0), QD_IN(F[QD_F_SST], 0), QD_IN(taux, 0),
                               QD_IN(tauy, 0), QD_IN(F[QD_F_QNET], 0), QD_IN8(c->icemask, 0)};
+    // whole globe, deferred mean, >= 64 columns: the rest of a sub-step is one launch (k_ocn_tail) + a one-wave kernel that turns
+    // its per-tile eta sums into the mean.  Measured alternatives, both slower: the tail kernel's last workgroup doing it behind
+    // two-level tickets (+12 us per sub-step: ticket round trips, acquire fence and read-back form a serial chain at the very end
+    // of the launch); every wave of the next momentum kernel adding the ~1100 sums itself (+3.7 us per launch).
+    const bool use_tail = c->use_fused && !band && defer_eta && G0.nlon >= 64 && c->ocn_tail;
     for (int s = 0; s < n_sub; ++s) {
         if (do_diff && c->use_fused && p.ocean_k4_nsub == 1) {
             const int m = qd_plan(c, {QD_IN(F[QD_F_ETA], 5), QD_IN(F[QD_F_UO], 4), QD_IN(F[QD_F_VO], 4), QD_IN(taux, 4),
@@ -719,7 +731,7 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
             qd_shapiro_fields(c, fl, 3, np_, m);
             F[QD_F_UO] = fl[0]; F[QD_F_VO] = fl[1]; F[QD_F_ETA] = fl[2];
         }
-        if (c->use_fused && !band && defer_eta && G0.nlon >= 64 && c->ocn_tail) {
+        if (use_tail) {
             // whole globe, deferred mean: the rest of the sub-step is ONE launch (qd_ocntail.hip) + the mean of its tile sums
             QdTailArgs A;
             A.uo = F[QD_F_UO]; A.vo = F[QD_F_VO]; A.Ts = F[QD_F_SST]; A.qnet = F[QD_F_QNET]; A.land = c->land; A.ice = c->icemask;
@@ -730,8 +742,8 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
             A.r_a = 1.0 / p.a; A.r_dlon = 1.0 / c->dlon; A.r_dlat = 1.0 / c->dlat; A.r_2dlon = 1.0 / (2 * c->dlon); A.r_2dlat = 1.0 / (2 * c->dlat);
             A.r_rcH = 1.0 / HP.rcH;
             if (qd_launch_ocn_tail(c, Gown, A)) return -1;
-            hipLaunchKernelGGL(k_eta_mean, dim3(1), blk, 0, c->stream, c->red_partial, qd_ocn_tail_tiles(Gown), c->wsum_ocean,
-                               c->dscal + QD_S_ETA_MEAN);
+            hipLaunchKernelGGL(k_eta_mean_tail, dim3(1), dim3(64), 0, c->stream, c->red_partial, qd_ocn_tail_tiles(Gown), c->wsum_ocean,
+                                   c->dscal + QD_S_ETA_MEAN);
             qd_swap(c, QD_F_SST, 1); qd_swap(c, QD_F_UO, 2); qd_swap(c, QD_F_VO, 3);
         } else if (c->use_fused) {
             QdScope sc(c, "ocean_cont_sst");

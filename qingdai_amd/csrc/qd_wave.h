@@ -39,3 +39,16 @@ __device__ __forceinline__ unsigned qd_xcd_chunk(unsigned L, unsigned nb) {
     const unsigned per = nb >> 3, rem = nb & 7u, x = L & 7u;
     return x * per + (x < rem ? x : rem) + (L >> 3);
 }
+
+// area-weighted mean of eta from the tile sums of k_ocn_tail: every wave that needs the mean adds the (~1000) partial sums itself,
+// in one fixed order (lane-strided, then a shuffle tree), so all waves of all consumers get the same bits -- cheaper than a
+// launch of its own between two sub-steps for one scalar
+__device__ __forceinline__ double qd_partial_mean(const double* __restrict__ p, int n, double wsum) {
+    const int lane = threadIdx.x & 63;
+    double a = 0.0;
+    for (int k = lane; k < n; k += 64) a += p[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+    a = __shfl(a, 0, 64);
+    return a / (wsum + 1e-15);
+}
