@@ -137,35 +137,114 @@ def d_rank(dev, group):
     return group.devs.index(dev)
 
 
-def init_rccl(dev: Device, rank, world, tag="id", timeout_s=180.0):
-    """Rank 0 creates the ncclUniqueId and publishes it in a file keyed by the launcher's
-    MASTER_PORT / run id; everyone calls ncclCommInitRank through the library."""
-    lib = dev.lib
-    # unique per launch: all ranks of one torchrun share the agent as parent process
-    key = f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}_{world}_{tag}"
-    path = os.path.join("/tmp", f"qd_rdzv_{key}")
-    buf = (ctypes.c_char * 128)()
+def _rendezvous_key(world, tag):
+    """Unique per launch AND per restart of a launch: MASTER_PORT, the elastic run id and restart count when a launcher sets
+    them, the launcher's pid (all ranks of one torchrun share the agent as parent process), the world size."""
+    env = os.environ
+    return "_".join(str(x) for x in (env.get("MASTER_PORT", "0"), env.get("TORCHELASTIC_RUN_ID", "none"),
+                                     env.get("TORCHELASTIC_RESTART_COUNT", "0"), os.getppid(), world, tag))
+
+
+def _write_atomic(path, data):
+    with open(path + f".tmp{os.getpid()}", "wb") as fh:
+        fh.write(data)
+    os.replace(path + f".tmp{os.getpid()}", path)
+
+
+def exchange_unique_id(rank, world, make_id, key, before_publish=None, timeout_s=180.0, root="/tmp"):
+    """File rendezvous that cannot be fooled by what an earlier run left behind under the same key.
+
+    Every rank k > 0 draws a fresh 16-byte nonce and posts it as <path>.req.k (re-posting it whenever the file disappears);
+    rank 0 first deletes every file of the key (stale id, stale requests), then waits for the world-1 requests, then publishes
+    ONE id file = all nonces + the id.  Rank k accepts an id file only if slot k holds ITS nonce -- a file from an earlier run
+    cannot.  `before_publish()` runs on rank 0 after the id exists and before it is published (creates what the other ranks will
+    open next, e.g. the shared-memory ring).  Returns the id bytes; finish_rendezvous() removes the files after a barrier."""
+    import glob
+    path = os.path.join(root, f"qd_rdzv_{key}")
     if rank == 0:
-        if lib.qd_comm_unique_id(buf, 128) != 0:
-            raise _lib.QdError("qd_comm_unique_id failed")
-        with open(path + ".tmp", "wb") as fh:
-            fh.write(bytes(buf))
-        os.replace(path + ".tmp", path)
-    else:
+        for f in glob.glob(path + "*"):
+            try:
+                os.remove(f)
+            except OSError:
+                pass
+        uid = bytes(make_id())
+        nonces = [b"\0" * 16] * world
         t0 = time.time()
-        while not os.path.exists(path):
-            if time.time() - t0 > timeout_s:
-                raise _lib.QdError("RCCL rendezvous timeout")
-            time.sleep(0.01)
-        with open(path, "rb") as fh:
-            data = fh.read()
-        ctypes.memmove(buf, data, min(128, len(data)))
-    if lib.qd_comm_init(dev.h, buf, 128) != 0:
-        raise _lib.QdError("qd_comm_init failed: " + (lib.qd_last_error(dev.h) or b"?").decode())
+        for k in range(1, world):
+            while True:
+                try:
+                    with open(f"{path}.req.{k}", "rb") as fh:
+                        d = fh.read()
+                    if len(d) == 16:
+                        nonces[k] = d
+                        break
+                except OSError:
+                    pass
+                if time.time() - t0 > timeout_s:
+                    raise _lib.QdError(f"rendezvous timeout: rank {k} never posted its request")
+                time.sleep(0.005)
+        if before_publish is not None:
+            before_publish()
+        _write_atomic(path, b"QDRZ" + b"".join(nonces) + uid)
+        return uid
+    nonce = os.urandom(16)
+    req = f"{path}.req.{rank}"
+    t0 = time.time()
+    while True:
+        if not os.path.exists(req):
+            _write_atomic(req, nonce)                      # (re-)post: rank 0 wipes the key's files when it starts
+        try:
+            with open(path, "rb") as fh:
+                d = fh.read()
+            if len(d) > 4 + 16 * world and d[:4] == b"QDRZ" and d[4 + 16 * rank: 20 + 16 * rank] == nonce:
+                return d[4 + 16 * world:]
+        except OSError:
+            pass
+        if time.time() - t0 > timeout_s:
+            raise _lib.QdError("rendezvous timeout: no id file carrying this rank's nonce")
+        time.sleep(0.005)
+
+
+def finish_rendezvous(rank, key, root="/tmp"):
+    """After a barrier that every rank has passed: rank 0 removes the key's files."""
+    import glob
+    if rank == 0:
+        for f in glob.glob(os.path.join(root, f"qd_rdzv_{key}") + "*"):
+            try:
+                os.remove(f)
+            except OSError:
+                pass
+
+
+def init_rccl(dev: Device, rank, world, tag="id", timeout_s=180.0):
+    """One process per GPU: rank 0 creates the ncclUniqueId and hands it to the others through exchange_unique_id(); everyone
+    calls ncclCommInitRank through the library; a barrier; rank 0 removes the rendezvous files."""
+    lib = dev.lib
+    key = _rendezvous_key(world, tag)
     # QD_HOST_RING=1: the ranks of one node also meet in a shared-memory ring for the few host-visible scalars of a step (eta
     # sums, CFL maxima) instead of one RCCL all-reduce each.  Opt-in: on the one-rank self-ring a host round trip per ocean
     # sub-step (~33 us) is slower than a queued one-rank ncclAllReduce (~23 us); it can only win where a real N-rank all-reduce
     # costs more than that, which this pool's 1-GPU boxes cannot tell.
-    if os.environ.get("QD_HOST_RING") == "1":
-        if lib.qd_comm_init_shm(dev.h, f"/qd_ring_{key}".encode()) != 0:
+    ring = os.environ.get("QD_HOST_RING") == "1"
+    ring_name = f"/qd_ring_{key}".encode()
+
+    def make_id():
+        buf = (ctypes.c_char * 128)()
+        if lib.qd_comm_unique_id(buf, 128) != 0:
+            raise _lib.QdError("qd_comm_unique_id failed")
+        return bytes(buf)
+
+    def open_ring():
+        if lib.qd_comm_init_shm(dev.h, ring_name) != 0:
             raise _lib.QdError("qd_comm_init_shm failed: " + (lib.qd_last_error(dev.h) or b"?").decode())
+
+    # rank 0 creates the ring segment (unlinking a stale one) BEFORE the id is published; the others open it after reading the id
+    uid = exchange_unique_id(rank, world, make_id, key, before_publish=open_ring if ring else None, timeout_s=timeout_s)
+    buf = (ctypes.c_char * 128)()
+    ctypes.memmove(buf, uid, min(128, len(uid)))
+    if ring and rank != 0:
+        open_ring()
+    if lib.qd_comm_init(dev.h, buf, 128) != 0:
+        raise _lib.QdError("qd_comm_init failed: " + (lib.qd_last_error(dev.h) or b"?").decode())
+    dev._chk(lib.qd_comm_barrier(dev.h), "qd_comm_barrier")
+    finish_rendezvous(rank, key)

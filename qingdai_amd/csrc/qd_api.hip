@@ -335,7 +335,7 @@ extern "C" int qd_destroy(qd_handle c) {
     if (c->sel_cand) hipFree(c->sel_cand); if (c->sel_ccount) hipFree(c->sel_ccount);
     if (c->med_pred) hipFree(c->med_pred);
     if (c->med_gather) hipFree(c->med_gather);
-    if (c->hring) { qd_hostring_close(c->hring); c->hring = nullptr; }
+    qd_comm_release(c);
     if (c->hpin) hipHostFree(c->hpin);
     if (c->hpin_rows) hipHostFree(c->hpin_rows);
     if (c->stage) hipHostFree(c->stage);

@@ -73,16 +73,36 @@ static int ring_allreduce(QdHostRing* r, double* v, int n, int op, double timeou
 }
 
 // handle-free entry points (tests/test_bands_cpu.py drives them from several processes without a GPU)
+// Rank 0 OWNS the segment: it removes whatever a crashed earlier run left under the name, creates it exclusively and sizes it
+// (new pages read as zero: sequence 0); the other ranks only ever open an existing, fully sized segment and wait for it to
+// appear.  Callers that can reuse a name across runs must not let a non-zero rank in before rank 0 has created the segment of
+// THIS run (qingdai_amd.bands.init_rccl publishes the RCCL id only afterwards).
 extern "C" int qd_hostring_open(const char* name, int rank, int world, void** out) {
     if (!name || !out || world < 1 || world > QD_RING_MAXRANKS || rank < 0 || rank >= world) return -1;
     QdHostRing* r = new QdHostRing();
     r->rank = rank; r->world = world; r->name = name;
-    int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
-    if (fd < 0) { delete r; return -2; }
-    if (ftruncate(fd, sizeof(QdRingSeg)) != 0) { close(fd); delete r; return -3; }     // new pages read as zero: sequence 0
+    int fd = -1;
+    if (rank == 0) {
+        shm_unlink(name);                                    // stale segment of a crashed run: its counters are not zero
+        fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0) { delete r; return -2; }
+        if (ftruncate(fd, sizeof(QdRingSeg)) != 0) { close(fd); shm_unlink(name); delete r; return -3; }
+    } else {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            fd = shm_open(name, O_RDWR, 0600);
+            if (fd >= 0) {
+                struct stat st;
+                if (fstat(fd, &st) == 0 && (size_t)st.st_size >= sizeof(QdRingSeg)) break;
+                close(fd); fd = -1;
+            }
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0) { delete r; return -2; }
+            usleep(2000);
+        }
+    }
     void* m = mmap(nullptr, sizeof(QdRingSeg), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     close(fd);
-    if (m == MAP_FAILED) { delete r; return -4; }
+    if (m == MAP_FAILED) { if (rank == 0) shm_unlink(name); delete r; return -4; }
     r->seg = (QdRingSeg*)m; r->mapped = true; r->owner = (rank == 0);
     *out = r;
     return 0;
@@ -326,7 +346,8 @@ extern "C" int qd_comm_init_local(qd_handle* handles, int n) {
 }
 
 // one process per GPU: the ranks of a node meet in the POSIX shared-memory segment `name` (qingdai_amd.bands.init_rccl picks a
-// name unique to the launch; rank 0 creates it before it publishes the RCCL id, so it exists when the others open it)
+// name unique to the launch; rank 0 calls this -- and thereby creates the segment -- BEFORE it publishes the RCCL id, the
+// other ranks after they have read the id, so nobody can map a segment of an earlier run)
 extern "C" int qd_comm_init_shm(qd_handle c, const char* name) {
     if (!c || !name) return -1;
     if (c->geo.full) return 0;
@@ -337,6 +358,23 @@ extern "C" int qd_comm_init_shm(qd_handle c, const char* name) {
     c->hring = r;
     return 0;
 }
+// called by qd_destroy: communicator, host ring and (by the last peer) the in-process group
+void qd_comm_release(qd_ctx* c) {
+    if (c->comm) { ncclCommDestroy((ncclComm_t)c->comm); c->comm = nullptr; }
+    if (c->hring) {
+        QdHostRing* r = (QdHostRing*)c->hring;
+        if (r->mapped) qd_hostring_close(r); else delete r;          // rings of an in-process group point into the group
+        c->hring = nullptr;
+    }
+    if (c->lgroup) {
+        QdLocalGroup* g = c->lgroup;
+        c->lgroup = nullptr;
+        bool last = true;
+        for (qd_ctx*& p : g->peers) { if (p == c) p = nullptr; else if (p) last = false; }
+        if (last) { pthread_barrier_destroy(&g->bar); delete g; }
+    }
+}
+
 extern "C" int qd_comm_host_allreduce_count(qd_handle c, int* n) { if (!c || !n) return -1; *n = c->host_allreduces; return 0; }
 
 extern "C" int qd_comm_allreduce_max(qd_handle c, double* inout, int n) {

@@ -261,6 +261,7 @@ int qd_allreduce_u32(qd_ctx* c, unsigned int* dptr, int n);            // sum
 int qd_host_allreduce(qd_ctx* c, double* host_vals, int n, int op);    // op 0 sum, 1 max; HOST scalars through the host ring
 bool qd_has_host_ring(const qd_ctx* c);
 extern "C" int qd_hostring_close(void* ring);
+void qd_comm_release(qd_ctx* c);                         // qd_band.hip: ncclCommDestroy, host ring, in-process group
 #define QD_ROWS(c, margin, G, ...) do { QdSegs _sg = qd_segments((c), (margin)); for (int _k = 0; _k < _sg.n; ++_k) { const QdGeom& G = _sg.g[_k]; __VA_ARGS__; } } while (0)
 
 static inline dim3 qd_grid2d(const QdGeom& G, int fields = 1) {

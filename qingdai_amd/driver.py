@@ -50,13 +50,19 @@ def _nc_backend():
     return ncio.backend()
 
 
-def save_restart(path, grid, dev, t_seconds, land_mask):
-    """run_simulation.py:63-124: dims lat/lon, f4 state variables, land_mask u1, scalar t_seconds (f8), format=v1.
-    netCDF4 when importable, else NetCDF-3 through scipy.io (no u1 there: land_mask is i1)."""
+OCEAN_VARS = ("uo", "vo", "eta", "Ts")
+
+
+def save_restart(path, grid, dev, t_seconds, land_mask, with_ocean=True):
+    """run_simulation.py:63-124: dims lat/lon, every state variable AND land_mask as f4 (the reference's `wvar` writes them all
+    through one f4 helper, :86-111), the ocean variables only when an ocean exists (:99-103), scalar t_seconds (f8), format=v1.
+    netCDF4 when importable, else NetCDF-3 through scipy.io."""
     v = {"lat": ("f4", ("lat",), np.asarray(grid.lat, np.float32)), "lon": ("f4", ("lon",), np.asarray(grid.lon, np.float32))}
     for name, fid in RESTART_VARS.items():
+        if name in OCEAN_VARS and not with_ocean:
+            continue
         v[name] = ("f4", ("lat", "lon"), dev.get(fid).astype(np.float32))
-    v["land_mask"] = ("u1", ("lat", "lon"), np.asarray(land_mask, np.uint8))
+    v["land_mask"] = ("f4", ("lat", "lon"), np.asarray(land_mask, np.float32))
     v["t_seconds"] = ("f8", (), float(t_seconds))
     ncio.write_nc(path, {"lat": grid.n_lat, "lon": grid.n_lon}, v,
                   {"title": "Qingdai GCM Restart", "creator": "qingdai_amd", "format": "v1"})
@@ -195,13 +201,24 @@ class Simulation:
         self.t = float(rst.get("t_seconds", 0.0))
 
     def save(self, path):
-        save_restart(path, self.grid, self.dev, self.t, self.land_mask)
+        save_restart(path, self.grid, self.dev, self.t, self.land_mask, with_ocean=self.ocean is not None)
+
+    def load_ocean_override(self, path):
+        """run_simulation.py:1497-1509 / 1542-1553: QD_LOAD_OCEAN=1 (default) lets a standardized data/ocean.nc override the ocean
+        fields after the atmosphere checkpoint was read.  Returns True when something was loaded."""
+        if self.ocean is None or not os.path.exists(path):
+            return False
+        v, _ = ncio.read_nc(path, list(OCEAN_VARS))
+        for name in OCEAN_VARS:
+            if name in v:
+                self.dev.set(RESTART_VARS[name], np.asarray(v[name], dtype=np.float64))
+        return bool(v)
 
     def save_autosave(self, data_dir="data"):
         """run_simulation.py:248-270 + 126-159 + 185-220: data/atmosphere.nc (the restart layout with the epoch
         in t_seconds), data/ocean.nc, data/topography.nc.  Ecology / genes files are outside this path."""
         day = self.t / (2 * np.pi / PLANET_OMEGA)
-        save_restart(os.path.join(data_dir, "atmosphere.nc"), self.grid, self.dev, self.t, self.land_mask)
+        save_restart(os.path.join(data_dir, "atmosphere.nc"), self.grid, self.dev, self.t, self.land_mask, with_ocean=self.ocean is not None)
         if self.ocean is not None:
             save_ocean(os.path.join(data_dir, "ocean.nc"), self.grid, self.dev, day_value=day)
         topo.export_topography_to_netcdf(os.path.join(data_dir, "topography.nc"), self.grid, self.land_mask, self.base_albedo,
@@ -291,6 +308,18 @@ class Simulation:
                 "<E>": d.reduce("EFLUX", R_COSMEAN), "<P>": d.reduce("PRECIP", R_COSMEAN)}
 
 
+def chunk_until(t, dt, next_autosave_t, remaining, max_chunk=200):
+    """Steps to hand to the device loop in one go: at most `max_chunk`, at most `remaining`, and -- when a periodic autosave is
+    pending -- exactly up to the step whose END reaches the threshold (the reference tests `t >= next_autosave_t` at the top of the
+    following step, run_simulation.py:1762), at least one."""
+    n = min(max_chunk, remaining)
+    if next_autosave_t is not None:
+        to_thr = int(np.ceil((next_autosave_t - t) / dt - 1e-9))
+        if to_thr > 0:
+            n = max(1, min(n, to_thr))
+    return n
+
+
 def main(argv=None):
     env = os.environ
     print("--- Initializing Qingdai GCM (MI355X device path) ---")
@@ -306,11 +335,31 @@ def main(argv=None):
         duration = float(env["QD_SIM_DAYS"]) * day
     else:
         duration = 5 * sim.forcing.orbital_system.T_planet
+    # run_simulation.py:1451-1563: QD_RESTART_IN wins; else the autosave checkpoint data/atmosphere.nc when QD_AUTOSAVE_LOAD=1 (the
+    # default); in both cases data/ocean.nc then overrides the ocean fields when QD_LOAD_OCEAN=1 (default).  Load failures fall back
+    # to a fresh start, as in the reference.
+    data_dir = env.get("QD_DATA_DIR", "data")
     restart_in = env.get("QD_RESTART_IN")
+    autosave_nc = os.path.join(data_dir, "atmosphere.nc")
+    loaded = None
     if restart_in and os.path.exists(restart_in):
-        sim.load(restart_in)
-        print(f"[Restart] loaded '{restart_in}' at t={sim.t:.1f} s")
-    elif sim.t == 0.0:
+        loaded = restart_in
+    elif not restart_in and int(env.get("QD_AUTOSAVE_LOAD", "1")) == 1 and os.path.exists(autosave_nc):
+        loaded = autosave_nc
+    if loaded:
+        try:
+            sim.load(loaded)
+            print(f"[{'Restart' if loaded == restart_in else 'Autosave'}] loaded '{loaded}' at t={sim.t:.1f} s")
+            if int(env.get("QD_LOAD_OCEAN", "1")) == 1:
+                try:
+                    if sim.load_ocean_override(os.path.join(data_dir, "ocean.nc")):
+                        print("[Restart] Ocean state overridden from 'data/ocean.nc'.")
+                except Exception as e:     # noqa: BLE001
+                    print(f"[Restart] ocean.nc load skipped: {e}")
+        except Exception as e:             # noqa: BLE001
+            print(f"[Restart] Failed to load '{loaded}': {e}\nContinuing with fresh init.")
+            loaded = None
+    if not loaded and sim.t == 0.0:
         if env.get("QD_ORBIT_EPOCH_SECONDS"):
             sim.t = float(env["QD_ORBIT_EPOCH_SECONDS"])
         elif env.get("QD_ORBIT_EPOCH_DAYS"):
@@ -324,8 +373,14 @@ def main(argv=None):
 
     autosave_on = int(env.get("QD_AUTOSAVE_ENABLE", "1")) == 1
     restart_out = env.get("QD_RESTART_OUT") or os.path.join("data", "restart_autosave.nc")
-    every_h = float(env.get("QD_ECO_AUTOSAVE_EVERY_HOURS", "0") or 0)
-    autosave_steps = int(every_h * 3600 / sim.dt) if every_h > 0 else 0
+    # periodic autosave (run_simulation.py:1751-1764): every QD_ECO_AUTOSAVE_EVERY_HOURS PLANETARY hours (day / 24; default 6),
+    # tracked as a time threshold -- the first step whose time has reached it saves, whatever the chunking of the device loop
+    try:
+        every_h = float(env.get("QD_ECO_AUTOSAVE_EVERY_HOURS", "6"))
+        autosave_dt = every_h * (day / 24.0) if every_h > 0 else None
+    except ValueError:
+        autosave_dt = None
+    next_autosave_t = t0 + autosave_dt if autosave_dt else None
     state = {"saved": False}
 
     def _autosave(reason):
@@ -333,7 +388,7 @@ def main(argv=None):
             return
         try:
             # run_simulation.py:1669-1687: data/atmosphere.nc (+ data/ocean.nc, data/topography.nc); QD_RESTART_OUT on top
-            sim.save_autosave(env.get("QD_DATA_DIR", "data"))
+            sim.save_autosave(data_dir)
             if env.get("QD_RESTART_OUT"):
                 sim.save(restart_out)
             print(f"[Autosave] ({reason}) core state saved to 'data/atmosphere.nc' at t={sim.t:.1f} s")
@@ -348,11 +403,10 @@ def main(argv=None):
     signal.signal(signal.SIGTERM, _on_signal)
     atexit.register(lambda: _autosave("atexit"))
 
-    chunk = max(1, min(200, autosave_steps or 200))
     done = 0
     wall0 = time.perf_counter()
     while done < n_total:
-        n = min(chunk, n_total - done)
+        n = chunk_until(sim.t, sim.dt, next_autosave_t if autosave_on else None, n_total - done)
         sim.run_steps(n)
         done += n
         if int(env.get("QD_DYN_DIAG_PRINT", "1")) == 1:
@@ -360,13 +414,19 @@ def main(argv=None):
             el = time.perf_counter() - wall0
             print(f"t={sim.t / day:8.2f} d | " + " ".join(f"{k}={v:.4g}" for k, v in dg.items()) +
                   f" | {done / max(el, 1e-9):.0f} steps/s")
-        if autosave_steps and done % autosave_steps == 0:
+        if autosave_on and next_autosave_t is not None and sim.t >= next_autosave_t - 1e-9 * sim.dt and done < n_total:
             state["saved"] = False
             _autosave("periodic")
             state["saved"] = False
+            while next_autosave_t <= sim.t + 1e-9 * sim.dt:
+                next_autosave_t += autosave_dt
     if env.get("QD_RESTART_OUT"):
         sim.save(env["QD_RESTART_OUT"])
         print(f"[Restart] wrote {env['QD_RESTART_OUT']}")
+    # the reference leaves the final checkpoint to its atexit handler (run_simulation.py:1669-1706); doing it here gives the
+    # same files to a caller that invokes main() in-process (the handler then finds the state saved)
+    state["saved"] = False
+    _autosave("final")
     print("--- Simulation Finished ---")
     return 0
 

@@ -4,6 +4,7 @@ owns a band + halo, refreshes the halo with a ring send/recv exactly like qd_exc
 the global-operator on the rows it can see and must reproduce the whole-globe result on its band."""
 import os
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -161,3 +162,61 @@ def test_host_ring_allreduce_across_processes():
         p_.join(30)
     assert res == [(r, 0) for r in range(world)]
     assert not os.path.exists("/dev/shm" + name)                    # rank 0 unlinked the segment
+
+
+def _rdzv_worker(rank, world, key, root, q):
+    sys.path.insert(0, ROOT)
+    from qingdai_amd.bands import exchange_unique_id
+    uid = exchange_unique_id(rank, world, lambda: b"FRESH-ID-" + bytes(119), key, timeout_s=60.0, root=root)
+    q.put((rank, bytes(uid[:9])))
+
+
+@pytest.mark.timeout(120)
+def test_rendezvous_ignores_what_an_earlier_run_left_behind(tmp_path):
+    """the RCCL id rendezvous used to accept any existing file under a key that a later launch can reuse.  Now a rank
+    accepts an id file only if it carries the nonce that rank posted for THIS launch: stale id / request files are ignored (and
+    removed by rank 0), whatever order the ranks start in."""
+    import multiprocessing as mp
+    from qingdai_amd.bands import finish_rendezvous
+    world, key, root = 3, "29500_none_0_4242_3_id", str(tmp_path)
+    path = os.path.join(root, f"qd_rdzv_{key}")
+    with open(path, "wb") as fh:                                       # a complete id file of an earlier run
+        fh.write(b"QDRZ" + bytes(16 * world) + b"STALE-ID-" + bytes(119))
+    for k in (1, 2):
+        with open(f"{path}.req.{k}", "wb") as fh:                      # and its request files
+            fh.write(b"s" * 16)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_rdzv_worker, args=(r, world, key, root, q)) for r in (2, 1, 0)]   # rank 0 starts last
+    for p_ in ps:
+        p_.start()
+        time.sleep(0.3)
+    res = sorted(q.get(timeout=90) for _ in ps)
+    for p_ in ps:
+        p_.join(30)
+    assert res == [(r, b"FRESH-ID-") for r in range(world)]
+    finish_rendezvous(0, key, root=root)
+    assert not [f for f in os.listdir(root) if f.startswith("qd_rdzv_")]
+
+
+@pytest.mark.timeout(240)
+def test_host_ring_survives_a_stale_segment():
+    """A crashed run leaves its shared-memory segment behind with non-zero sequence counters; rank 0 of the next run replaces it
+    (unlink + exclusive create) and the others only map the new one: the reductions are right from the first call."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    world, iters = 3, 200
+    name = f"/qd_test_stale_{os.getpid()}"
+    with open("/dev/shm" + name, "wb") as fh:
+        fh.write(b"\xff" * 20000)                                      # garbage counters and values, larger than the real segment
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_ring_worker, args=(r, world, name, iters, q)) for r in range(world)]
+    ps[0].start()                                                      # rank 0 first: the others must find ITS segment
+    time.sleep(1.0)
+    for p_ in ps[1:]:
+        p_.start()
+    res = sorted(q.get(timeout=200) for _ in ps)
+    for p_ in ps:
+        p_.join(30)
+    assert res == [(r, 0) for r in range(world)]
+    assert not os.path.exists("/dev/shm" + name)

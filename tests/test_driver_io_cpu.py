@@ -27,9 +27,46 @@ def test_restart_roundtrip(tmp_path):
     rst = load_restart(path)
     assert rst["t_seconds"] == 12345.5
     assert np.array_equal(rst["land_mask"].astype(np.uint8), mask)
+    assert rst["land_mask"].dtype == np.float32                    # the reference writes the mask through its f4 helper too (:111)
     for name, fid in RESTART_VARS.items():
         assert rst[name].dtype == np.float32                       # the reference stores f4
         assert np.array_equal(rst[name], dev.get(fid).astype(np.float32)), name
+    # no ocean -> no ocean variables in the file (run_simulation.py:99-103)
+    path2 = str(tmp_path / "restart_noocean.nc")
+    save_restart(path2, g, dev, 1.0, mask, with_ocean=False)
+    rst2 = load_restart(path2)
+    assert not any(k in rst2 for k in ("uo", "vo", "eta", "Ts")) and "u" in rst2 and "W_land" in rst2
+
+
+def test_periodic_autosave_fires_on_schedule_whatever_the_chunking():
+    """`done % autosave_steps == 0` with chunks of min(200, autosave_steps) fired every 7200 steps for a 288-step
+    interval.  The loop now runs exactly up to each time threshold (run_simulation.py:1751-1764: QD_ECO_AUTOSAVE_EVERY_HOURS
+    planetary hours, default 6 = a quarter planet-day = 60 steps of 300 s)."""
+    from qingdai_amd.driver import chunk_until
+    dt, day = 300.0, 72000.0
+    for hours in (6.0, 28.8, 0.05):
+        every = hours * day / 24.0
+        t, nxt, done, saves, total = 0.0, every, 0, [], 1500
+        while done < total:
+            n = chunk_until(t, dt, nxt, total - done)
+            assert 1 <= n <= 200
+            t += n * dt
+            done += n
+            if t >= nxt - 1e-9 * dt and done < total:
+                saves.append(done)
+                while nxt <= t + 1e-9 * dt:
+                    nxt += every
+        want = []
+        k = 1
+        while True:                                                    # first step count whose end time reaches k * every
+            s_ = int(np.ceil(k * every / dt - 1e-9))
+            if s_ >= total:
+                break
+            if not want or s_ > want[-1]:
+                want.append(s_)
+            k += 1
+        assert saves == want, (hours, saves[:5], want[:5])
+    assert chunk_until(0.0, dt, None, 1000) == 200                     # no periodic autosave: plain chunks
 
 
 def test_ocean_file_roundtrip(tmp_path):
