@@ -258,6 +258,18 @@ int qd_comm_host_allreduce_count(qd_handle h, int* n);
 int qd_hostring_open(const char* name, int rank, int world, void** ring_out);
 int qd_hostring_allreduce(void* ring, double* vals, int n, int op_max);   /* n <= 8; op_max 0 = sum in rank order, 1 = max */
 int qd_hostring_close(void* ring);
+
+/* Planner simulation (host only, no device is touched): the latitude-band planner of SURVEY.md 8(e) -- validity margins, launch
+ * segments, the decision WHEN to exchange halos and WHICH rows move where -- on a handle that owns no memory.  Exchanges are
+ * logged instead of performed; tests/test_bands_cpu.py performs them with torch.distributed (gloo) on NumPy slabs.
+ * The reference has no counterpart (single process, np.roll on whole arrays: pygcm/ocean.py:306-310, dynamics.py:144-173). */
+int qd_plansim_create(const qd_grid_desc* desc, qd_handle* out);
+int qd_plansim_destroy(qd_handle h);
+int qd_plansim_plan(qd_handle h, const int* fields, const int* radii, int n, int want);      /* -> margin of the outputs */
+int qd_plansim_mark(qd_handle h, const int* fields, int n, int margin);
+int qd_plansim_margin(qd_handle h, int field);
+int qd_plansim_segments(qd_handle h, int margin, int* row0_nrows_pairs);                    /* -> number of segments (<= 3) */
+int qd_plansim_pop_exchange(qd_handle h, int* fields_out, int max_fields, int* geom4);      /* geom4 = {H, owned rows, up, dn} */
 int qd_comm_barrier(qd_handle h);
 int qd_comm_allreduce_max(qd_handle h, double* inout, int n);     /* bench timing: max over ranks */
 

@@ -35,6 +35,8 @@ SYMBOLS = [
     "qd_op_vorticity", "qd_op_gaussian", "qd_op_median_positive", "qd_reduce", "qd_energy_diagnostics", "qd_energy_diagnostics_last", "qd_band_insolation",
     "qd_comm_unique_id", "qd_comm_init", "qd_comm_init_local", "qd_comm_stats", "qd_comm_allreduce_count", "qd_comm_init_shm", "qd_comm_host_allreduce_count", "qd_hostring_open", "qd_hostring_allreduce",
     "qd_hostring_close", "qd_comm_barrier", "qd_comm_allreduce_max",
+    "qd_plansim_create", "qd_plansim_destroy", "qd_plansim_plan", "qd_plansim_mark", "qd_plansim_margin", "qd_plansim_segments",
+    "qd_plansim_pop_exchange",
     "qd_eco_configure", "qd_eco_set_lai_layers", "qd_eco_substep", "qd_eco_banded_alpha", "qd_eco_get_state", "qd_eco_set_state",
     "qd_indiv_configure", "qd_indiv_substep", "qd_indiv_download", "qd_indiv_upload",
     "qd_copy_ceiling", "qd_timing_enable", "qd_timing_select", "qd_timing_get", "qd_timing_reset",
@@ -127,6 +129,14 @@ def load():
     lib.qd_hostring_allreduce.argtypes = [vp, dp, i32, i32]
     lib.qd_hostring_close.argtypes = [vp]
     lib.qd_comm_allreduce_max.argtypes = [vp, dp, i32]
+    ip = ctypes.POINTER(i32)
+    lib.qd_plansim_create.argtypes = [ctypes.POINTER(qd_grid_desc), ctypes.POINTER(vp)]
+    lib.qd_plansim_destroy.argtypes = [vp]
+    lib.qd_plansim_plan.argtypes = [vp, ip, ip, i32, i32]
+    lib.qd_plansim_mark.argtypes = [vp, ip, i32, i32]
+    lib.qd_plansim_margin.argtypes = [vp, i32]
+    lib.qd_plansim_segments.argtypes = [vp, i32, ip]
+    lib.qd_plansim_pop_exchange.argtypes = [vp, ip, i32, ip]
     lib.qd_timing_enable.argtypes = [vp, i32]
     lib.qd_timing_select.argtypes = [vp, ctypes.c_char_p]
     lib.qd_timing_get.argtypes = [vp, ctypes.c_char_p, dp, ctypes.POINTER(i64)]

@@ -119,6 +119,11 @@ extern "C" int qd_hostring_close(void* ring) {
     return 0;
 }
 
+// planner simulation: a band handle WITHOUT a device -- only geometry, validity margins and the exchange log.  qd_plan,
+// qd_mark, qd_segments and the bookkeeping of qd_exchange are pure host code; these hooks let a CPU-only test drive them and
+// perform the recorded exchanges itself (torch.distributed / gloo) on real arrays.
+struct QdPlanSim { std::vector<std::vector<int>> log; };
+
 struct QdLocalGroup {
     std::vector<qd_ctx*> peers;
     pthread_barrier_t bar;
@@ -240,6 +245,13 @@ int qd_exchange(qd_ctx* c, const QdUse* slots, int n) {
         }
         QD_HIP(c, hipStreamSynchronize(c->stream));
         pthread_barrier_wait(&g->bar);
+    } else if (c->plansim) {
+        // planner simulation (no device, no transport): record WHAT would move -- the caller moves it (tests/test_bands_cpu.py)
+        QdPlanSim* ps = (QdPlanSim*)c->plansim;
+        std::vector<int> rec;
+        for (int k = 0; k < n; ++k) rec.push_back((int)((double**)slots[k].slot - c->f));
+        rec.push_back(H); rec.push_back(nown); rec.push_back(up); rec.push_back(dn);
+        ps->log.push_back(rec);
     } else {
         return qd_fail(c, "band handle without a communicator (qd_comm_init / qd_comm_init_local)");
     }
@@ -397,3 +409,70 @@ extern "C" int qd_comm_barrier(qd_handle c) {
 
 extern "C" int qd_comm_stats(qd_handle c, int* exchanges) { if (!c || !exchanges) return -1; *exchanges = c->exchanges; return 0; }
 extern "C" int qd_comm_allreduce_count(qd_handle c, int* allreduces) { if (!c || !allreduces) return -1; *allreduces = c->allreduces; return 0; }
+
+// ---- planner simulation (host only; tests) --------------------------------------------------
+extern "C" int qd_plansim_create(const qd_grid_desc* d, qd_handle* out) {
+    if (!d || !out || d->n_lat < 4 || d->n_lon < 1 || d->n_rows < 1 || d->halo < 0 || d->world < 1) return -1;
+    qd_ctx* c = new qd_ctx();
+    c->desc = *d;
+    const bool full = (d->row0 == 0 && d->n_rows == d->n_lat && d->world == 1);
+    c->geo = QdGeom{d->n_lat, d->n_lon, d->row0, d->n_rows, d->halo, full ? 1 : 0, d->row0 - d->halo, d->n_rows + 2 * d->halo};
+    c->own_row0 = d->row0; c->own_nrows = d->n_rows;
+    c->plansim = new QdPlanSim();
+    for (int f = 0; f < QD_F_COUNT_F64; ++f) c->f[f] = (double*)(uintptr_t)(0x10000u * (unsigned)(f + 1));     // identities, never dereferenced
+    *out = c;
+    return 0;
+}
+extern "C" int qd_plansim_destroy(qd_handle c) {
+    if (!c || !c->plansim) return -1;
+    delete (QdPlanSim*)c->plansim;
+    delete c;
+    return 0;
+}
+// margin the outputs of a launch can be computed on when it reads field[k] with stencil reach radius[k]; exchanges are logged
+extern "C" int qd_plansim_plan(qd_handle c, const int* fields, const int* radii, int n, int want) {
+    if (!c || !c->plansim || !fields || !radii || n < 1 || n > 16) return -1;
+    QdUse u[16];
+    for (int k = 0; k < n; ++k) { if (fields[k] < 0 || fields[k] >= QD_F_COUNT_F64) return -1; u[k] = QdUse{(void**)&c->f[fields[k]], radii[k], 0}; }
+    // qd_plan takes an initializer_list: build the call for the common small counts
+    switch (n) {
+        case 1: return qd_plan(c, {u[0]}, want < 0 ? INT_MAX : want);
+        case 2: return qd_plan(c, {u[0], u[1]}, want < 0 ? INT_MAX : want);
+        case 3: return qd_plan(c, {u[0], u[1], u[2]}, want < 0 ? INT_MAX : want);
+        case 4: return qd_plan(c, {u[0], u[1], u[2], u[3]}, want < 0 ? INT_MAX : want);
+        case 5: return qd_plan(c, {u[0], u[1], u[2], u[3], u[4]}, want < 0 ? INT_MAX : want);
+        case 6: return qd_plan(c, {u[0], u[1], u[2], u[3], u[4], u[5]}, want < 0 ? INT_MAX : want);
+        default: return -1;
+    }
+}
+extern "C" int qd_plansim_mark(qd_handle c, const int* fields, int n, int margin) {
+    if (!c || !c->plansim || !fields) return -1;
+    for (int k = 0; k < n; ++k) { if (fields[k] < 0 || fields[k] >= QD_F_COUNT_F64) return -1; qd_mark(c, {(const void*)c->f[fields[k]]}, margin); }
+    return 0;
+}
+extern "C" int qd_plansim_margin(qd_handle c, int field) {
+    if (!c || !c->plansim || field < 0 || field >= QD_F_COUNT_F64) return -1;
+    return qd_vm_get(c, c->f[field]);
+}
+// launch segments for a margin: out[2k] = first global row, out[2k+1] = row count; returns the number of segments (<= 3)
+extern "C" int qd_plansim_segments(qd_handle c, int margin, int* out) {
+    if (!c || !c->plansim || !out) return -1;
+    const QdSegs S = qd_segments(c, margin);
+    for (int k = 0; k < S.n; ++k) { out[2 * k] = S.g[k].row0; out[2 * k + 1] = S.g[k].nrows; }
+    return S.n;
+}
+// oldest logged exchange: fields_out[0..n) and geom = {halo rows H, owned rows, rank that receives my top rows (up), rank that
+// receives my bottom rows (dn)}.  Slab layout: local rows [0,H) south halo <- dn's top rows [nown, nown+H) (local numbering);
+// [H, H+nown) owned; [H+nown, 2H+nown) north halo <- up's bottom rows [H, 2H).  Returns n, 0 when the log is empty.
+extern "C" int qd_plansim_pop_exchange(qd_handle c, int* fields_out, int max_fields, int* geom4) {
+    if (!c || !c->plansim || !fields_out || !geom4) return -1;
+    QdPlanSim* ps = (QdPlanSim*)c->plansim;
+    if (ps->log.empty()) return 0;
+    const std::vector<int> rec = ps->log.front();
+    ps->log.erase(ps->log.begin());
+    const int n = (int)rec.size() - 4;
+    if (n > max_fields) return -1;
+    for (int k = 0; k < n; ++k) fields_out[k] = rec[k];
+    for (int k = 0; k < 4; ++k) geom4[k] = rec[n + k];
+    return n;
+}

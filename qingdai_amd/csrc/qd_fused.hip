@@ -813,15 +813,18 @@ static void qd_tile_init(qd_ctx* c) {
 
 // one launch per row segment (a whole-globe handle has one; a polar band computing its wrap rows has two)
 template <int TR> static void launch_dyn(qd_ctx* c, const QdDynArgs& P, int margin) {
-    static bool once = false;
-    if (!once) { hipFuncSetAttribute((const void*)k_dyn_hyper<TR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)QdPl<TR>::lds_bytes); once = true; }
+    // the dynamic-LDS cap is a property of the (kernel, DEVICE) pair: one flag per device, not per process
+    static bool once[QD_MAX_DEVICES] = {false};
+    const int dv = c->desc.device >= 0 && c->desc.device < QD_MAX_DEVICES ? c->desc.device : 0;
+    if (!once[dv]) { hipFuncSetAttribute((const void*)k_dyn_hyper<TR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)QdPl<TR>::lds_bytes); once[dv] = c->desc.device == dv; }
     QdDynArgs Q = P;
     QD_ROWS(c, margin, G, Q.ts.ntr = (G.nrows + TR - 1) / TR; hipLaunchKernelGGL(k_dyn_hyper<TR>, dim3(Q.ts.ntr * Q.ts.ntc), dim3(QD_FBLOCK),
                                              QdPl<TR>::lds_bytes, c->stream, G, c->tabs, Q));
 }
 template <int TR> static void launch_ocn(qd_ctx* c, const QdOcnArgs& P, int margin) {
-    static bool once = false;
-    if (!once) { hipFuncSetAttribute((const void*)k_ocn_hyper<TR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)QdPl<TR>::lds_bytes); once = true; }
+    static bool once[QD_MAX_DEVICES] = {false};
+    const int dv = c->desc.device >= 0 && c->desc.device < QD_MAX_DEVICES ? c->desc.device : 0;
+    if (!once[dv]) { hipFuncSetAttribute((const void*)k_ocn_hyper<TR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)QdPl<TR>::lds_bytes); once[dv] = c->desc.device == dv; }
     QdOcnArgs Q = P;
     QD_ROWS(c, margin, G, Q.ts.ntr = (G.nrows + TR - 1) / TR; hipLaunchKernelGGL(k_ocn_hyper<TR>, dim3(Q.ts.ntr * Q.ts.ntc), dim3(QD_FBLOCK),
                                              QdPl<TR>::lds_bytes, c->stream, G, c->tabs, Q));

@@ -21,6 +21,7 @@
 #include "../../include/qingdai_hip.h"
 
 #define QD_NSCRATCH 16
+#define QD_MAX_DEVICES 64     // per-device one-time kernel attributes (hipFuncSetAttribute is per device)
 #define QD_PAD_ROWS 8        // rows of slack behind every slab (see qd_create)
 #define QD_BLOCK 256
 #define QD_MAXF 5            // fields per batched stencil launch
@@ -216,6 +217,7 @@ struct qd_ctx {
     int allreduces = 0;
     double eta_seq = 0.0;          // sequence number of the eta sum the host is waiting for (bands with a host ring)
     void* hring = nullptr;         // host ring (shared-memory scalar all-reduce), see qd_band.hip
+    void* plansim = nullptr;       // planner simulation (qd_plansim_*): a handle without a device, exchanges are logged
     int host_allreduces = 0;
     // timing
     const char* lap_tag = "k_laplacian";       // timing-group names of the two del^4 kernels

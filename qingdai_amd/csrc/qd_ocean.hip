@@ -554,8 +554,12 @@ static int qd_wait_host_flag(qd_ctx* c, volatile double* flag, double seq, const
     const auto t0 = std::chrono::steady_clock::now();
     unsigned spins = 0;
     while (*flag != seq) {
-        if ((++spins & 0xFFFFu) == 0) {
-            if (hipStreamQuery(c->stream) == hipSuccess && *flag != seq) return qd_fail(c, what);
+        __builtin_ia32_pause();
+        if ((++spins & 0x3FFFu) == 0) {
+            // a stream that is no longer "not ready" cannot deliver the flag any more: either it drained without writing it, or a
+            // kernel faulted (sticky error) -- report that error instead of spinning out the timeout
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q != hipErrorNotReady && *flag != seq) return qd_fail(c, what, q);
             if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 60.0) return qd_fail(c, what);
         }
     }

@@ -485,8 +485,9 @@ int qd_zonal_filter_fields(qd_ctx* c, double** fields, int nf, double cutoff, do
     const int nb = kN - kcut + 1;
     const size_t lds = sizeof(double) * (3 * (size_t)n + 2 * (size_t)nb);
     if (lds > 150 * 1024) return qd_fail(c, "zonal filter: row too long for the LDS-staged DFT");
-    static bool once = false;
-    if (!once) { hipFuncSetAttribute((const void*)k_zonal_filter, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); once = true; }
+    static bool once[QD_MAX_DEVICES] = {false};                // per (kernel, device)
+    const int dv = c->desc.device >= 0 && c->desc.device < QD_MAX_DEVICES ? c->desc.device : 0;
+    if (!once[dv]) { hipFuncSetAttribute((const void*)k_zonal_filter, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); once[dv] = c->desc.device == dv; }
     QdFieldList fl{}; fl.n = nf;
     for (int f = 0; f < nf; ++f) { fl.in[f] = fields[f]; fl.out[f] = fields[f]; }
     QD_ROWS(c, m, G, hipLaunchKernelGGL(k_zonal_filter, dim3(1, G.nrows, nf), dim3(QD_BLOCK), lds, c->stream, G, fl, c->zonal_tw,

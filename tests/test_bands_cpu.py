@@ -220,3 +220,125 @@ def test_host_ring_survives_a_stale_segment():
         p_.join(30)
     assert res == [(r, 0) for r in range(world)]
     assert not os.path.exists("/dev/shm" + name)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# The library's OWN planner (qd_plan / qd_mark / qd_segments / the bookkeeping of qd_exchange, qd_band.hip) driven without a
+# GPU: qd_plansim_* handles own no memory and log the halo exchanges they decide on; each gloo rank performs the logged
+# exchanges on NumPy slabs and runs a chain of ring-periodic row stencils on exactly the rows the planner says are valid.
+def _plan_worker(rank, world, port, nlat, nlon, H, q):
+    sys.path.insert(0, ROOT)
+    import ctypes
+    import torch
+    import torch.distributed as dist
+    from qingdai_amd import _lib
+    from qingdai_amd.bands import band_ranges
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib = _lib.load()
+    r0, n = band_ranges(nlat, world)[rank]
+    desc = _lib.qd_grid_desc(nlat, nlon, r0, n, H, 0, rank, world)
+    h = ctypes.c_void_p()
+    assert lib.qd_plansim_create(ctypes.byref(desc), ctypes.byref(h)) == 0
+    I = ctypes.c_int32
+    rng = np.random.default_rng(5)
+    NF = 3
+    truth = [rng.integers(-50, 50, (nlat, nlon)).astype(float) for _ in range(NF)]       # small integers: every sum is exact
+    rows_of_slab = (r0 - H + np.arange(n + 2 * H)) % nlat
+    slabs = []
+    for f in range(NF):
+        s = np.full((n + 2 * H, nlon), np.nan)
+        s[H:H + n] = truth[f][r0:r0 + n]
+        slabs.append(s)
+    n_exch, bad = 0, []
+
+    def do_exchanges():
+        nonlocal n_exch
+        fl, geo = (I * 16)(), (I * 4)()
+        while True:
+            k = lib.qd_plansim_pop_exchange(h, fl, 16, geo)
+            assert k >= 0
+            if k == 0:
+                return
+            n_exch += 1
+            Hh, nown, up, dn = geo[0], geo[1], geo[2], geo[3]
+            assert (Hh, nown, up, dn) == (H, n, (rank + 1) % world, (rank - 1) % world)
+            for f in list(fl)[:k]:
+                s = slabs[f]
+                top = torch.from_numpy(s[nown:nown + Hh].copy()); bot = torch.from_numpy(s[Hh:2 * Hh].copy())
+                south = torch.empty_like(top); north = torch.empty_like(bot)
+                # tag 2f: northward traffic (my top rows -> up's south halo), tag 2f+1: southward -- world 2 has up == dn
+                reqs = [dist.isend(top, up, tag=2 * f), dist.irecv(south, dn, tag=2 * f),
+                        dist.isend(bot, dn, tag=2 * f + 1), dist.irecv(north, up, tag=2 * f + 1)]
+                for rq in reqs:
+                    rq.wait()
+                s[:Hh] = south.numpy(); s[Hh + nown:] = north.numpy()
+
+    # (inputs, radii, output): a chain shaped like a step: reach-4/5 stencils (del^4, momentum), reach-1/2 ones, a wide gather
+    ops = [([0], [4], 1), ([1], [4], 2), ([2, 0], [1, 5], 1), ([1], [2], 0), ([0], [4], 2), ([2], [4], 1), ([1, 2], [H - 2, 1], 0),
+           ([0], [1], 1), ([1], [5], 2), ([2], [4], 0), ([0, 1], [4, 4], 2), ([2], [H, ], 1)]
+    for it, (ins, radii, out) in enumerate(ops):
+        m = lib.qd_plansim_plan(h, (I * len(ins))(*ins), (I * len(ins))(*radii), len(ins), -1)
+        assert m >= 0, (it, m)
+        do_exchanges()
+        for f, r in zip(ins, radii):
+            assert lib.qd_plansim_margin(h, f) >= m + r                     # what the planner promised
+        # launch segments for margin m: together exactly the rows own +- m, none wrapping inside itself
+        seg = (I * 6)()
+        ns = lib.qd_plansim_segments(h, m, seg)
+        cover = np.concatenate([np.arange(seg[2 * k], seg[2 * k] + seg[2 * k + 1]) for k in range(ns)])
+        want_rows = (r0 - m + np.arange(n + 2 * m)) % nlat
+        if not (np.array_equal(cover, want_rows) and all(0 <= seg[2 * k] and seg[2 * k] + seg[2 * k + 1] <= nlat for k in range(ns))):
+            bad.append(("segments", it))
+        # out = sum over inputs of (x[i-r] + 2 x[i] + x[i+r]), rows periodic with period nlat (np.roll(axis=0) semantics)
+        lo, hi = H - m, H + n + m
+        new = np.zeros((hi - lo, nlon))
+        tnew = np.zeros((nlat, nlon))
+        for f, r in zip(ins, radii):
+            s = slabs[f]
+            new += s[lo - r:hi - r] + 2.0 * s[lo:hi] + s[lo + r:hi + r]
+            tnew += np.roll(truth[f], r, 0) + 2.0 * truth[f] + np.roll(truth[f], -r, 0)
+        tnew = np.mod(tnew + 50.0, 101.0) - 50.0                            # keep the integers small
+        new = np.mod(new + 50.0, 101.0) - 50.0
+        if not np.array_equal(new, tnew[rows_of_slab[lo:hi]]):
+            bad.append(("values", it, m))
+        truth[out] = tnew
+        slabs[out][:] = np.nan
+        slabs[out][lo:hi] = new
+        assert lib.qd_plansim_mark(h, (I * 1)(out), 1, m) == 0
+    lib.qd_plansim_destroy(h)
+    q.put((rank, bad, n_exch))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_library_planner_drives_gloo_halo_exchanges(world):
+    """world_size 2 (and 3) over gloo: the planner decides, the test moves the rows the planner's exchange log names, and
+    every stencil result on own +- margin equals the whole-globe one -- margins, segment lists (incl. the pole wrap of the
+    first / last band), ring neighbours and row offsets of qd_exchange are all exercised by real data movement."""
+    import json
+    import subprocess
+    nlat, nlon, H = 61, 8, 9
+    port = 29850 + (os.getpid() % 100) + 7 * world
+    code = (
+        "import sys, json\n"
+        f"sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})\n"
+        "import test_bands_cpu as t\n"
+        "class Q:\n"
+        "    def put(self, x): print('RESULT ' + json.dumps(x), flush=True)\n"
+        f"t._plan_worker(int(sys.argv[1]), {world}, {port}, {nlat}, {nlon}, {H}, Q())\n"
+    )
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(world)]
+    res = []
+    for p in procs:
+        out, err = p.communicate(timeout=250)
+        assert p.returncode == 0, err[-3000:]
+        res.append(json.loads([ln for ln in out.splitlines() if ln.startswith("RESULT ")][-1][len("RESULT "):]))
+    for rank, bad, n_exch in res:
+        assert bad == [], (rank, bad)
+        assert 1 <= n_exch < 12, (rank, n_exch)                              # deep halos: fewer exchanges than launches
+    assert len({r[2] for r in res}) == 1                                     # every rank decided on the same exchanges
