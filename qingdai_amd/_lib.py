@@ -13,7 +13,7 @@ import os
 from .params import qd_params
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libqingdai_hip.so")
+LIB_PATH = os.environ.get("QD_LIB_PATH") or os.path.join(_HERE, "libqingdai_hip.so")     # QD_LIB_PATH: developer A/B builds
 
 # field ids (enum qd_field)
 FIELDS = ["U", "V", "H", "TS", "Q", "CLOUD", "HICE", "ISR", "ISR_A", "ISR_B", "TEQ", "ALBEDO",

@@ -539,6 +539,7 @@ k_dyn_stream(QsDynArgs A) {
     QsW W;
     qs_strip(A.G, A.R, A.ntc, A.nrs, W);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wv <= 1) __builtin_amdgcn_s_setprio(2);             // the momentum waves are the long ones of a strip (measured: -5 % on k_ocn_stream)
     if (!A.exact) {
         const bool bad = qs_dyn_wave<PRIM, QS_FAST>(A, W, wv);
         if (__builtin_amdgcn_ballot_w64(bad) == 0ull) return;
@@ -551,6 +552,7 @@ k_ocn_stream(QsOcnArgs A) {
     QsW W;
     qs_strip(A.G, A.R, A.ntc, A.nrs, W);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wv <= 1) __builtin_amdgcn_s_setprio(2);             // the momentum waves are the long ones of a strip (measured: -5 % on k_ocn_stream)
     if (!A.exact) {
         const bool bad = qs_ocn_wave<QS_FAST>(A, W, wv);
         if (__builtin_amdgcn_ballot_w64(bad) == 0ull) return;
