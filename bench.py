@@ -173,6 +173,9 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--no-ecology-leg", action="store_true",
                     help="skip the supplementary BASELINE configs[4] measurement (16-band ecology sub-step in the loop)")
+    ap.add_argument("--timing-stride", type=int, default=-1,
+                    help="bracket every n-th launch of the profiled kernels with HIP events (default: automatic, see below; "
+                         "1 = every launch, 1000000 = practically none)")
     ap.add_argument("--profile-kernel", default="k_dyn_hyper",
                     help="kernel whose HIP-event time feeds `roofline` (k_dyn_hyper: the fused dynamics + del^4 kernel)")
     args = ap.parse_args()
@@ -228,7 +231,12 @@ def main():
         dev.lib.qd_comm_host_allreduce_count(dev.h, _ct.byref(nh))
         comm0 = (ne.value, na.value, nh.value)
     also = "k_ocn_hyper" if (with_ocean and args.profile_kernel != "k_ocn_hyper") else None
-    dev.timing(select=args.profile_kernel + ("," + also if also else ""))
+    # HIP-event brackets inside the timed region, SAMPLED: an event pair idles the stream for ~5 us per bracket (kernel trace,
+    # profiles/README.md), 14 brackets a step were 7 % of the step.  The per-step kernel is bracketed on ~16 steps of the K, the
+    # per-sub-step kernel on every 16th launch (about one a step).
+    s_main = max(1, K // 16) if args.timing_stride < 0 else max(1, args.timing_stride)
+    s_also = 16 if args.timing_stride < 0 else max(1, args.timing_stride)
+    dev.timing(select=f"{args.profile_kernel}:{s_main}" + (f",{also}:{s_also}" if also else ""))
     t0 = time.perf_counter()
     dev.step_n(stars_k, dt, with_ocean=with_ocean, with_physics=with_phys, pass_albedo=True)
     barrier()

@@ -22,11 +22,17 @@ static hipEvent_t qd_get_event(qd_ctx* c) {
 }
 QdScope::QdScope(qd_ctx* c_, const char* n) : c(c_), name(n) {
     on = c->timing == 1;
-    if (c->timing == 2) {                       // selection: one name or a comma-separated list
+    if (c->timing == 2) {                       // selection: "name[:stride]" or a comma-separated list of them
         const std::string& sel = c->timing_sel;
         const size_t ln = std::strlen(n);
-        for (size_t pos = sel.find(n); pos != std::string::npos && !on; pos = sel.find(n, pos + 1))
-            on = (pos == 0 || sel[pos - 1] == ',') && (pos + ln == sel.size() || sel[pos + ln] == ',');
+        for (size_t pos = sel.find(n); pos != std::string::npos && !on; pos = sel.find(n, pos + 1)) {
+            const size_t e = pos + ln;
+            if (!(pos == 0 || sel[pos - 1] == ',') || !(e == sel.size() || sel[e] == ',' || sel[e] == ':')) continue;
+            // an event pair costs the stream ~5 us of idle time per bracket (measured in the kernel trace): with a stride only
+            // every stride-th launch of the group is bracketed, so the timed loop is barely disturbed by its own measurement
+            const long stride = (e < sel.size() && sel[e] == ':') ? std::max(1L, std::atol(sel.c_str() + e + 1)) : 1L;
+            on = (c->timing_seen[n]++ % stride) == 0;
+        }
     }
     if (on) { e0 = qd_get_event(c); e1 = qd_get_event(c); hipEventRecord(e0, c->stream); }
 }
@@ -244,7 +250,7 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
     { const char* ef = std::getenv("QD_FUSED"); if (ef && ef[0] == '0') c->use_fused = 0; }
     { const char* ef = std::getenv("QD_FUSED_FAST"); if (ef) c->fused_fast = std::atoi(ef); }
     { const char* ef = std::getenv("QD_STREAM_R"); if (ef) c->stream_rows = std::max(1, std::atoi(ef)); }
-    { const char* ef = std::getenv("QD_OCN_TAIL"); if (ef) c->ocn_tail = std::atoi(ef); }   // 0: two launches (k_cont_sstadv, k_sst_outlier_fused) instead of k_ocn_tail
+    { const char* ef = std::getenv("QD_OCN_TAIL"); if (ef) c->ocn_tail = std::atoi(ef); }   // 0: two launches (k_cont_sstadv, k_sst_outlier_fused); 1: k_ocn_tail_stream (default); 2: LDS-tiled k_ocn_tail
     c->geo = QdGeom{d->n_lat, d->n_lon, d->row0, d->n_rows, d->halo, full ? 1 : 0, d->row0 - d->halo, d->n_rows + 2 * d->halo};
     c->own_row0 = d->row0; c->own_nrows = d->n_rows;
     auto bail = [&](const char* w, hipError_t e) { qd_fail(nullptr, w, e); qd_destroy(c); return -1; };
@@ -694,7 +700,7 @@ extern "C" int qd_timing_enable(qd_handle c, int on) { if (!c) return -1; c->tim
 extern "C" int qd_timing_select(qd_handle c, const char* name) {
     if (!c || !name) return -1; c->timing = 2; c->timing_sel = name; return 0;
 }
-extern "C" int qd_timing_reset(qd_handle c) { if (!c) return -1; qd_resolve_timers(c); c->timers.clear(); return 0; }
+extern "C" int qd_timing_reset(qd_handle c) { if (!c) return -1; qd_resolve_timers(c); c->timers.clear(); c->timing_seen.clear(); return 0; }
 extern "C" int qd_timing_get(qd_handle c, const char* name, double* mean_ms, int64_t* launches) {
     if (!c || !name) return -1;
     hipSetDevice(c->desc.device);

@@ -224,6 +224,7 @@ struct qd_ctx {
     const char* hyp_tag = "k_hyper_apply";     // (the ocean switches them to ocean_* around its calls)
     int timing = 0;                 // 0 off, 1 all groups, 2 only `timing_sel`
     std::string timing_sel;
+    std::map<std::string, long> timing_seen;   // launches seen per selected group (stride sampling)
     std::map<std::string, QdTimer> timers;
     struct Pending { hipEvent_t e0, e1; std::string name; };
     std::vector<Pending> pending;   // recorded, not yet resolved (never synchronises inside a step)

@@ -535,10 +535,17 @@ k_sst_clamp_inject(QdGeom G, double* __restrict__ sst, double tmin, double tmax,
     if (inject && land[o] == 0 && !(has_ice && ice[o] != 0)) Ts_atm[o] = t;
 }
 
-// the mean of k_ocn_tail's tile sums as a launch of its own (QD_OCN_TAIL=2), in the order the tail kernel's last workgroup uses
-__global__ void k_eta_mean_tail(const double* __restrict__ partial, int n, double wsum, double* __restrict__ out) {
-    const double m = qd_partial_mean(partial, n, wsum);
-    if (threadIdx.x == 0) *out = m;
+// the mean of the tail kernel's strip / tile sums: one workgroup, fixed order (thread-strided partial sums, shuffle tree per
+// wave, waves 0..3 in order) -- a few thousand values in ~4 us
+__global__ void __launch_bounds__(256) k_eta_mean_tail(const double* __restrict__ partial, int n, double wsum, double* __restrict__ out) {
+    __shared__ double sm[4];
+    double a = 0.0;
+    for (int k = threadIdx.x; k < n; k += 256) a += partial[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = (((sm[0] + sm[1]) + sm[2]) + sm[3]) / (wsum + 1e-15);
 }
 
 // ------------------------------------------------------------------ host orchestration
@@ -746,7 +753,7 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
             A.r_a = 1.0 / p.a; A.r_dlon = 1.0 / c->dlon; A.r_dlat = 1.0 / c->dlat; A.r_2dlon = 1.0 / (2 * c->dlon); A.r_2dlat = 1.0 / (2 * c->dlat);
             A.r_rcH = 1.0 / HP.rcH;
             if (qd_launch_ocn_tail(c, Gown, A)) return -1;
-            hipLaunchKernelGGL(k_eta_mean_tail, dim3(1), dim3(64), 0, c->stream, c->red_partial, qd_ocn_tail_tiles(Gown), c->wsum_ocean,
+            hipLaunchKernelGGL(k_eta_mean_tail, dim3(1), dim3(256), 0, c->stream, c->red_partial, qd_ocn_tail_tiles(c, Gown), c->wsum_ocean,
                                    c->dscal + QD_S_ETA_MEAN);
             qd_swap(c, QD_F_SST, 1); qd_swap(c, QD_F_UO, 2); qd_swap(c, QD_F_VO, 3);
         } else if (c->use_fused) {

@@ -8,8 +8,8 @@ struct QdTailArgs {
     double *eta, *Ts_out, *uo_out, *vo_out, *partial;
     double a, dlat, dlon, sub_dt, msdtH, alpha, K_h, rcH, ice_qfac, cap;
     double r_a, r_dlon, r_dlat, r_2dlon, r_2dlat, r_rcH;     // correctly rounded reciprocals of a, dlon, dlat, 2 dlon, 2 dlat, rcH (host)
-    int use_q, has_ice, mean4, ntc;
+    int use_q, has_ice, mean4, ntc, R, pad_;                 // R: strip height of the streaming form
 };
 
-int qd_ocn_tail_tiles(const QdGeom& G);
+int qd_ocn_tail_tiles(const qd_ctx* c, const QdGeom& G);
 int qd_launch_ocn_tail(qd_ctx* c, const QdGeom& G, QdTailArgs& P);

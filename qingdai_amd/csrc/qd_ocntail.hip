@@ -14,6 +14,9 @@
 #include "qd_device.h"
 #include "qd_wave.h"
 #include "qd_ocntail.h"
+#include <cstdlib>
+#include <cstring>
+#include <algorithm>
 
 #define QT_TR 16                  // owned rows per tile
 #define QT_TC 62                  // owned columns per tile (lanes 1..62)
@@ -200,14 +203,226 @@ k_ocn_tail(QdGeom G, QdTabs T, QdTailArgs P) {
     if (threadIdx.x == 0) P.partial[w] = ((sAcc[0] + sAcc[1]) + sAcc[2]) + sAcc[3];
 }
 
-int qd_ocn_tail_tiles(const QdGeom& G) { return ((G.nrows + QT_TR - 1) / QT_TR) * ((G.nlon + QT_TC - 1) / QT_TC); }
+// =========================================================================================
+// row-streaming form of the same sub-step tail (default): no LDS, no barrier
+// =========================================================================================
+// Two wavefronts per strip of QS_R rows x 62 owned columns (lane l = column 62 cs - 1 + l; lanes 0 and 63 are halo columns),
+// each marching down its rows like the waves of qd_stream.hip:
+//   wave 0 (currents)  continuity + outlier filter: a 3-row register window of uo and vo (row g+1 arrives while row g is worked
+//                      on); east / west neighbours by DPP; stores eta, uo, vo of row g; accumulates the area-weighted eta sum.
+//   wave 1 (SST)       rows o0-2 .. o1+1: the departure point of row g+1 is computed and its four gather loads are issued while
+//                      row g's gathered values are consumed (one row of software pipelining); nan_to_num(T1) lives in a 5-row
+//                      register window; K_h lap(T1) + heating of row g-2 is stored.
+// Same device expressions as k_ocn_tail above (qt_div, qt_departure's arithmetic, the row-table Laplacian): the two forms agree to
+// the rounding of the eta sum.
+#define QS_TC2 62
+
+typedef unsigned int qt_u32x2 __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t qt_rsrc;
+__device__ __forceinline__ qt_rsrc qt_make_rsrc(const void* p, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000); }
+__device__ __forceinline__ double qt_ld(qt_rsrc r, unsigned row_elems, unsigned vo) { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, vo, row_elems * 8u, 0)); }
+__device__ __forceinline__ void qt_st(qt_rsrc r, unsigned row_elems, unsigned vo, double v) { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(qt_u32x2, v), r, vo, row_elems * 8u, 0); }
+__device__ __forceinline__ int qt_ld8(qt_rsrc r, unsigned row_elems, unsigned vo8) { return (int)__builtin_amdgcn_raw_buffer_load_b8(r, vo8, row_elems, 0); }
+
+struct QtW { int n, m, lane, j, o0, o1; unsigned vo, vs, vo8, slab; bool own; };
+
+// element offset of global row g (whole-globe handles: local row = global row), clamped into the domain
+__device__ __forceinline__ unsigned qt_row(const QtW& W, int g) { return (unsigned)qd_clampi(g, 0, W.n - 1) * (unsigned)W.m; }
+__device__ __forceinline__ unsigned qt_row_roll(const QtW& W, int g) { if (g < 0) g += W.n; else if (g >= W.n) g -= W.n; return qt_row(W, g); }
+
+// ---- wave 0: continuity (ocean.py:365-374) + outlier filter and caps (ocean.py:409-434)
+__device__ __forceinline__ double qt_currents_wave(const QdTabs& T, const QdTailArgs& P, const QtW& W) {
+    const unsigned sb = W.slab;
+    const qt_rsrc U = qt_make_rsrc(P.uo, sb), V = qt_make_rsrc(P.vo, sb), E = qt_make_rsrc(P.eta, sb), L = qt_make_rsrc(P.land, sb / 8u);
+    const qt_rsrc UO = qt_make_rsrc(P.uo_out, sb), VO = qt_make_rsrc(P.vo_out, sb);
+    // np.roll rows: mean4 of the outlier filter reads row -1 as row n-1 and row n as row 0
+    double us = qt_ld(U, qt_row_roll(W, W.o0 - 1), W.vo), vs = qt_ld(V, qt_row_roll(W, W.o0 - 1), W.vo);
+    double uc = qt_ld(U, qt_row(W, W.o0), W.vo), vc = qt_ld(V, qt_row(W, W.o0), W.vo);
+    double en = qt_ld(E, qt_row(W, W.o0), W.vo); int ln = qt_ld8(L, qt_row(W, W.o0), W.vo8);
+    double acc = 0.0;
+    for (int g = W.o0; g < W.o1; ++g) {
+        const unsigned rn = qt_row_roll(W, g + 1), r1 = qt_row(W, g + 1);
+        const double un = qt_ld(U, rn, W.vo), vn = qt_ld(V, rn, W.vo);                 // row g+1 (in flight while row g is worked on)
+        const double e0 = en; const int l0 = ln;
+        en = qt_ld(E, r1, W.vo); ln = qt_ld8(L, r1, W.vo8);
+        // divergence (grid.py:41-88 through qt_div_point's expressions)
+        const double dp = qt_div(qd_east(uc) - qd_west(uc), 2 * P.dlon, P.r_2dlon);
+        double dq = 0.0;
+        if (g != 0 && g != W.n - 1) {
+            const double qn = vn * qd_sload(T.cos_raw, g + 1);
+            const double qs = vs * qd_sload(T.cos_raw, g - 1);
+            dq = qt_div(qn - qs, 2 * P.dlat, P.r_2dlat);
+        }
+        const double div = qd_sload(T.inv_acos6, g) * (dp + dq);
+        double e = e0 + P.msdtH * div;
+        const bool island = l0 == 1;
+        if (island) e = 0.0;
+        const unsigned r0 = qt_row(W, g);
+        qt_st(E, r0, W.vs, e);
+        acc += W.own ? e * (island ? 0.0 : qd_sload(T.warea, g)) : 0.0;
+        // outliers + caps
+        double u = qd_nn(uc), v = qd_nn(vc);
+        const double cap = P.cap, s2 = u * u + v * v;
+        if (!(s2 < 0.81 * (cap * cap))) {
+            const double speed = sqrt(s2);
+            if (P.mean4) {
+                if (speed > cap) {
+                    u = 0.25 * (qd_nn(un) + qd_nn(us) + qd_nn(qd_east(uc)) + qd_nn(qd_west(uc)));
+                    v = 0.25 * (qd_nn(vn) + qd_nn(vs) + qd_nn(qd_east(vc)) + qd_nn(qd_west(vc)));
+                }
+                const double sp2 = sqrt(u * u + v * v);
+                const double sc2 = (sp2 > cap) ? cap / (sp2 + 1e-12) : 1.0;
+                u = u * sc2; v = v * sc2;
+            } else {
+                const double sc = (speed > cap) ? cap / (speed + 1e-12) : 1.0;
+                u = u * sc; v = v * sc;
+            }
+        }
+        qt_st(UO, r0, W.vs, u); qt_st(VO, r0, W.vs, v);
+        us = uc; uc = un; vs = vc; vc = vn;
+    }
+    return acc;
+}
+
+// the departure point of (row gi, this lane's column) and the four corner loads of its bilinear gather, issued but not consumed
+struct QtGather { double f00, f01, f10, f11, wr0, wr1, wc0, wc1; bool nan_coord; };
+__device__ __forceinline__ QtGather qt_gather_issue(const QdGeom& G, const QdTabs& T, const QdTailArgs& P, int gi, int j, double u, double v) {
+    const QdBilin b = qt_departure(G, gi, j, u, v, P.sub_dt, P.a * qd_sload(T.cos05, gi), qd_sload(T.ocn_igx, gi), P);
+    const size_t r0 = (size_t)b.l0 * G.nlon, r1 = (size_t)b.l1 * G.nlon;
+    QtGather q;
+    q.f00 = P.Ts[r0 + b.c0]; q.f01 = P.Ts[r0 + b.c1]; q.f10 = P.Ts[r1 + b.c0]; q.f11 = P.Ts[r1 + b.c1];
+    q.wr0 = b.wr0; q.wr1 = b.wr1; q.wc0 = b.wc0; q.wc1 = b.wc1; q.nan_coord = b.nan_coord;
+    return q;
+}
+__device__ __forceinline__ double qt_gather_use(const QtGather& q) {      // qd_gather's corner order (scipy NI_GeometricTransform)
+    double t = 0.0;
+    t += q.f00 * q.wr0 * q.wc0;
+    t += q.f01 * q.wr0 * q.wc1;
+    t += q.f10 * q.wr1 * q.wc0;
+    t += q.f11 * q.wr1 * q.wc1;
+    return q.nan_coord ? 0.0 : t;
+}
+
+// qt_lap on a 5-row register window w[0..4] = nan_to_num(T1) rows i-2 .. i+2 (rows outside the domain hold anything)
+__device__ __forceinline__ double qt_lap_win(const double (&w)[5], const QdTabs& T, int i, int n, double dphi, double dlam, double a) {
+    const double cc = w[2], e = qd_east(cc), wst = qd_west(cc);
+    if (i >= 2 && i <= n - 3) {
+        const double Gb = qd_sload(T.lapA[1], i + 1) * (w[4] - cc);
+        const double Ga = qd_sload(T.lapA[1], i - 1) * (cc - w[0]);
+        const double d2 = (e - 2.0 * cc) + wst;
+        return qd_sload(T.lapP[1], i) * (Gb - Ga) + qd_sload(T.lapQ[1], i) * d2;
+    }
+    // the two rows next to each pole: the literal reference form (ocean.py:100-117); F(r) = w[r - i + 2]
+    const double* __restrict__ cosf = T.cos05;
+    auto dphi_of = [&](int r) -> double {
+        if (r == 0) return (w[1 - i + 2] - w[0 - i + 2]) / dphi;
+        if (r == n - 1) return (w[n - 1 - i + 2] - w[n - 2 - i + 2]) / dphi;
+        return (w[r + 1 - i + 2] - w[r - 1 - i + 2]) / (2.0 * dphi);
+    };
+    int ra, rb; double den;
+    if (i == 0) { ra = 0; rb = 1; den = dphi; }
+    else if (i == n - 1) { ra = n - 2; rb = n - 1; den = dphi; }
+    else { ra = i - 1; rb = i + 1; den = 2.0 * dphi; }
+    const double Ga = qd_sload(cosf, ra) * dphi_of(ra);
+    const double Gb = qd_sload(cosf, rb) * dphi_of(rb);
+    const double ci = qd_sload(cosf, i);
+    const double term_phi = (1.0 / ci) * ((Gb - Ga) / den);
+    const double d2 = ((e - 2.0 * cc) + wst) / (dlam * dlam);
+    const double term_lam = d2 / (ci * ci);
+    return (term_phi + term_lam) / (a * a);
+}
+
+// ---- wave 1: SST blend (ocean.py:380-382), K_h lap + heating (ocean.py:385-406, 440)
+__device__ __forceinline__ void qt_sst_wave(const QdGeom& G, const QdTabs& T, const QdTailArgs& P, const QtW& W) {
+    const unsigned sb = W.slab;
+    const qt_rsrc U = qt_make_rsrc(P.uo, sb), V = qt_make_rsrc(P.vo, sb), S = qt_make_rsrc(P.Ts, sb), Q = qt_make_rsrc(P.qnet, sb);
+    const qt_rsrc L = qt_make_rsrc(P.land, sb / 8u), I = qt_make_rsrc(P.ice, sb / 8u), SO = qt_make_rsrc(P.Ts_out, sb);
+    const int n = W.n;
+    const int t0 = W.o0 - 2 > 0 ? W.o0 - 2 : 0, t1 = W.o1 + 2 < n ? W.o1 + 2 : n;      // rows of T1 this strip needs
+    double w[5] = {0, 0, 0, 0, 0};                                                       // nan_to_num(T1) rows g-4 .. g at step g
+    // pipeline: at step g the gather of row g is consumed and the gather of row g+1 is issued
+    double u1 = qt_ld(U, qt_row(W, t0 + 1), W.vo), v1 = qt_ld(V, qt_row(W, t0 + 1), W.vo);   // currents of row g+1
+    double tc0 = qt_ld(S, qt_row(W, t0), W.vo), tc1 = qt_ld(S, qt_row(W, t0 + 1), W.vo);     // SST at the cell itself, rows g, g+1
+    QtGather cur = qt_gather_issue(G, T, P, t0, W.j, qt_ld(U, qt_row(W, t0), W.vo), qt_ld(V, qt_row(W, t0), W.vo));
+    for (int g = t0; g < t1 + 2; ++g) {                                                  // two drain steps: the window centre lags by 2
+        double t1v = 0.0;
+        if (g < t1) {
+            // issue row g+1 first (its loads fly while row g is finished), rows g+2 of the plain inputs behind it
+            const double un = qt_ld(U, qt_row(W, g + 2), W.vo), vn = qt_ld(V, qt_row(W, g + 2), W.vo), tn = qt_ld(S, qt_row(W, g + 2), W.vo);
+            const QtGather nxt = qt_gather_issue(G, T, P, qd_clampi(g + 1, 0, n - 1), W.j, u1, v1);
+            t1v = qd_nn((1.0 - P.alpha) * tc0 + P.alpha * qt_gather_use(cur));
+            cur = nxt; u1 = un; v1 = vn; tc0 = tc1; tc1 = tn;
+        }
+        w[0] = w[1]; w[1] = w[2]; w[2] = w[3]; w[3] = w[4]; w[4] = t1v;
+        const int i = g - 2;                                                             // window centre
+        if (i >= W.o0 && i < W.o1) {
+            const unsigned r = qt_row(W, i);
+            double Tv = w[2];
+            if (P.K_h > 0.0) Tv = Tv + P.sub_dt * P.K_h * qt_lap_win(w, T, i, n, P.dlat, P.dlon, P.a);
+            if (P.use_q) {
+                const double heat = qt_div(qt_ld(Q, r, W.vo), P.rcH, P.r_rcH);
+                const bool ocean = qt_ld8(L, r, W.vo8) == 0;
+                if (P.has_ice) {
+                    const bool ic = qt_ld8(I, r, W.vo8) != 0;
+                    if (ocean && !ic) Tv = Tv + P.sub_dt * heat;
+                    if (P.ice_qfac > 0.0 && ocean && ic) Tv = Tv + P.sub_dt * P.ice_qfac * heat;
+                } else if (ocean) Tv = Tv + P.sub_dt * heat;
+            }
+            qt_st(SO, r, W.vs, qd_nn(Tv));
+        }
+    }
+}
+
+__global__ void __launch_bounds__(128)
+k_ocn_tail_stream(QdGeom G, QdTabs T, QdTailArgs P) {
+    const unsigned w = qd_xcd_chunk(blockIdx.x, gridDim.x);
+    const int rs = (int)(w / (unsigned)P.ntc), cs = (int)(w % (unsigned)P.ntc);
+    QtW W;
+    W.n = G.nlat; W.m = G.nlon; W.lane = threadIdx.x & 63;
+    const int jraw = cs * QS_TC2 - 1 + W.lane;
+    W.j = jraw < 0 ? jraw + W.m : (jraw >= W.m ? jraw - W.m : jraw);
+    W.own = W.lane >= 1 && W.lane <= QS_TC2 && jraw < W.m;
+    W.vo = (unsigned)W.j * 8u; W.vo8 = (unsigned)W.j; W.vs = W.own ? (unsigned)jraw * 8u : 0x80000000u;
+    W.slab = (unsigned)(G.lrows_ + QD_PAD_ROWS) * (unsigned)G.nlon * 8u;
+    W.o0 = G.row0 + rs * P.R;
+    W.o1 = min(W.o0 + P.R, G.row0 + G.nrows);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wv == 1) { __builtin_amdgcn_s_setprio(2); qt_sst_wave(G, T, P, W); return; }      // the SST wave is the long one
+    double acc = qt_currents_wave(T, P, W);
+    acc = qt_wave_sum(acc);
+    if (W.lane == 0) P.partial[w] = acc;
+}
+
+// Strip height of the streaming form.  Measured (rocprofv3 kernel trace, 721 x 1440): R = 4 / 6 / 8 / 10 / 12 / 16 / 24 ->
+// 27.0 / 26.2 / 23.9 / 25.4 / 27.4 / 32.7 / 41.3 us (a wave is a serial chain of rows, shorter strips mean more of them in
+// parallel; below 8 the SST wave's four halo rows dominate); one-wave workgroups with separate strip heights for the two roles:
+// 24.6 us at best.  QD_TAIL_R: tuning override, read per launch.
+static int qt_rows(const qd_ctx* c) {
+    if (const char* e = std::getenv("QD_TAIL_R")) { const int r = std::atoi(e); if (r > 0) return r; }
+    return 8;
+}
+
+// number of eta partial sums the launch leaves in P.partial
+int qd_ocn_tail_tiles(const qd_ctx* c, const QdGeom& G) {
+    if (c->ocn_tail == 2) return ((G.nrows + QT_TR - 1) / QT_TR) * ((G.nlon + QT_TC - 1) / QT_TC);
+    const int R = qt_rows(c);
+    return ((G.nrows + R - 1) / R) * ((G.nlon + QS_TC2 - 1) / QS_TC2);
+}
 
 int qd_launch_ocn_tail(qd_ctx* c, const QdGeom& G, QdTailArgs& P) {
     if (G.nlon < 64 || !G.full) return qd_fail(c, "k_ocn_tail: whole-globe handles of >= 64 columns only");
-    P.ntc = (G.nlon + QT_TC - 1) / QT_TC;
-    const int ntr = (G.nrows + QT_TR - 1) / QT_TR;
-    if (ntr * P.ntc > c->red_blocks) return qd_fail(c, "k_ocn_tail: partial buffer too small");
     QdScope sc(c, "ocean_tail");
-    hipLaunchKernelGGL(k_ocn_tail, dim3(ntr * P.ntc), dim3(256), 0, c->stream, G, c->tabs, P);
+    if (c->ocn_tail == 2) {                                  // LDS-tiled form
+        P.ntc = (G.nlon + QT_TC - 1) / QT_TC;
+        const int ntr = (G.nrows + QT_TR - 1) / QT_TR;
+        if (ntr * P.ntc > c->red_blocks) return qd_fail(c, "k_ocn_tail: partial buffer too small");
+        hipLaunchKernelGGL(k_ocn_tail, dim3(ntr * P.ntc), dim3(256), 0, c->stream, G, c->tabs, P);
+        return 0;
+    }
+    P.R = qt_rows(c);
+    P.ntc = (G.nlon + QS_TC2 - 1) / QS_TC2;
+    const int nrs = (G.nrows + P.R - 1) / P.R;
+    if (nrs * P.ntc > c->red_blocks) return qd_fail(c, "k_ocn_tail_stream: partial buffer too small");
+    hipLaunchKernelGGL(k_ocn_tail_stream, dim3(nrs * P.ntc), dim3(128), 0, c->stream, G, c->tabs, P);
     return 0;
 }
