@@ -250,6 +250,7 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
     { const char* ef = std::getenv("QD_FUSED"); if (ef && ef[0] == '0') c->use_fused = 0; }
     { const char* ef = std::getenv("QD_FUSED_FAST"); if (ef) c->fused_fast = std::atoi(ef); }
     { const char* ef = std::getenv("QD_STREAM_R"); if (ef) c->stream_rows = std::max(1, std::atoi(ef)); }
+    { const char* ef = std::getenv("QD_SHAPIRO_STREAM"); if (ef) c->shapiro_stream = std::atoi(ef); }
     { const char* ef = std::getenv("QD_OCN_TAIL"); if (ef) c->ocn_tail = std::atoi(ef); }   // 0: two launches (k_cont_sstadv, k_sst_outlier_fused); 1: k_ocn_tail_stream (default); 2: LDS-tiled k_ocn_tail
     c->geo = QdGeom{d->n_lat, d->n_lon, d->row0, d->n_rows, d->halo, full ? 1 : 0, d->row0 - d->halo, d->n_rows + 2 * d->halo};
     c->own_row0 = d->row0; c->own_nrows = d->n_rows;

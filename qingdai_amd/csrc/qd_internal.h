@@ -193,6 +193,7 @@ struct qd_ctx {
     int use_fused = 1;              // QD_FUSED=0 selects the unfused reference-order kernels
     int fused_fast = 1;             // QD_FUSED_FAST: 1 row-streaming kernels (qd_stream.hip), FAST variant with per-wave EXACT fallback; 2 the same kernels,
                                     // every wave EXACT; 0 LDS-tiled kernels (qd_fused.hip), every tile EXACT; 3 LDS-tiled kernels with their FAST path
+    int shapiro_stream = 1;         // QD_SHAPIRO_STREAM=0: one k_shapiro_pass launch per pass
     int ocn_tail = 1;               // QD_OCN_TAIL=0: continuity + SST + outlier filter as the two launches of qd_ocean.hip
     int stream_rows = 0;            // QD_STREAM_R: strip height of the row-streaming kernels (0 = pick per launch)
     // row-streaming kernels (qd_stream.hip): per-field packed row tables {lapA[r+1], lapP[r], lapQ[r], k4[r]}, [0] atmosphere

@@ -12,6 +12,8 @@
 // metrics (cos floors, k4, pole one-sidedness) are wave-uniform scalars.
 #include "qd_internal.h"
 #include "qd_device.h"
+#include "qd_wave.h"
+#include <cstdlib>
 
 // ------------------------------------------------------------------ Laplacian (device)
 __global__ void __launch_bounds__(QD_BLOCK)
@@ -130,9 +132,90 @@ void qd_launch_shapiro_pass(qd_ctx* c, const QdFieldList& fl, int scrub, int m) 
     QD_ROWS(c, m, G, hipLaunchKernelGGL(k_shapiro_pass, qd_grid2d(G, fl.n), dim3(QD_BLOCK), 0, c->stream, G, fl, scrub));
 }
 
+// All NP passes in ONE launch, rows streamed through registers.  One wave owns a strip of 64 - 2 NP columns x R rows of one field:
+// lanes are columns (the longitude taps are DPP lane shifts; every pass spoils one more lane at either end), rows arrive in
+// order and run through a cascade of NP stages, each holding the two previous longitude-filtered rows of its input.
+//   stage p receives row r of pass p-1's output, l_r = (x[j-1]/4 + x[j]/2) + x[j+1]/4, and emits row r-1 = (l_{r-2}/4 + l_{r-1}/2) + l_r/4
+// scipy's mode='nearest' at the poles (dynamics.py:228) is l_{-1} := l_0 and l_n := l_{n-1} of the SAME pass: a stage primes both
+// history registers with the first row it sees, and gets one virtual row behind the north pole.  Same operations in the same
+// order as NP launches of k_shapiro_pass, so the results are bit-identical; HBM traffic is one read and one write per field
+// (+ 2 NP halo rows per strip) instead of NP of each.
+#define QD_SH_PF 8                              // rows in flight ahead of the cascade
+#define QD_SH_WAVES 1                            // waves per workgroup (measured: 4 is 5 % slower)
+template <int NP> __global__ void __launch_bounds__(64 * QD_SH_WAVES)
+k_shapiro_stream(QdGeom G, QdFieldList fl, int scrub, int R, int ntc, int nstrips) {
+    constexpr int W = 64 - 2 * NP;
+    const unsigned w = qd_xcd_chunk(blockIdx.x, gridDim.x) * QD_SH_WAVES + (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (w >= (unsigned)nstrips) return;
+    const int rs = (int)(w / (unsigned)ntc), cs = (int)(w % (unsigned)ntc);
+    const int lane = threadIdx.x & 63, n = G.nlat;
+    const int jraw = cs * W - NP + lane;
+    const int j = jraw < 0 ? jraw + G.nlon : (jraw >= G.nlon ? jraw - G.nlon : jraw);
+    const bool own = lane >= NP && lane < 64 - NP && jraw < G.nlon;
+    const unsigned vo = (unsigned)j * 8u, vs = own ? (unsigned)jraw * 8u : QD_BUF_OOB;
+    const unsigned slab = (unsigned)(G.lrows_ + QD_PAD_ROWS) * (unsigned)G.nlon * 8u;
+    const qd_rsrc src = qd_buf(fl.in[blockIdx.y], slab), dst = qd_buf(fl.out[blockIdx.y], slab);
+    int a[NP + 1], b[NP + 1];                   // rows stage p has to produce (stage 0: rows to read)
+    a[NP] = G.row0 + rs * R; b[NP] = min(a[NP] + R, G.row0 + G.nrows) - 1;
+#pragma unroll
+    for (int p = NP; p > 0; --p) { a[p - 1] = max(0, a[p] - 1); b[p - 1] = min(n - 1, b[p] + 1); }
+    const int t0 = a[0], t1 = b[NP] + NP;       // the last owned row leaves the cascade NP ticks after it was read
+    auto row_off = [&](int g) { return (unsigned)qd_lrow(G, min(g, n - 1)) * (unsigned)G.nlon; };
+    double pf[QD_SH_PF], h1[NP], h2[NP];
+#pragma unroll
+    for (int k = 0; k < QD_SH_PF; ++k) pf[k] = qd_buf_ld(src, row_off(t0 + k), vo);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) h1[p] = h2[p] = 0.0;
+    for (int tb = t0; tb <= t1; tb += QD_SH_PF) {
+#pragma unroll
+        for (int k = 0; k < QD_SH_PF; ++k) {
+            const int t = tb + k;
+            double cur = pf[k];
+            pf[k] = qd_buf_ld(src, row_off(t + QD_SH_PF), vo);
+            if (t > t1) continue;
+            if (scrub) cur = qd_nn(cur);
+            bool live = false;                                  // did the last stage emit a row on this tick
+#pragma unroll
+            for (int p = 1; p <= NP; ++p) {
+                const int rp = t - (p - 1);                     // the row arriving at stage p on this tick
+                live = false;
+                if (rp < a[p - 1] || rp > b[p - 1] + (b[p - 1] == n - 1 ? 1 : 0)) continue;    // filling / drained
+                const double l = rp <= n - 1 ? (qd_west(cur) * 0.25 + cur * 0.5) + qd_east(cur) * 0.25 : h1[p - 1];
+                if (rp == a[p - 1]) { h1[p - 1] = l; h2[p - 1] = l; continue; }
+                const double o = (h2[p - 1] * 0.25 + h1[p - 1] * 0.5) + l * 0.25;       // row rp - 1 of pass p
+                h2[p - 1] = h1[p - 1]; h1[p - 1] = l;
+                live = rp - 1 >= a[p] && rp - 1 <= b[p];
+                if (live) cur = o;
+            }
+            if (live) qd_buf_st(dst, row_off(t - NP), vs, cur);
+        }
+    }
+}
+
+// strip height of the one-launch Shapiro filter (QD_SHAPIRO_R: tuning override).  rocprofv3 kernel trace, u v h at 721 x 1440, two
+// passes: R = 6 / 8 / 12 / 16 / 24 / 32 -> 17.1 / 15.8 / 16.1 / 17.1 / 18.9 / 19.7 us (two k_shapiro_pass launches: 42 us);
+// 4 instead of 8 rows in flight: +1 us.
+static int qd_shapiro_rows() {
+    if (const char* e = std::getenv("QD_SHAPIRO_R")) { const int r = std::atoi(e); if (r > 0) return r; }
+    return 8;
+}
+
 int qd_shapiro_fields(qd_ctx* c, double** fields, int n, int npass, int m_out) {
     if (npass < 1) npass = 1;
     QdFieldList a; a.n = n;
+    if (npass <= 3 && c->geo.nlon >= 64 && c->shapiro_stream) {
+        for (int k = 0; k < n; ++k) { a.in[k] = fields[k]; a.out[k] = qd_scratch(c, k); a.aux[k] = nullptr; a.k4row[k] = nullptr; a.k4s[k] = 0; }
+        const int R = qd_shapiro_rows(), W = 64 - 2 * npass, ntc = (c->geo.nlon + W - 1) / W;
+        QD_ROWS(c, m_out, G, {
+            const int ns = ((G.nrows + R - 1) / R) * ntc;
+            const dim3 grid((ns + QD_SH_WAVES - 1) / QD_SH_WAVES, n), blk(64 * QD_SH_WAVES);
+            if (npass == 1) hipLaunchKernelGGL(k_shapiro_stream<1>, grid, blk, 0, c->stream, G, a, 1, R, ntc, ns);
+            else if (npass == 2) hipLaunchKernelGGL(k_shapiro_stream<2>, grid, blk, 0, c->stream, G, a, 1, R, ntc, ns);
+            else hipLaunchKernelGGL(k_shapiro_stream<3>, grid, blk, 0, c->stream, G, a, 1, R, ntc, ns);
+        });
+        for (int k = 0; k < n; ++k) { double* t = fields[k]; fields[k] = c->scratch[k]; c->scratch[k] = t; qd_mark(c, {fields[k]}, m_out); }
+        return 0;
+    }
     for (int p = 0; p < npass; ++p) {
         for (int k = 0; k < n; ++k) { a.in[k] = fields[k]; a.out[k] = qd_scratch(c, k); a.aux[k] = nullptr; a.k4row[k] = nullptr; a.k4s[k] = 0; }
         const int m = m_out + (npass - 1 - p);

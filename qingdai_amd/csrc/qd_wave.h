@@ -32,6 +32,23 @@ __device__ __forceinline__ double qd_west(double x) {
 }
 __device__ __forceinline__ int qd_clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
+// buffer access: the range check of the resource drops a store (returns 0 for a load) whose lane offset is QD_BUF_OOB, so a
+// masked store needs no exec branch (a branch around a store costs the row loops a full s_waitcnt vmcnt(0))
+typedef unsigned int qd_u32x2 __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t qd_rsrc;
+#define QD_BUF_FLAGS 0x00020000                // raw buffer, 32-bit data format (word 3 of gfx90a / gfx94x / gfx950)
+#define QD_BUF_OOB 0x80000000u
+__device__ __forceinline__ qd_rsrc qd_buf(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, QD_BUF_FLAGS);
+}
+// row: ELEMENT offset of the row (wave-uniform -> SGPR offset); vo: the lane's byte offset inside the row
+__device__ __forceinline__ double qd_buf_ld(qd_rsrc r, unsigned row, unsigned vo) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, vo, row * 8u, 0));
+}
+__device__ __forceinline__ void qd_buf_st(qd_rsrc r, unsigned row, unsigned vo, double v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(qd_u32x2, v), r, vo, row * 8u, 0);
+}
+
 // XCD-contiguous dealing of a 1-D grid: workgroups are dealt round-robin over the 8 XCDs (block b and b+8 share an L2),
 // so the linear id is remapped such that every XCD walks one contiguous chunk of work items (rows re-read by vertically
 // adjacent strips then come from the same L2).  Pure performance: any placement gives the same result.

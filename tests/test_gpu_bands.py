@@ -277,3 +277,32 @@ def test_rccl_transport_equals_in_process_transport(gpu, monkeypatch):
     assert counts[("rccl", True)][2] >= 5 and counts[("rccl", True)][1] < counts[("rccl", False)][1]
     for k in names:                                              # the ring changes where the eta mean is reduced, not its value
         assert relerr(out[("rccl", True)][k], out[("rccl", False)][k]) < 1e-12, k
+
+
+@pytest.mark.parametrize("shape", [(64, 64), (91, 144), (181, 360), (33, 130)])
+def test_one_launch_shapiro_equals_one_launch_per_pass(gpu, shape, monkeypatch):
+    """k_shapiro_stream (all passes in one launch: lon taps by DPP lane shifts, lat taps from registers, rows streamed) against
+    k_shapiro_pass once per pass (QD_SHAPIRO_STREAM=0) and against the oracle's scipy-convolve form (dynamics.py:215-231): bit for
+    bit, 1-3 passes, with NaN / +-inf cells (scrubbed by the first pass only) in the interior, on the poles and on the seam; the
+    strip heights cover one strip per globe, strips that end on a pole row and one-row strips."""
+    import qingdai_amd as qa
+    from qingdai_amd.device import Device
+    from qd_oracle import numerics as onx
+    nlat, nlon = shape
+    r = np.random.default_rng(nlat * 1000 + nlon)
+    F = r.normal(0.0, 10.0, (nlat, nlon))
+    F[0, 3] = np.nan; F[nlat - 1, nlon - 1] = np.inf; F[nlat // 2, 0] = -np.inf; F[1, nlon // 2] = np.nan; F[nlat - 2, 7] = 1e308
+    monkeypatch.setenv("QD_SHAPIRO_STREAM", "0")
+    ref_dev = Device(qa.SphericalGrid(nlat, nlon))
+    want = {n: ref_dev.op_shapiro(F, n) for n in (1, 2, 3)}
+    ref_dev.close()
+    for n in (1, 2, 3):
+        assert np.array_equal(want[n], onx.shapiro(F, n)), n
+    monkeypatch.setenv("QD_SHAPIRO_STREAM", "1")
+    for R in ("16", "1", "7", str(nlat), str(nlat - 1)):
+        monkeypatch.setenv("QD_SHAPIRO_R", R)
+        dev = Device(qa.SphericalGrid(nlat, nlon))
+        for n in (1, 2, 3):
+            got = dev.op_shapiro(F, n)
+            assert np.array_equal(got, want[n]), (R, n, np.argwhere(got != want[n])[:5])
+        dev.close()
