@@ -152,7 +152,7 @@ int qd_driver_physics(qd_handle h, double dt);
 int qd_hydrology_commit(qd_handle h, double dt);
 /* benchmark_jax.py:124-158 as one resident loop of n steps: forcing -> albedo -> time_step [-> ocean
  * coupling] [-> hydrology commit].  flags bit0 = with_ocean, bit1 = with_driver_physics (else the simple
- * ocean/land albedo of benchmark_jax.py:129), bit2 = pass albedo to time_step, bit3 = hydrology commit, bit4 = energy diagnostics on the first step (qd_energy_diagnostics_last), bit5 = ecology sub-step (qd_eco_substep, and qd_indiv_substep when a pool is configured; needs bit1).  `stars` holds n rows of 7 host scalars
+ * ocean/land albedo of benchmark_jax.py:129), bit2 = pass albedo to time_step, bit3 = hydrology commit, bit4 = energy diagnostics on the first step (qd_energy_diagnostics_last), bit5 = ecology sub-step (qd_eco_substep, and qd_indiv_substep when a pool is configured; needs bit1), bit6 = tracer transport after the ocean step (qd_phyto_advect_diffuse; needs bit0 and qd_phyto_configure).  `stars` holds n rows of 7 host scalars
  * (flux_A, decl_A, ra_A, flux_B, decl_B, ra_B, theta), evaluated by the caller as forcing.py:85-125 does. */
 int qd_step_n(qd_handle h, int n, double dt, int flags, const double* stars);
 int qd_last_ocean_nsub(qd_handle h, int* n_sub);
@@ -229,6 +229,15 @@ int qd_indiv_configure(qd_handle h, int n_cells, const int32_t* sample_j, const 
 int qd_indiv_substep(qd_handle h, double dt, int* fired_or_null);
 int qd_indiv_download(qd_handle h, double* E_day, double* stress_days);   /* each [n_indiv]; band handles: own cells, 0 elsewhere */
 int qd_indiv_upload(qd_handle h, const double* E_day, const double* stress_days);   /* daily reset / restart */
+
+/* ---- phytoplankton tracers carried by the ocean currents (pygcm/ecology/phyto.py:496-547) ------------
+ * PhytoManager.advect_diffuse on resident state: C_phyto_s [S][n_lat][n_lon] lives on the device next to the ocean's
+ * uo / vo; the driver calls it once per step after the SST write-back (scripts/run_simulation.py:2254-2258).
+ * K_h = QD_PHYTO_KH (phyto.py:123), adv_alpha = QD_PHYTO_ADV_ALPHA (phyto.py:517).  n_species = 0 frees the stack. */
+int qd_phyto_configure(qd_handle h, int n_species, double K_h, double adv_alpha);
+int qd_phyto_upload(qd_handle h, int species, const double* host);      /* [n_lat][n_lon] f64 */
+int qd_phyto_download(qd_handle h, int species, double* host);
+int qd_phyto_advect_diffuse(qd_handle h, double dt_seconds);             /* all species, three launches */
 
 /* ---- reductions for diagnostics (energy.py:494-538, ocean.py:535-561) -------------- */
 /* compute_energy_diagnostics (energy.py:494-538) from the resident state, with the flux formulas of the driver's

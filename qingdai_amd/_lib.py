@@ -39,6 +39,7 @@ SYMBOLS = [
     "qd_plansim_pop_exchange",
     "qd_eco_configure", "qd_eco_set_lai_layers", "qd_eco_substep", "qd_eco_banded_alpha", "qd_eco_get_state", "qd_eco_set_state",
     "qd_indiv_configure", "qd_indiv_substep", "qd_indiv_download", "qd_indiv_upload",
+    "qd_phyto_configure", "qd_phyto_upload", "qd_phyto_download", "qd_phyto_advect_diffuse",
     "qd_copy_ceiling", "qd_timing_enable", "qd_timing_select", "qd_timing_get", "qd_timing_reset",
 ]
 
@@ -117,6 +118,10 @@ def load():
     lib.qd_indiv_substep.argtypes = [vp, dbl, ip]
     lib.qd_indiv_download.argtypes = [vp, vp, vp]
     lib.qd_indiv_upload.argtypes = [vp, vp, vp]
+    lib.qd_phyto_configure.argtypes = [vp, i32, dbl, dbl]
+    lib.qd_phyto_upload.argtypes = [vp, i32, vp]
+    lib.qd_phyto_download.argtypes = [vp, i32, vp]
+    lib.qd_phyto_advect_diffuse.argtypes = [vp, dbl]
     lib.qd_comm_unique_id.argtypes = [vp, sz]
     lib.qd_comm_init.argtypes = [vp, vp, sz]
     lib.qd_comm_barrier.argtypes = [vp]

@@ -329,6 +329,7 @@ extern "C" int qd_destroy(qd_handle c) {
                         "last miss at call %.0f: centre %.6g -> median %.6g\n", s, h[16 * s], h[16 * s + 8], h[16 * s + 9], h[16 * s + 4],
                         h[16 * s + 5], h[16 * s + 6], h[16 * s + 7], h[16 * s + 13], h[16 * s + 14], h[16 * s + 15]);
     }
+    qd_phyto_release(c);
     for (int f = 0; f < QD_F_COUNT_F64; ++f) if (c->f[f]) hipFree(c->f[f]);
     for (int s = 0; s < QD_NSCRATCH; ++s) if (c->scratch[s]) hipFree(c->scratch[s]);
     for (double* t : c->tab_alloc) hipFree(t);
@@ -511,7 +512,9 @@ extern "C" int qd_step_n(qd_handle c, int n, double dt, int flags, const double*
     if (!c || !stars) return -1;
     hipSetDevice(c->desc.device);
     const int with_ocean = flags & 1, with_phys = flags & 2, pass_alb = flags & 4, with_hydro = flags & 8, want_diag = flags & 16;
-    const int with_eco = flags & 32;
+    const int with_eco = flags & 32, with_phyto = flags & 64;
+    if (with_phyto && !with_ocean) return qd_fail(c, "qd_step_n: the tracer transport (bit6) needs the ocean step (bit0)");
+    if (with_phyto && c->phyto.S == 0) return qd_fail(c, "qd_step_n: bit6 set but qd_phyto_configure has not been called");
     if (with_eco && !with_phys) return qd_fail(c, "qd_step_n: the ecology sub-step (bit5) needs the driver physics (bit1)");
     if (with_eco && !c->eco.configured) return qd_fail(c, "qd_step_n: bit5 set but qd_eco_configure has not been called");
     for (int s = 0; s < n; ++s) {
@@ -528,6 +531,7 @@ extern "C" int qd_step_n(qd_handle c, int n, double dt, int flags, const double*
         // fluxes of the coupling block (run_simulation.py:2199-2246) -- and kept for qd_energy_diagnostics_last
         if (with_ocean && want_diag && s == 0 && (rc = qd_energy_diag_impl(c, c->last_diag))) return rc;
         if (with_ocean && (rc = qd_ocean_step_impl(c, dt, 1, 1, 1))) return rc;
+        if (with_phyto && (rc = qd_phyto_step_impl(c, dt))) return rc;      // run_simulation.py:2254-2258
         // IndividualPool.try_substep reads this step's isr_A / isr_B and W_land before the bucket update (run_simulation.py:2021-2046)
         if (with_eco && c->eco.n_indiv > 0 && (rc = qd_indiv_substep_impl(c, dt, nullptr))) return rc;
         if (with_hydro && (rc = qd_hydrology_commit_impl(c, dt))) return rc;

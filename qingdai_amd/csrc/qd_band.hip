@@ -174,7 +174,8 @@ QdSegs qd_segments(qd_ctx* c, int margin) {
     return S;
 }
 
-int qd_plan(qd_ctx* c, std::initializer_list<QdUse> in, int want) {
+int qd_plan(qd_ctx* c, const QdUse* in_, int n_in, int want) {
+    struct { const QdUse* p; int n; const QdUse* begin() const { return p; } const QdUse* end() const { return p + n; } } in{in_, n_in};
     if (c->geo.full) return 0;
     const int H = c->geo.halo;
     bool need = false;

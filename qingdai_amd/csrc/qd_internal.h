@@ -127,6 +127,11 @@ __device__ __forceinline__ QdTile qd_tile() {
 struct QdUse { void** slot; int radius; int u8; };
 // ecology sub-step: clocks and cache flags of PopulationManager / EcologyAdapter / IndividualPool (qd_eco.hip)
 #define QD_MAXBANDS 32
+// phytoplankton tracer stack (qd_phyto.hip): stack[0] holds the S species, stack[1] the advected intermediate
+// (cur / tmp are members, not heap storage: the in-process band transport finds a peer's slab at the same offset in ITS context)
+#define QD_MAX_SPECIES 64
+struct QdPhyto { int S = 0; double* stack[2] = {nullptr, nullptr}; size_t stride = 0; double* cur[QD_MAX_SPECIES] = {nullptr}; double* tmp[QD_MAX_SPECIES] = {nullptr}; double K_h = 5.0e3, alpha = 0.7; };
+
 struct QdEco {
     qd_eco_params p{0.5, 0.3, 0.20, 1.0, 6.0, 0.05, 1, 0, 0, 0, 1, 0};
     int configured = 0;
@@ -177,6 +182,7 @@ struct qd_ctx {
     int bands_nb = 0;
     double last_diag[10] = {0};      // energy-budget means taken inside qd_step_n (flags bit 4)
     int has_elevation = 0;           // an ELEVATION map has been uploaded (orographic factor needs one)
+    QdPhyto phyto;                   // resident tracers of PhytoManager.advect_diffuse
     QdEco eco;                       // ecology sub-step state
     double* zonal_tw = nullptr;      // [2][nlon] cos / sin(2 pi m / nlon) of the zonal spectral filter
     double* sel_cand = nullptr;      // [2][cells] candidates of the two middle ranks after two radix passes (whole-globe handles)
@@ -254,7 +260,8 @@ struct QdScope {               // optional per-kernel-group timing with hipEvent
 #define QD_IN8(ptr, r) QdUse{(void**)&(ptr), (r), 1}
 // makes sure every input slab is valid `radius` rows beyond what the launch will compute; exchanges
 // halos when one is not; returns the margin (rows beyond the owned band) the outputs can be computed on
-int qd_plan(qd_ctx* c, std::initializer_list<QdUse> in, int want = INT_MAX);
+int qd_plan(qd_ctx* c, const QdUse* in, int n, int want = INT_MAX);
+inline int qd_plan(qd_ctx* c, std::initializer_list<QdUse> in, int want = INT_MAX) { return qd_plan(c, in.begin(), (int)in.size(), want); }
 void qd_mark(qd_ctx* c, std::initializer_list<const void*> out, int margin);
 int qd_vm_get(qd_ctx* c, const void* slab);
 struct QdSegs { QdGeom g[3]; int n; };
@@ -311,6 +318,8 @@ int  qd_eco_eday_impl(qd_ctx* c, double dt);              // E_day += nan_to_num
 int  qd_indiv_substep_impl(qd_ctx* c, double dt, int* fired);
 void qd_eco_free(qd_ctx* c);
 int  qd_band_copy_in(qd_ctx* c, void* dst, const void* host, size_t esz);   // qd_api.hip
+int  qd_phyto_step_impl(qd_ctx* c, double dt);                              // qd_phyto.hip
+void qd_phyto_release(qd_ctx* c);
 
 // qd_reduce.hip
 int qd_reduce_field(qd_ctx* c, const double* x, int op, double* host_out);

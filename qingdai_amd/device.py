@@ -130,19 +130,42 @@ class Device:
         self._chk(self.lib.qd_hydrology_commit(self.h, float(dt)), "qd_hydrology_commit")
 
     def step_n(self, stars, dt, with_ocean=False, with_physics=False, pass_albedo=True, with_hydrology=False, energy_diag=False,
-               ecology=False):
+               ecology=False, phyto=False):
         """benchmark_jax.py:124-158 as one resident loop (qd_step_n).  `stars`: [n][7] host
         scalars from ThermalForcing.star_table()."""
         self.flush()
         st = np.ascontiguousarray(stars, dtype=np.float64)
         assert st.ndim == 2 and st.shape[1] == 7
         flags = ((1 if with_ocean else 0) | (2 if with_physics else 0) | (4 if pass_albedo else 0) | (8 if with_hydrology else 0) |
-                 (16 if energy_diag else 0) | (32 if ecology else 0))
+                 (16 if energy_diag else 0) | (32 if ecology else 0) | (64 if phyto else 0))
         self._chk(self.lib.qd_step_n(self.h, int(st.shape[0]), float(dt), flags,
                                      st.ctypes.data_as(ctypes.POINTER(ctypes.c_double))), "qd_step_n")
 
     def sync(self):
         self._chk(self.lib.qd_sync(self.h), "qd_sync")
+
+    # ---- phytoplankton tracers carried by the ocean currents (pygcm/ecology/phyto.py:496-547), resident
+    def phyto_configure(self, n_species, K_h, adv_alpha):
+        self._chk(self.lib.qd_phyto_configure(self.h, int(n_species), float(K_h), float(adv_alpha)), "qd_phyto_configure")
+        self._phyto_S = int(n_species)
+
+    def phyto_upload(self, C_s):
+        C_s = np.ascontiguousarray(C_s, dtype=np.float64)
+        assert C_s.ndim == 3 and C_s.shape[0] == getattr(self, "_phyto_S", -1) and C_s.shape[1:] == self.shape
+        for s in range(C_s.shape[0]):
+            self._chk(self.lib.qd_phyto_upload(self.h, s, C_s[s].ctypes.data), "qd_phyto_upload")
+
+    def phyto_download(self):
+        self.flush()
+        out = np.zeros((self._phyto_S,) + self.shape, dtype=np.float64)
+        for s in range(self._phyto_S):
+            self._chk(self.lib.qd_phyto_download(self.h, s, out[s].ctypes.data), "qd_phyto_download")
+        return out
+
+    def phyto_advect_diffuse(self, dt_seconds):
+        """PhytoManager.advect_diffuse on the resident tracers and the resident uo / vo (three launches for all species)."""
+        self.flush()
+        self._chk(self.lib.qd_phyto_advect_diffuse(self.h, float(dt_seconds)), "qd_phyto_advect_diffuse")
 
     def last_ocean_nsub(self):
         n = ctypes.c_int(0)

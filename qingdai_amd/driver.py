@@ -13,8 +13,11 @@ Ecology (QD_ECO_ENABLE, default on like the reference): the per-step part -- Eco
 into the base albedo, IndividualPool.try_substep -- runs inside the resident loop (qingdai_amd/ecology.py, qd_eco_*); the
 DAILY population dynamics are host code outside this package, reached through `Simulation(daily_hook=...)`, which is called
 where the reference calls eco.step_daily (run_simulation.py:1786-1864).  Without a hook the LAI stays at its initial value.
-Not carried over (out of the hot path): phytoplankton daily step, river routing, genes / diversity,
-matplotlib panels (a note is printed instead of a plot).
+Phytoplankton (QD_PHYTO_ENABLE and QD_PHYTO_ADVECTION, default on like the reference, needs the ocean): the per-step transport of
+the tracers by the ocean currents (phyto.advect_diffuse, run_simulation.py:2254-2258) runs inside the resident loop on resident
+tracers (qingdai_amd/phyto.py PhytoTracers, qd_phyto_*); data/plankton.nc carries C_phyto_s through autosave / startup load.
+Not carried over (out of the hot path): phytoplankton daily growth / optics, river routing, genes /
+diversity, matplotlib panels (a note is printed instead of a plot).
 
 Per iteration (run_simulation.py:1760-2340), all on the device through one qd_step_n call per chunk:
   hybrid precipitation -> clouds -> cloud tracer -> insolation -> P019 lapse/snow -> albedo -> Teq ->
@@ -109,9 +112,10 @@ class Simulation:
     """The reference driver's state + loop, device resident."""
 
     def __init__(self, n_lat=None, n_lon=None, params: QdParams | None = None, use_ocean=None, quiet=False, device=0,
-                 ecology=None, individuals=None, daily_hook=None):
+                 ecology=None, individuals=None, daily_hook=None, phyto=None):
         """ecology / individuals: None = QD_ECO_ENABLE / QD_ECO_INDIV_ENABLE (both default 1, run_simulation.py:1324,1404).
-        daily_hook(sim, soil_idx, glacier_mask): the host-side daily ecology, called at planet-day boundaries."""
+        daily_hook(sim, soil_idx, glacier_mask): the host-side daily ecology, called at planet-day boundaries.
+        phyto: None = QD_PHYTO_ENABLE and QD_PHYTO_ADVECTION (both default 1, run_simulation.py:1347,1351)."""
         env = os.environ
         n_lat = int(n_lat if n_lat is not None else env.get("QD_N_LAT", "121"))   # run_simulation.py:1195 is 121x240
         n_lon = int(n_lon if n_lon is not None else env.get("QD_N_LON", "240"))
@@ -179,6 +183,15 @@ class Simulation:
                 lai = f"LAI mean {self.eco.pop.summary()['LAI_mean']:.2f}" if self.eco.pop is not None else "no population (M1)"
                 print(f"[Ecology] device sub-step: NB={self.eco.bands.nbands}, alpha_leaf={self.eco.alpha_leaf_scalar:.3f}, "
                       f"{lai}, individuals {self.indiv.n_indiv if self.indiv else 0}")
+        # phytoplankton tracers (run_simulation.py:1346-1364): only their transport by the currents is on this path
+        self.phyto = None
+        if phyto is None:
+            phyto = int(env.get("QD_PHYTO_ENABLE", "1")) == 1 and int(env.get("QD_PHYTO_ADVECTION", "1")) == 1
+        if phyto and self.ocean is not None:
+            from .phyto import PhytoTracers
+            self.phyto = PhytoTracers(self.grid, self.land_mask, dev=self.dev)
+            if not quiet:
+                print(f"[Phyto] resident tracers: S={self.phyto.S}, K_h={self.phyto.K_h:g} m^2/s, adv_alpha={self.phyto.adv_alpha:g}")
         # banded initial surface temperature (run_simulation.py:310-328)
         if int(env.get("QD_INIT_BANDED", "0")) == 1:
             T_eq, T_pole = float(env.get("QD_INIT_T_EQ", "295.0")), float(env.get("QD_INIT_T_POLE", "265.0"))
@@ -223,6 +236,8 @@ class Simulation:
             save_ocean(os.path.join(data_dir, "ocean.nc"), self.grid, self.dev, day_value=day)
         topo.export_topography_to_netcdf(os.path.join(data_dir, "topography.nc"), self.grid, self.land_mask, self.base_albedo,
                                          self.friction, elevation=self.elevation)
+        if self.phyto is not None:                              # run_simulation.py:1677-1685 (the tracer part of plankton.nc)
+            self.phyto.save_distribution_nc(os.path.join(data_dir, "plankton.nc"), day_value=day)
 
     # -- the loop
     def bootstrap_ecology(self):
@@ -296,7 +311,7 @@ class Simulation:
         times = self.t + self.dt * np.arange(n)
         stars = self.forcing.star_table(times)
         self.dev.step_n(stars, float(self.dt), with_ocean=self.ocean is not None, with_physics=True, pass_albedo=False,
-                        with_hydrology=True, energy_diag=energy_diag, ecology=self.eco is not None)
+                        with_hydrology=True, energy_diag=energy_diag, ecology=self.eco is not None, phyto=self.phyto is not None)
         self.t = float(times[-1] + self.dt)
         self._step_index += n
 
@@ -359,6 +374,11 @@ def main(argv=None):
         except Exception as e:             # noqa: BLE001
             print(f"[Restart] Failed to load '{loaded}': {e}\nContinuing with fresh init.")
             loaded = None
+    # run_simulation.py:1377-1399: data/plankton.nc restores the tracer distributions at startup (QD_LOAD_PLANKTON=1, default)
+    if sim.phyto is not None and int(env.get("QD_LOAD_PLANKTON", "1")) == 1:
+        pnc = os.path.join(data_dir, "plankton.nc")
+        if os.path.exists(pnc):
+            print(f"[Phyto] plankton.nc load {'OK' if sim.phyto.load_distribution_nc(pnc) else 'skipped/failed'}.")
     if not loaded and sim.t == 0.0:
         if env.get("QD_ORBIT_EPOCH_SECONDS"):
             sim.t = float(env["QD_ORBIT_EPOCH_SECONDS"])

@@ -153,3 +153,32 @@ def test_greenhouse_autotune_matches_oracle():
         assert (p.qnet_lw_eps0, p.qnet_lw_kc) == (eps, kc)
         assert 0.30 <= eps <= 0.98 and 0.0 <= kc <= 0.80
     assert (p.lw_eps0, p.lw_kc) == (e0, k0)
+
+
+def test_phyto_tracers_initial_state_and_plankton_nc(tmp_path, monkeypatch):
+    """PhytoTracers without a device: the initial state of phyto.py:253-270 (fractions of chl0 over the ocean, 0 on land), the
+    QD_PHYTO_* knobs, and the C_phyto_s round trip through data/plankton.nc (f4, dims species/lat/lon like phyto.py:752-765)."""
+    import qingdai_amd as qa
+    from qingdai_amd.phyto import PhytoTracers
+    from qingdai_amd.topography import create_land_sea_mask
+    from qingdai_amd import ncio
+    grid = qa.SphericalGrid(19, 36)
+    mask = create_land_sea_mask(grid)
+    monkeypatch.setenv("QD_PHYTO_NSPECIES", "3")
+    monkeypatch.setenv("QD_PHYTO_INIT_FRAC", "2,1,1")
+    monkeypatch.setenv("QD_PHYTO_CHL0", "0.08")
+    ph = PhytoTracers(grid, mask)
+    assert ph.S == 3 and ph.K_h == 5.0e3 and ph.adv_alpha == 0.7
+    C = ph.C_phyto_s
+    assert C.shape == (3, 19, 36) and np.all(C[:, mask == 1] == 0.0)
+    assert np.allclose(C[0][mask == 0], 0.5 * 0.08) and np.allclose(C[2][mask == 0], 0.25 * 0.08)
+    path = str(tmp_path / "plankton.nc")
+    ph.C_phyto_s = C * np.linspace(0.5, 1.5, 36)[None, None, :]
+    assert ph.save_distribution_nc(path, day_value=3.5)
+    v, attrs = ncio.read_nc(path, ["C_phyto_s"])
+    assert v["C_phyto_s"].dtype == np.float32 and float(attrs["day"]) == 3.5 and int(attrs["S"]) == 3
+    ph2 = PhytoTracers(grid, mask)
+    assert ph2.load_distribution_nc(path)
+    assert np.allclose(ph2.C_phyto_s, ph.C_phyto_s, rtol=1e-6)
+    monkeypatch.setenv("QD_PHYTO_NSPECIES", "2")
+    assert not PhytoTracers(grid, mask).load_distribution_nc(path)          # species count mismatch: keep the current state

@@ -1,0 +1,155 @@
+"""GPU (-m gpu): PhytoManager.advect_diffuse on RESIDENT tracers (qd_phyto_*; pygcm/ecology/phyto.py:496-547, called by the driver
+at scripts/run_simulation.py:2254-2258): against the reference's golden vectors, against the oracle at a size with real land /
+NaN / K_h = 0, inside qd_step_n on the currents the ocean step has just written, and on latitude bands."""
+import numpy as np
+import pytest
+
+from util import load_golden, relerr, surface
+from test_gpu_bands import _seed_state, _setup
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape", [(19, 36), (37, 72)])
+def test_resident_transport_vs_reference_goldens(gpu, shape):
+    import qingdai_amd as qa
+    from qingdai_amd.device import Device
+    meta, d = load_golden(f"phyto_{shape[0]}x{shape[1]}")
+    _, mask, _, _ = surface(*shape)
+    dev = Device(qa.SphericalGrid(*shape))
+    dev.upload_now("LAND_MASK", mask); dev.upload_now("UO", d["uo"]); dev.upload_now("VO", d["vo"])
+    dev.phyto_configure(d["C0"].shape[0], meta["K_h"], meta["adv_alpha"])
+    dev.phyto_upload(d["C0"])
+    for _ in range(meta["nsteps"]):
+        dev.phyto_advect_diffuse(meta["dt"])
+    C = dev.phyto_download()
+    dev.close()
+    e = relerr(C, d["ref_C"])
+    print(e)
+    assert e < 1e-12
+    assert np.all(C[:, mask == 1] == 0.0) and np.all(C >= 0.0)
+
+
+@pytest.mark.parametrize("K_h", [5.0e3, 0.0])
+def test_resident_transport_vs_oracle(gpu, K_h):
+    """91 x 144, 5 species, 4 steps, a NaN and an inf cell in the tracers (scrubbed by nan_to_num only when K_h > 0: with K_h = 0
+    the reference lets them through, phyto.py:520-522); the device must agree with the oracle to rounding, NaN for NaN."""
+    import qingdai_amd as qa
+    from qingdai_amd.device import Device
+    from qd_oracle import phyto as ophyto
+    import qd_oracle as qo
+    nlat, nlon, S = 91, 144, 5
+    g, mask, _, _ = surface(nlat, nlon)
+    r = np.random.default_rng(11)
+    lat = np.linspace(-np.pi / 2, np.pi / 2, nlat)[:, None]; lon = np.linspace(0, 2 * np.pi, nlon, endpoint=False)[None, :]
+    uo = 1.5 * np.cos(lat) * np.sin(2 * lon) + r.normal(0, 0.2, (nlat, nlon))
+    vo = 0.8 * np.sin(2 * lat) * np.cos(3 * lon) + r.normal(0, 0.1, (nlat, nlon))
+    C0 = np.abs(r.normal(0.3, 0.2, (S, nlat, nlon))) * (mask == 0)
+    C0[1, 40, 70] = np.nan; C0[2, 0, 5] = np.inf
+    dev = Device(qa.SphericalGrid(nlat, nlon))
+    dev.upload_now("LAND_MASK", mask); dev.upload_now("UO", uo); dev.upload_now("VO", vo)
+    dev.phyto_configure(S, K_h, 0.7)
+    dev.phyto_upload(C0)
+    want = C0
+    with np.errstate(all="ignore"):
+        for _ in range(4):
+            dev.phyto_advect_diffuse(900.0)
+            want = ophyto.advect_diffuse(want, uo, vo, 900.0, qo.Grid(nlat, nlon), mask, K_h=K_h, adv_alpha=0.7)
+    got = dev.phyto_download()
+    dev.close()
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), fin)
+    e = relerr(np.where(fin, got, 0.0), np.where(fin, want, 0.0))
+    print(K_h, e)
+    assert e < 1e-12
+
+
+def _coupled(world, nlat, nlon, nsteps, S):
+    """nsteps of the coupled loop with the tracer transport inside qd_step_n (flags bit6)."""
+    from qingdai_amd.bands import BandGroup
+    from qingdai_amd.device import Device
+    qa, grid, mask, alb, fric, p = _setup(nlat, nlon, dict(energy_w=1.0, ocean_cfl=0.05))
+    forcing = qa.ThermalForcing(qa.SphericalGrid(nlat, nlon), qa.OrbitalSystem())
+    stars = forcing.star_table([i * 300.0 for i in range(nsteps)])
+    st = _seed_state(nlat, nlon, 5)
+    r = np.random.default_rng(2)
+    st["UO"] = r.normal(0, 0.3, (nlat, nlon)) * (mask == 0); st["VO"] = r.normal(0, 0.3, (nlat, nlon)) * (mask == 0)
+    C0 = np.abs(r.normal(0.3, 0.2, (S, nlat, nlon))) * (mask == 0)
+    fields = {"LAND_MASK": mask, "FRICTION": fric, "BASE_ALBEDO": alb, **st}
+    devs = [Device(grid, p)] if world == 1 else None
+    grp = None
+    if world > 1:
+        grp = BandGroup(grid, world, p)
+        devs = grp.devs
+    for d in devs:
+        for k, v in fields.items():
+            d.upload_now(k, v)
+        d.phyto_configure(S, 5.0e3, 0.7)
+        d.phyto_upload(C0)
+    run = (lambda fn: fn(devs[0], 0)) if world == 1 else grp.run
+    run(lambda d, rk: d.step_n(stars, 300.0, with_ocean=True, with_physics=True, pass_albedo=True, phyto=True))
+    C = np.zeros_like(C0)
+    for k, d in enumerate(devs):
+        part = d.phyto_download()
+        r0, n = (0, nlat) if world == 1 else grp.ranges[k]
+        C[:, r0:r0 + n] = part[:, r0:r0 + n]
+    uo = devs[0].get("UO").copy() if world == 1 else grp.get("UO")
+    (devs[0].close() if world == 1 else grp.close())
+    return C, uo, C0
+
+
+def test_transport_inside_the_resident_loop_and_on_bands(gpu):
+    """flags bit6 of qd_step_n: the tracers move with the currents of THIS step's ocean update.  Whole globe against 3 latitude
+    bands (halo exchanges of the tracer slabs planned like every other stencil input): bit-identical tracers."""
+    one, uo1, C0 = _coupled(1, 61, 96, 4, 3)
+    assert relerr(one, C0) > 1e-3                      # something moved
+    three, uo3, _ = _coupled(3, 61, 96, 4, 3)
+    assert relerr(uo3, uo1) < 1e-12
+    assert relerr(three, one) < 1e-12
+
+
+def test_coupled_loop_with_tracers_vs_oracle(gpu):
+    """The configs[2] loop (forcing -> driver physics -> time_step -> ocean) with the tracer transport after every ocean step, 6
+    steps at 61 x 96: the device moves the tracers with ITS currents inside qd_step_n, the oracle moves them with the oracle
+    ocean's currents after each DriverOracle.step (scripts/run_simulation.py:2249-2258)."""
+    import qd_oracle as qo
+    from qd_oracle.driver import DriverOracle
+    from qd_oracle import phyto as ophyto
+    import qingdai_amd as qa
+    from qingdai_amd.topography import create_land_sea_mask, generate_base_properties
+    nlat, nlon, S, nsteps, dt = 61, 96, 4, 6, 300.0
+    over = dict(energy_w=1.0, cloud_couple=1)
+    grid = qa.SphericalGrid(nlat, nlon)
+    mask = create_land_sea_mask(grid)
+    base_albedo, friction = generate_base_properties(mask)
+    Cs_ocean = 1000.0 * 4200.0 * 50.0
+    csmap = np.where(mask == 1, 3e6, Cs_ocean).astype(float)
+    m = qa.SpectralModel(grid, friction, H=8000, tau_rad=10 * 24 * 3600, greenhouse_factor=0.40, C_s_map=csmap, land_mask=mask,
+                         Cs_ocean=Cs_ocean, Cs_land=3e6, Cs_ice=5e6, params=qa.QdParams(**over))
+    qa.WindDrivenSlabOcean(grid, mask, 50.0, init_Ts=np.full((nlat, nlon), 288.0))
+    lat = np.deg2rad(grid.lat_mesh); lon = np.deg2rad(grid.lon_mesh)
+    u0 = 60.0 * np.cos(lat) * (1.0 + 0.08 * np.sin(3 * lon)); v0 = 40.0 * np.sin(2 * lat) * np.cos(2 * lon)
+    m.u, m.v = u0, v0
+    dev = m._dev
+    dev.upload_now("BASE_ALBEDO", base_albedo)
+    r = np.random.default_rng(4)
+    C0 = np.abs(r.normal(0.3, 0.2, (S, nlat, nlon))) * (mask == 0)
+    dev.phyto_configure(S, 5.0e3, 0.7)
+    dev.phyto_upload(C0)
+    forcing = qa.ThermalForcing(grid, qa.OrbitalSystem())
+    dev.step_n(forcing.star_table([i * dt for i in range(nsteps)]), dt, with_ocean=True, with_physics=True, pass_albedo=True, phyto=True)
+    got = dev.phyto_download()
+    g = qo.Grid(nlat, nlon)
+    P = qo.defaults(**over)
+    om = qo.AtmosOracle(g, friction, mask, P, C_s_map=csmap)
+    om.u, om.v = u0.copy(), v0.copy()
+    oo = qo.OceanOracle(g, mask, P, init_Ts=np.full((nlat, nlon), 288.0))
+    d = DriverOracle(g, om, oo, qo.Forcing(g), mask, base_albedo, P)
+    want = C0
+    for i in range(nsteps):
+        d.step(i * dt, dt, pass_albedo=True, commit=False)
+        want = ophyto.advect_diffuse(want, oo.uo, oo.vo, dt, g, mask, K_h=5.0e3, adv_alpha=0.7)
+    e = relerr(got, want)
+    print(e, relerr(dev.get("UO"), oo.uo))
+    assert relerr(want, C0) > 1e-4 and e < 1e-9
