@@ -151,7 +151,40 @@ def ecology_leg(dev, grid, mask, forcing, dt, W, K):
     ind32_ms, _ = dev.timing_get("eco_indiv")
     dev.timing(on=False)
     st = eco.pop.state()
-    return {"ms_per_step": with_eco, "individual_substep_kernel_ms": ind_ms, "individual_substeps_timed": ind_n,
+    # f32 STORAGE of the canopy maps (LAI_tot, snapshot, f, alpha, banded alpha; QD_ECO_F32, BASELINE configs[4] "f32 mixed
+    # precision") on a second handle of the same case: the same loop, and the deviation of its maps from this handle's f64 maps
+    f32 = None
+    try:
+        for k in ("ECO_ALPHA", "ECO_F"):
+            dev._host.pop(k, None)
+        a64, f64_ = dev.get("ECO_ALPHA").copy(), dev.get("ECO_F").copy()
+        grid2, m2, _, forcing2, _, _, _ = build_case(grid.n_lat, grid.n_lon, True)
+        dev2 = m2._dev
+        eco2 = EcologyAdapter(grid2, mask, dev=dev2, albedo_couple=True, f32_maps=True)
+        IndividualPool(grid2, mask, eco2, sample_frac=0.02, per_cell=150, substeps_per_day=10, f32_storage=True)
+        eco2.pop.push_layers()
+
+        def run2(eco_on, n):
+            dev2.sync()
+            t0 = time.perf_counter()
+            dev2.step_n(stars[:n], dt, with_ocean=True, with_physics=True, pass_albedo=False, with_hydrology=True, ecology=eco_on)
+            dev2.sync()
+            return (time.perf_counter() - t0) / n * 1e3, dev2.last_ocean_nsub()
+        run2(True, W)
+        legs2 = [run2(False, h), run2(True, h), run2(False, h), run2(True, h)]     # a younger state than the f64 handle's: fewer ocean sub-steps
+        pair2 = next(((a, b) for a, b in ((legs2[0], legs2[1]), (legs2[2], legs2[1]), (legs2[2], legs2[3])) if a[1] == b[1]), (legs2[0], legs2[1]))
+        ms32, nsub32 = pair2[1]
+        a32, f32m = dev2.get("ECO_ALPHA"), dev2.get("ECO_F")
+        f32 = {"ms_per_step": ms32, "ms_per_step_without_ecology": pair2[0][0], "ocean_n_sub_of_the_pair": nsub32,
+               "legs_ms_nsub_A_B_A_B": [[round(a, 4), b] for a, b in legs2], "stored_as_f32": ["ECO_LAI", "ECO_LAI_SNAP", "ECO_F", "ECO_ALPHA", "ECO_ALPHA_BANDED",
+                                                                           "individual coefficient table"],
+               "kept_f64": ["E_day", "LAI plane sum", "lai-delta reduction", "all arithmetic"],
+               "alpha_max_abs_dev_vs_f64_maps": float(np.nanmax(np.abs(a32 - a64))), "canopy_factor_max_abs_dev_vs_f64_maps": float(np.max(np.abs(f32m - f64_))),
+               "dev_vs_reference_fixture": "tests/test_gpu_ecology.py::test_canopy_alpha_sequence_vs_reference[f32_maps] (eco_19x36*.npz): < 5e-7"}
+        dev2.close()
+    except Exception as e:       # noqa: BLE001
+        f32 = {"error": str(e)}
+    return {"ms_per_step": with_eco, "f32_maps": f32, "individual_substep_kernel_ms": ind_ms, "individual_substeps_timed": ind_n,
             "individual_substep_kernel_ms_f32_table": ind32_ms, "individual_table_bytes_f64": int(pool32.n_indiv) * int(eco.bands.nbands) * 8,
             "canopy_policy_launch_ms": can_ms, "canopy_policy_launches_timed": can_n, "ms_per_step_without_ecology": base, "bands": int(eco.bands.nbands),
             "species_planes": int(eco.pop.LAI_layers_SK.shape[0] * eco.pop.LAI_layers_SK.shape[1]),

@@ -195,7 +195,9 @@ typedef struct qd_eco_params {
     int32_t water_couple;        /* QD_PHYTO_ENABLE && QD_PHYTO_ALBEDO_COUPLE: ocean base albedo <- clip(WATER_ALPHA), :2121-2128 */
     int32_t use_lai;             /* QD_ECO_USE_LAI (1).  0 = the adapter's M1 branch (adapter.py:162-166): no population, no E_day,
                                     alpha = clip(leaf_scalar) on land */
-    int32_t reserved;
+    int32_t map_f32;             /* QD_ECO_F32 (0): store the canopy maps ECO_LAI, ECO_LAI_SNAP, ECO_F, ECO_ALPHA, ECO_ALPHA_BANDED as f32
+                                    (arithmetic, the LAI plane sum, the lai-delta reduction and E_day stay f64); qd_upload /
+                                    qd_download of these fields still exchange f64 with the host.  Fixed once the maps hold data. */
 } qd_eco_params;
 int qd_eco_configure(qd_handle h, const qd_eco_params* p, size_t sizeof_params);
 /* PopulationManager.total_LAI (population.py:288-294): layers = [n_planes][n_lat][n_lon] host f64 (the flattened

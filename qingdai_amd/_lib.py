@@ -48,7 +48,7 @@ class qd_eco_params(ctypes.Structure):
     """include/qingdai_hip.h: qd_eco_params"""
     _fields_ = ([(n, ctypes.c_double) for n in ("k_canopy", "leaf_scalar", "soil_ref", "w_lai", "light_update_hours",
                                                  "recompute_lai_delta")] +
-                [(n, ctypes.c_int32) for n in ("substep_every_nphys", "albedo_couple", "bands_couple", "water_couple", "use_lai", "reserved")])
+                [(n, ctypes.c_int32) for n in ("substep_every_nphys", "albedo_couple", "bands_couple", "water_couple", "use_lai", "map_f32")])
 
 
 class qd_grid_desc(ctypes.Structure):

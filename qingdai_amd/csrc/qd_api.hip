@@ -384,7 +384,10 @@ extern "C" int qd_upload(qd_handle c, int field, const void* host, size_t bytes)
     } else {
         if (field < 0 || field >= QD_F_COUNT_F64) return qd_fail(c, "qd_upload: unknown field");
         if (bytes != n * sizeof(double)) return qd_fail(c, "qd_upload: size mismatch (expect n_lat*n_lon float64)");
-        if (qd_band_copy_in(c, c->f[field], host, sizeof(double))) return qd_fail(c, "qd_upload: copy failed");
+        if (qd_eco_is_f32(c, field)) {                         // the slab stores f32: stage the f64 host map, round once
+            if (qd_band_copy_in(c, c->scratch[10], host, sizeof(double))) return qd_fail(c, "qd_upload: copy failed");
+            qd_eco_convert_slab(c, c->scratch[10], 0, c->f[field], 1);
+        } else if (qd_band_copy_in(c, c->f[field], host, sizeof(double))) return qd_fail(c, "qd_upload: copy failed");
         qd_mark(c, {c->f[field]}, c->geo.halo);
         if (field == QD_F_CLOUD_EFF) c->cloud_eff_valid = 1;
         if (field == QD_F_ELEVATION) c->has_elevation = 1;
@@ -419,6 +422,7 @@ extern "C" int qd_download(qd_handle c, int field, void* host, size_t bytes) {
     else {
         if (field < 0 || field >= QD_F_COUNT_F64) return qd_fail(c, "qd_download: unknown field");
         src = c->f[field]; esz = sizeof(double);
+        if (qd_eco_is_f32(c, field)) { qd_eco_convert_slab(c, c->f[field], 1, c->scratch[10], 0); src = c->scratch[10]; }
     }
     if (bytes != n * esz) return qd_fail(c, "qd_download: size mismatch");
     const size_t rowb = (size_t)G.nlon * esz;

@@ -18,12 +18,31 @@
 #include <cstring>
 #include <vector>
 
+// ------------------------------------------------------------------ map storage
+// qd_eco_params.map_f32 (QD_ECO_F32, BASELINE configs[4] "f32 mixed precision"): the canopy maps LAI_tot, its snapshot, the canopy
+// factor f and the two alpha maps are STORED as f32 in their slabs (same allocation, first half used); every kernel loads them
+// into f64, computes in f64 and rounds once on the store.  E_day, the plane sum of the LAI stack and the lai-delta reduction
+// stay f64.  f32: wave-uniform flag, the branch is free.
+__device__ __forceinline__ double qd_mld(const double* __restrict__ p, size_t o, int f32) {
+    return f32 ? (double)reinterpret_cast<const float*>(p)[o] : p[o];
+}
+__device__ __forceinline__ void qd_mst(double* __restrict__ p, size_t o, int f32, double v) {
+    if (f32) reinterpret_cast<float*>(p)[o] = (float)v; else p[o] = v;
+}
+
 // ------------------------------------------------------------------ kernels
 __global__ void __launch_bounds__(QD_BLOCK)
 k_eco_lai_accum(size_t n, const double* __restrict__ plane, double* __restrict__ lai, int first) {
     const size_t o = (size_t)blockIdx.x * QD_BLOCK + threadIdx.x;
     if (o >= n) return;
     lai[o] = first ? plane[o] : lai[o] + plane[o];            // np.sum(axis=(0,1)): plane after plane, s outer, k inner
+}
+
+// storage conversion of a whole slab (upload / download seam, end of the f64 plane sum); src and dst are different slabs
+__global__ void __launch_bounds__(QD_BLOCK)
+k_eco_convert(size_t n, const double* __restrict__ src, int src_f32, double* __restrict__ dst, int dst_f32) {
+    const size_t o = (size_t)blockIdx.x * QD_BLOCK + threadIdx.x;
+    if (o < n) qd_mst(dst, o, dst_f32, qd_mld(src, o, src_f32));
 }
 
 __global__ void __launch_bounds__(QD_BLOCK)
@@ -43,42 +62,42 @@ k_eco_eday(QdGeom G, const double* __restrict__ isr, double dt, double* __restri
 
 // f = 1 - exp(-k max(LAI_tot, 0)); snapshot <- LAI_tot          (population.py:911-915, 274-277)
 __global__ void __launch_bounds__(QD_BLOCK)
-k_eco_canopy(size_t n, const double* __restrict__ lai, double k, double* __restrict__ f, double* __restrict__ snap) {
+k_eco_canopy(size_t n, const double* __restrict__ lai, double k, double* __restrict__ f, double* __restrict__ snap, int f32) {
     const size_t o = (size_t)blockIdx.x * QD_BLOCK + threadIdx.x;
     if (o >= n) return;
-    const double L = lai[o];
-    f[o] = 1.0 - exp(-k * qd_max(L, 0.0));
-    snap[o] = L;
+    const double L = qd_mld(lai, o, f32);
+    qd_mst(f, o, f32, 1.0 - exp(-k * qd_max(L, 0.0)));
+    qd_mst(snap, o, f32, L);
 }
 
 // alpha = clip(leaf_s f + (1 - f) soil, 0, 1) on land, NaN elsewhere          (adapter.py:160-174)
 __global__ void __launch_bounds__(QD_BLOCK)
 k_eco_alpha(size_t n, const double* __restrict__ f, const uint8_t* __restrict__ land, double leaf_s, double soil,
-            double* __restrict__ alpha) {
+            double* __restrict__ alpha, int f32) {
     const size_t o = (size_t)blockIdx.x * QD_BLOCK + threadIdx.x;
     if (o >= n) return;
-    if (!f) { alpha[o] = (land[o] == 1) ? qd_clip(leaf_s, 0.0, 1.0) : NAN; return; }      // M1 branch: no population (adapter.py:162-166)
-    const double fv = f[o];
-    alpha[o] = (land[o] == 1) ? qd_clip(leaf_s * fv + (1.0 - fv) * soil, 0.0, 1.0) : NAN;
+    if (!f) { qd_mst(alpha, o, f32, (land[o] == 1) ? qd_clip(leaf_s, 0.0, 1.0) : NAN); return; }      // M1 branch: no population (adapter.py:162-166)
+    const double fv = qd_mld(f, o, f32);
+    qd_mst(alpha, o, f32, (land[o] == 1) ? qd_clip(leaf_s * fv + (1.0 - fv) * soil, 0.0, 1.0) : NAN);
 }
 
 struct QdBandR { double r[QD_MAXBANDS], w[QD_MAXBANDS]; int nb; };
 // clip(nansum_b A_b w_b, 0, 1) with A_b = clip(R_eff[b] f + (1 - f) soil, 0, 1) on land, NaN elsewhere (nansum of NaNs = 0)
 __global__ void __launch_bounds__(QD_BLOCK)
 k_eco_banded(size_t n, QdBandR W, const double* __restrict__ f, const uint8_t* __restrict__ land, double soil,
-             double* __restrict__ out) {
+             double* __restrict__ out, int f32) {
     const size_t o = (size_t)blockIdx.x * QD_BLOCK + threadIdx.x;
     if (o >= n) return;
     double acc = 0.0;
     if (land[o] == 1) {
-        const double fv = f[o];
+        const double fv = qd_mld(f, o, f32);
         for (int b = 0; b < W.nb; ++b) {
             const double t = qd_clip(W.r[b] * fv + (1.0 - fv) * soil, 0.0, 1.0) * W.w[b];
             const double tt = (t != t) ? 0.0 : t;              // nansum
             acc = (b == 0) ? tt : acc + tt;
         }
     }
-    out[o] = qd_clip(acc, 0.0, 1.0);
+    qd_mst(out, o, f32, qd_clip(acc, 0.0, 1.0));
 }
 
 __device__ __forceinline__ double qd_eco_wsum(double x) {
@@ -89,13 +108,13 @@ __device__ __forceinline__ double qd_eco_wsum(double x) {
 // four row partials of lai_delta_ratio (population.py:903-907): sum |now - snap| and count over non-NaN, sum max(snap, 1e-6)
 // and count over non-NaN
 __global__ void __launch_bounds__(QD_BLOCK)
-k_eco_ratio_rows(QdGeom G, const double* __restrict__ lai, const double* __restrict__ snap, double* __restrict__ partial) {
+k_eco_ratio_rows(QdGeom G, const double* __restrict__ lai, const double* __restrict__ snap, double* __restrict__ partial, int f32) {
     __shared__ double sm[4][QD_BLOCK / 64];
     const size_t b = (size_t)qd_lrow(G, G.row0 + blockIdx.x) * G.nlon;
     double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     for (int j = threadIdx.x; j < G.nlon; j += QD_BLOCK) {
-        const double s = snap[b + j];
-        const double d = fabs(lai[b + j] - s);
+        const double s = qd_mld(snap, b + j, f32);
+        const double d = fabs(qd_mld(lai, b + j, f32) - s);
         if (d == d) { a0 += d; a1 += 1.0; }
         const double m = qd_max(s, 1e-6);
         if (m == m) { a2 += m; a3 += 1.0; }
@@ -171,12 +190,24 @@ void qd_eco_free(qd_ctx* c) {
     E.n_indiv = E.n_cells = 0;
 }
 
+// fields whose slab holds f32 when map_f32 is set
+bool qd_eco_is_f32(const qd_ctx* c, int field) {
+    return c->eco.p.map_f32 && (field == QD_F_ECO_LAI || field == QD_F_ECO_LAI_SNAP || field == QD_F_ECO_F || field == QD_F_ECO_ALPHA ||
+                                field == QD_F_ECO_ALPHA_BANDED);
+}
+void qd_eco_convert_slab(qd_ctx* c, const double* src, int src_f32, double* dst, int dst_f32) {
+    const size_t n = c->geo.cells();
+    hipLaunchKernelGGL(k_eco_convert, flat_grid(n), dim3(QD_BLOCK), 0, c->stream, n, src, src_f32, dst, dst_f32);
+}
+
 extern "C" int qd_eco_configure(qd_handle c, const qd_eco_params* p, size_t sz) {
     if (!c || !p) return -1;
     if (sz != sizeof(qd_eco_params)) return qd_fail(c, "qd_eco_configure: struct size mismatch (ABI)");
     QdEco& E = c->eco;
     const bool first = !E.configured;
     if (!first && (p->leaf_scalar != E.p.leaf_scalar || p->soil_ref != E.p.soil_ref || p->use_lai != E.p.use_lai)) E.alpha_dirty = 1;
+    if (!first && (p->map_f32 != 0) != (E.p.map_f32 != 0) && (E.have_lai || E.alpha_valid || E.banded_valid))
+        return qd_fail(c, "qd_eco_configure: map_f32 cannot change once the canopy maps hold data");
     E.p = *p;
     if (first) E.next_h = p->light_update_hours;               // population.py:72
     E.configured = 1;
@@ -189,11 +220,14 @@ extern "C" int qd_eco_set_lai_layers(qd_handle c, const double* layers, int n_pl
     const size_t n = c->geo.cells(), plane = (size_t)c->geo.nlat * c->geo.nlon;
     double* stage = c->scratch[10];
     double* lai = c->f[QD_F_ECO_LAI];
+    const int f32 = c->eco.p.map_f32 ? 1 : 0;
+    double* acc = f32 ? c->scratch[11] : lai;                   // the plane sum is a reduction: f64 whatever the storage
     for (int k = 0; k < n_planes; ++k) {
         if (qd_band_copy_in(c, stage, layers + (size_t)k * plane, sizeof(double))) return qd_fail(c, "qd_eco_set_lai_layers: copy failed");
-        hipLaunchKernelGGL(k_eco_lai_accum, flat_grid(n), dim3(QD_BLOCK), 0, c->stream, n, stage, lai, k == 0 ? 1 : 0);
+        hipLaunchKernelGGL(k_eco_lai_accum, flat_grid(n), dim3(QD_BLOCK), 0, c->stream, n, stage, acc, k == 0 ? 1 : 0);
         QD_HIP(c, hipStreamSynchronize(c->stream));             // the staging slab is reused; the host buffer is borrowed
     }
+    if (f32) hipLaunchKernelGGL(k_eco_convert, flat_grid(n), dim3(QD_BLOCK), 0, c->stream, n, acc, 0, lai, 1);
     QdEco& E = c->eco;
     E.have_lai = 1; E.lai_version++;
     if (init) {
@@ -210,7 +244,7 @@ extern "C" int qd_eco_set_lai_layers(qd_handle c, const double* layers, int n_pl
 static int eco_ratio(qd_ctx* c, double* ratio) {
     const QdGeom G = qd_segments(c, 0).g[0];
     hipLaunchKernelGGL(k_eco_ratio_rows, dim3(G.nrows), dim3(QD_BLOCK), 0, c->stream, G, c->f[QD_F_ECO_LAI], c->f[QD_F_ECO_LAI_SNAP],
-                       c->red_partial);
+                       c->red_partial, c->eco.p.map_f32 ? 1 : 0);
     hipLaunchKernelGGL(k_eco_ratio_finish, dim3(1), dim3(QD_BLOCK), 0, c->stream, c->red_partial, G.nrows, c->dscal + QD_S_DIAG0);
     if (qd_allreduce_f64(c, c->dscal + QD_S_DIAG0, 4, 0)) return -1;
     QD_HIP(c, hipMemcpyAsync(c->hpin, c->dscal + QD_S_DIAG0, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -229,7 +263,7 @@ int qd_eco_canopy_impl(qd_ctx* c, double dt) {
         E.count++;
         if (E.count % std::max(1, (int)E.p.substep_every_nphys) == 0 && (E.alpha_dirty || !E.alpha_valid)) {
             hipLaunchKernelGGL(k_eco_alpha, flat_grid(n), dim3(QD_BLOCK), 0, c->stream, n, (const double*)nullptr, c->land,
-                               E.p.leaf_scalar, E.p.soil_ref, c->f[QD_F_ECO_ALPHA]);
+                               E.p.leaf_scalar, E.p.soil_ref, c->f[QD_F_ECO_ALPHA], E.p.map_f32 ? 1 : 0);
             qd_mark(c, {c->f[QD_F_ECO_ALPHA]}, c->geo.halo);
             E.alpha_valid = 1; E.alpha_dirty = 0;
         }
@@ -247,7 +281,7 @@ int qd_eco_canopy_impl(qd_ctx* c, double dt) {
     }
     if (rec) {
         hipLaunchKernelGGL(k_eco_canopy, flat_grid(n), dim3(QD_BLOCK), 0, c->stream, n, c->f[QD_F_ECO_LAI], E.p.k_canopy,
-                           c->f[QD_F_ECO_F], c->f[QD_F_ECO_LAI_SNAP]);
+                           c->f[QD_F_ECO_F], c->f[QD_F_ECO_LAI_SNAP], E.p.map_f32 ? 1 : 0);
         qd_mark(c, {c->f[QD_F_ECO_F], c->f[QD_F_ECO_LAI_SNAP]}, c->geo.halo);
         E.f_valid = 1; E.alpha_dirty = 1; E.snap_version = E.lai_version; E.n_recompute++;
         E.next_h = E.hours + E.p.light_update_hours;
@@ -255,7 +289,7 @@ int qd_eco_canopy_impl(qd_ctx* c, double dt) {
     const int every = std::max(1, (int)E.p.substep_every_nphys);
     if (E.count % every == 0 && (E.alpha_dirty || !E.alpha_valid)) {
         hipLaunchKernelGGL(k_eco_alpha, flat_grid(n), dim3(QD_BLOCK), 0, c->stream, n, c->f[QD_F_ECO_F], c->land, E.p.leaf_scalar,
-                           E.p.soil_ref, c->f[QD_F_ECO_ALPHA]);
+                           E.p.soil_ref, c->f[QD_F_ECO_ALPHA], E.p.map_f32 ? 1 : 0);
         qd_mark(c, {c->f[QD_F_ECO_ALPHA]}, c->geo.halo);
         E.alpha_valid = 1; E.alpha_dirty = 0;
     }
@@ -290,13 +324,13 @@ extern "C" int qd_eco_banded_alpha(qd_handle c, int nb, const double* r_eff, con
     const size_t n = c->geo.cells();
     if (!E.f_valid) {                                           // canopy_reflectance_factor builds the cache on demand (population.py:837-838)
         hipLaunchKernelGGL(k_eco_canopy, flat_grid(n), dim3(QD_BLOCK), 0, c->stream, n, c->f[QD_F_ECO_LAI], E.p.k_canopy,
-                           c->f[QD_F_ECO_F], c->scratch[10]);
+                           c->f[QD_F_ECO_F], c->scratch[10], E.p.map_f32 ? 1 : 0);
         E.f_valid = 1; E.alpha_dirty = 1; E.n_recompute++;
     }
     QdBandR W; W.nb = nb;
     for (int b = 0; b < QD_MAXBANDS; ++b) { W.r[b] = b < nb ? r_eff[b] : 0.0; W.w[b] = b < nb ? w_b[b] : 0.0; }
     hipLaunchKernelGGL(k_eco_banded, flat_grid(n), dim3(QD_BLOCK), 0, c->stream, n, W, c->f[QD_F_ECO_F], c->land, E.p.soil_ref,
-                       c->f[QD_F_ECO_ALPHA_BANDED]);
+                       c->f[QD_F_ECO_ALPHA_BANDED], E.p.map_f32 ? 1 : 0);
     qd_mark(c, {c->f[QD_F_ECO_ALPHA_BANDED], c->f[QD_F_ECO_F]}, c->geo.halo);
     E.banded_valid = 1;
     hipError_t e = hipGetLastError();

@@ -320,6 +320,8 @@ void qd_eco_free(qd_ctx* c);
 int  qd_band_copy_in(qd_ctx* c, void* dst, const void* host, size_t esz);   // qd_api.hip
 int  qd_phyto_step_impl(qd_ctx* c, double dt);                              // qd_phyto.hip
 void qd_phyto_release(qd_ctx* c);
+bool qd_eco_is_f32(const qd_ctx* c, int field);                             // qd_eco.hip: slab stored as f32 (qd_eco_params.map_f32)
+void qd_eco_convert_slab(qd_ctx* c, const double* src, int src_f32, double* dst, int dst_f32);
 
 // qd_reduce.hip
 int qd_reduce_field(qd_ctx* c, const double* x, int op, double* host_out);

@@ -176,7 +176,7 @@ k_cloud_blend(QdGeom G, QdBlendP P, const double* __restrict__ cfp, const double
     cloud[o] = qd_clip(c, 0.0, 1.0);
 }
 
-struct QdAlbP { double alpha, hice_ref_safe, alpha_ice, alpha_cloud, alpha_water, alpha_snow, w_lai; int do_adv, use_topo, snow, eco, banded, water; };
+struct QdAlbP { double alpha, hice_ref_safe, alpha_ice, alpha_cloud, alpha_water, alpha_snow, w_lai; int do_adv, use_topo, snow, eco, banded, water, eco_f32; };
 
 // cloud <- clip((1-a) cloud + a adv, 0, 1)  and  the dynamic albedo (physics.py:164-250)
 __global__ void __launch_bounds__(QD_BLOCK)
@@ -198,11 +198,11 @@ k_cloud_albedo(QdGeom G, QdAlbP P, const double* __restrict__ adv, double* __res
     fi = fi * ((land[o] == 0) ? 1.0 : 0.0);
     double b0 = P.use_topo ? base[o] : P.alpha_water;
     if (P.eco && land[o] == 1 && glacier[o] == 0.0) {        // run_simulation.py:2086-2100: ecology alpha, not on ice sheets
-        const double ae = eco_alpha[o];
+        const double ae = P.eco_f32 ? (double)reinterpret_cast<const float*>(eco_alpha)[o] : eco_alpha[o];
         if (fabs(ae) <= DBL_MAX) b0 = (1.0 - P.w_lai) * b0 + P.w_lai * ae;
     }
     if (P.banded && land[o] == 1) {                          // run_simulation.py:2107-2112: daily banded alpha
-        const double ab = banded[o];
+        const double ab = P.eco_f32 ? (double)reinterpret_cast<const float*>(banded)[o] : banded[o];
         if (fabs(ab) <= DBL_MAX) b0 = qd_clip(ab, 0.0, 1.0);
     }
     if (P.water && land[o] == 0) {                           // run_simulation.py:2121-2128: ocean colour
@@ -486,7 +486,7 @@ int qd_driver_physics_impl(qd_ctx* c, double dt) {
         QdAlbP A{p.cloud_adv_alpha, std::max(1e-6, p.hice_ref), p.alpha_ice, p.alpha_cloud, p.alpha_water, p.snow_albedo_fresh, E.p.w_lai,
                  p.cloud_advect ? 1 : 0, p.use_topo_albedo ? 1 : 0, p.swe_enable ? 1 : 0,
                  (E.configured && E.p.albedo_couple && E.alpha_valid) ? 1 : 0, (E.configured && E.p.bands_couple && E.banded_valid) ? 1 : 0,
-                 (E.configured && E.p.water_couple && E.water_valid) ? 1 : 0};
+                 (E.configured && E.p.water_couple && E.water_valid) ? 1 : 0, (E.configured && E.p.map_f32) ? 1 : 0};
         if (A.eco) { const int me = qd_plan(c, {QD_IN(F[QD_F_ECO_ALPHA], 0)}); if (me < 0) return -1; m = std::min(m, me); }
         if (A.banded) { const int me = qd_plan(c, {QD_IN(F[QD_F_ECO_ALPHA_BANDED], 0)}); if (me < 0) return -1; m = std::min(m, me); }
         if (A.water) { const int me = qd_plan(c, {QD_IN(F[QD_F_WATER_ALPHA], 0)}); if (me < 0) return -1; m = std::min(m, me); }

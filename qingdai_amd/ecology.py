@@ -156,7 +156,9 @@ class AdapterConfig:
 
 
 class EcologyAdapter:
-    def __init__(self, grid, land_mask, dev=None, albedo_couple=None):
+    def __init__(self, grid, land_mask, dev=None, albedo_couple=None, f32_maps=None):
+        """f32_maps: None = QD_ECO_F32 (0) -- store the canopy maps (LAI_tot, snapshot, f, alpha, banded alpha) as f32 on the device
+        (BASELINE configs[4] "f32 mixed precision"); arithmetic, reductions and E_day stay f64."""
         self.grid = grid
         self._dev = dev if dev is not None else getattr(grid, "_device", None)
         if self._dev is None:
@@ -177,7 +179,8 @@ class EcologyAdapter:
             substep_every_nphys=max(1, self.cfg.substep_every_nphys), albedo_couple=1 if albedo_couple else 0,
             bands_couple=1 if _envi("QD_ECO_BANDS_COUPLE", 0) == 1 else 0,
             water_couple=1 if (_envi("QD_PHYTO_ENABLE", 0) == 1 and _envi("QD_PHYTO_ALBEDO_COUPLE", 1) == 1) else 0,
-            use_lai=1 if _envi("QD_ECO_USE_LAI", 1) == 1 else 0, reserved=0)
+            use_lai=1 if _envi("QD_ECO_USE_LAI", 1) == 1 else 0,
+            map_f32=1 if ((_envi("QD_ECO_F32", 0) == 1) if f32_maps is None else bool(f32_maps)) else 0)
         self.configure()
         self._count = 0
         self.pop = None
