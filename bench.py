@@ -264,9 +264,11 @@ def main():
         dev.lib.qd_comm_host_allreduce_count(dev.h, _ct.byref(nh))
         comm0 = (ne.value, na.value, nh.value)
     also = "k_ocn_hyper" if (with_ocean and args.profile_kernel != "k_ocn_hyper") else None
-    # HIP-event brackets inside the timed region, SAMPLED: an event pair idles the stream for ~5 us per bracket (kernel trace,
-    # profiles/README.md), 14 brackets a step were 7 % of the step.  The per-step kernel is bracketed on ~16 steps of the K, the
-    # per-sub-step kernel on every 16th launch (about one a step).
+    # HIP events inside the timed region, on the handle's stream, SAMPLED.  The two profiled kernels are single launches whose start /
+    # stop events ride on the dispatch itself (hipExtLaunchKernelGGL: the timestamps of the dispatch's completion signal, the interval
+    # the rocprofv3 kernel trace reports); a timed dispatch still idles the stream for a few us (kernel trace, profiles/README.md: 14
+    # timed launches a step were 7 % of the step), so the per-step kernel is timed on ~16 steps of the K and the per-sub-step kernel
+    # on every 16th launch (about one a step).
     s_main = max(1, K // 16) if args.timing_stride < 0 else max(1, args.timing_stride)
     s_also = 16 if args.timing_stride < 0 else max(1, args.timing_stride)
     dev.timing(select=f"{args.profile_kernel}:{s_main}" + (f",{also}:{s_also}" if also else ""))
@@ -327,7 +329,7 @@ def main():
     # What cannot be measured from inside this process comes from the committed rocprofv3 summaries of this same command
     # (profiles/, one pass per counter as MI355X_MICROARCH.md prescribes), when they cover this kernel and grid -- else null:
     #   traffic                 FETCH_SIZE (x2: gfx950 correction) + WRITE_SIZE per launch, bytes
-    #   avg_kernel_ms_rocprof   the kernel-trace duration (the HIP-event pair above also brackets the ~3 us dispatch gap)
+    #   avg_kernel_ms_rocprof   the kernel-trace duration of the committed profile (the events above time the same interval live)
     try:
         prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_fused_kernels.json")
         with open(prof) as fh:

@@ -20,7 +20,7 @@ static hipEvent_t qd_get_event(qd_ctx* c) {
     hipEventCreate(&e);
     return e;
 }
-QdScope::QdScope(qd_ctx* c_, const char* n) : c(c_), name(n) {
+QdScope::QdScope(qd_ctx* c_, const char* n, bool attach_) : c(c_), name(n), attach(attach_) {
     on = c->timing == 1;
     if (c->timing == 2) {                       // selection: "name[:stride]" or a comma-separated list of them
         const std::string& sel = c->timing_sel;
@@ -34,10 +34,10 @@ QdScope::QdScope(qd_ctx* c_, const char* n) : c(c_), name(n) {
             on = (c->timing_seen[n]++ % stride) == 0;
         }
     }
-    if (on) { e0 = qd_get_event(c); e1 = qd_get_event(c); hipEventRecord(e0, c->stream); }
+    if (on) { e0 = qd_get_event(c); e1 = qd_get_event(c); if (!attach) hipEventRecord(e0, c->stream); }
 }
 QdScope::~QdScope() {
-    if (on) { hipEventRecord(e1, c->stream); c->pending.push_back({e0, e1, name}); }
+    if (on) { if (!attach) hipEventRecord(e1, c->stream); c->pending.push_back({e0, e1, name}); }
 }
 static void qd_resolve_timers(qd_ctx* c) {
     if (c->pending.empty()) return;

@@ -8,6 +8,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <string>
 #include <vector>
@@ -250,10 +251,16 @@ int qd_fail(qd_ctx* c, const char* what, hipError_t e = hipSuccess);
 #define QD_HIP(c, call) do { hipError_t _e = (call); if (_e != hipSuccess) return qd_fail((c), #call, _e); } while (0)
 
 struct QdScope {               // optional per-kernel-group timing with hipEvents on the handle's stream
-    qd_ctx* c; const char* name; hipEvent_t e0 = nullptr, e1 = nullptr; bool on = false;
-    QdScope(qd_ctx* c_, const char* n);
+    qd_ctx* c; const char* name; hipEvent_t e0 = nullptr, e1 = nullptr; bool on = false, attach = false;
+    // attach_ = true: the group is ONE launch and the caller hands e0 / e1 to hipExtLaunchKernelGGL (QD_LAUNCH_TIMED), which takes
+    // the start / stop time from the dispatch itself (what the rocprofv3 kernel trace reports); otherwise the events are recorded
+    // around the group, and the pair also brackets the dispatch gaps on either side (~3.5 us per bracket on this stack)
+    QdScope(qd_ctx* c_, const char* n, bool attach_ = false);
     ~QdScope();
 };
+#define QD_LAUNCH_TIMED(sc, kernel, grid, block, stream, ...) do { \
+    if ((sc).on && (sc).attach) hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, (sc).e0, (sc).e1, 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__); } while (0)
 
 // ---- latitude-band planning (qd_band.hip) ----------------------------------------------------
 #define QD_IN(ptr, r) QdUse{(void**)&(ptr), (r), 0}

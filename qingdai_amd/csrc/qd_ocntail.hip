@@ -411,18 +411,18 @@ int qd_ocn_tail_tiles(const qd_ctx* c, const QdGeom& G) {
 
 int qd_launch_ocn_tail(qd_ctx* c, const QdGeom& G, QdTailArgs& P) {
     if (G.nlon < 64 || !G.full) return qd_fail(c, "k_ocn_tail: whole-globe handles of >= 64 columns only");
-    QdScope sc(c, "ocean_tail");
+    QdScope sc(c, "ocean_tail", true);
     if (c->ocn_tail == 2) {                                  // LDS-tiled form
         P.ntc = (G.nlon + QT_TC - 1) / QT_TC;
         const int ntr = (G.nrows + QT_TR - 1) / QT_TR;
         if (ntr * P.ntc > c->red_blocks) return qd_fail(c, "k_ocn_tail: partial buffer too small");
-        hipLaunchKernelGGL(k_ocn_tail, dim3(ntr * P.ntc), dim3(256), 0, c->stream, G, c->tabs, P);
+        QD_LAUNCH_TIMED(sc, k_ocn_tail, dim3(ntr * P.ntc), dim3(256), c->stream, G, c->tabs, P);
         return 0;
     }
     P.R = qt_rows(c);
     P.ntc = (G.nlon + QS_TC2 - 1) / QS_TC2;
     const int nrs = (G.nrows + P.R - 1) / P.R;
     if (nrs * P.ntc > c->red_blocks) return qd_fail(c, "k_ocn_tail_stream: partial buffer too small");
-    hipLaunchKernelGGL(k_ocn_tail_stream, dim3(nrs * P.ntc), dim3(128), 0, c->stream, G, c->tabs, P);
+    QD_LAUNCH_TIMED(sc, k_ocn_tail_stream, dim3(nrs * P.ntc), dim3(128), c->stream, G, c->tabs, P);
     return 0;
 }

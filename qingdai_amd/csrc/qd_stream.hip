@@ -656,12 +656,12 @@ int qd_launch_dyn_stream(qd_ctx* c, const QdDynArgs& P, int margin) {
     for (int f = 0; f < 5; ++f) A.rec[f] = QsRec{in[f], aux[f], out[f], tab + (size_t)f * c->geo.nlat * 4, P.skip[f], 0};
     A.dt = P.dt; A.inv_dlon = P.inv_dlon; A.inv_2dlon = P.inv_2dlon; A.inv_dlat = P.inv_dlat; A.inv_2dlat = P.inv_2dlat; A.pgf_y = P.pgf_y;
     A.exact = c->fused_fast == 2;
-    QdScope sc(c, "k_dyn_hyper");
+    QdScope sc(c, "k_dyn_hyper", c->geo.full != 0);          // whole globe: one launch, timed by the dispatch itself
     QD_ROWS(c, margin, G,
             const QsShape sh = qs_shape(c, G.nrows, G.nlon, P.primitive ? 1 : 0);
             A.G = G; A.R = sh.R; A.nrs = sh.nrs; A.ntc = (G.nlon + QS_TC - 1) / QS_TC;
-            if (P.primitive) hipLaunchKernelGGL(k_dyn_stream<true>, dim3(A.nrs * A.ntc), dim3(320), 0, c->stream, A);
-            else hipLaunchKernelGGL(k_dyn_stream<false>, dim3(A.nrs * A.ntc), dim3(320), 0, c->stream, A));
+            if (P.primitive) QD_LAUNCH_TIMED(sc, k_dyn_stream<true>, dim3(A.nrs * A.ntc), dim3(320), c->stream, A);
+            else QD_LAUNCH_TIMED(sc, k_dyn_stream<false>, dim3(A.nrs * A.ntc), dim3(320), c->stream, A));
     return 0;
 }
 
@@ -692,10 +692,10 @@ int qd_launch_ocn_stream(qd_ctx* c, const QdOcnArgs& P, int margin) {
     A.eta_mean = P.eta_mean; A.eta_cap = P.eta_cap; A.sub_dt = P.sub_dt; A.g = P.g; A.r_bot = P.r_bot;
     A.inv_2dlon = P.inv_2dlon; A.inv_2dlat = P.inv_2dlat; A.inv_a = P.inv_a; A.inv_rhoH = P.inv_rhoH;
     A.exact = c->fused_fast == 2;
-    QdScope sc(c, "k_ocn_hyper");
+    QdScope sc(c, "k_ocn_hyper", c->geo.full != 0);
     QD_ROWS(c, margin, G,
             const QsShape sh = qs_shape(c, G.nrows, G.nlon, 2);
             A.G = G; A.R = sh.R; A.nrs = sh.nrs; A.ntc = (G.nlon + QS_TC - 1) / QS_TC;
-            hipLaunchKernelGGL(k_ocn_stream, dim3(A.nrs * A.ntc), dim3(192), 0, c->stream, A));
+            QD_LAUNCH_TIMED(sc, k_ocn_stream, dim3(A.nrs * A.ntc), dim3(192), c->stream, A));
     return 0;
 }

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Turns the output of scripts/profile_round.sh (gpurun_out/<tag>/) into the committed summaries profiles/<tag>_*:
+kernel stats / trace summary / step timeline / bench lines (copied), <tag>_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE per launch),
+<tag>_pmc_sq.json and <tag>_fused_kernels.json (what bench.py reads for roofline.traffic / avg_kernel_ms_rocprof).
+usage: assemble_profiles.py <tag> [tcc.json]"""
+import json
+import os
+import re
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    tag = sys.argv[1]
+    R = os.path.join(ROOT, "gpurun_out", tag)
+    P = os.path.join(ROOT, "profiles")
+    for src, dst in (("kernel_stats.csv", "kernel_stats.csv"), ("kernel_trace_summary.txt", "kernel_trace_summary.txt"),
+                     ("step_timeline.txt", "step_timeline.txt"), ("bench.json", "bench.json"), ("bench_under_trace.json", "bench_under_trace.json")):
+        shutil.copy(os.path.join(R, src), os.path.join(P, f"{tag}_{dst}"))
+    f = json.load(open(os.path.join(R, "fetch.json"))); w = json.load(open(os.path.join(R, "write.json")))
+    s = json.load(open(os.path.join(R, "sq.json")))
+    t = json.load(open(sys.argv[2])) if len(sys.argv) > 2 else {}
+    tr = {}
+    for line in open(os.path.join(R, "kernel_trace_summary.txt")):
+        m = re.match(r"(.*?)\s+wgs=\s*(\d+)\s+n=\s*(\d+)\s+mean\s+([\d.]+) us", line)
+        if not m:
+            continue
+        name, n, mean = m.group(1).strip(), int(m.group(3)), float(m.group(4))
+        n0, m0 = tr.get(name, (0, 0.0))
+        tr[name] = (n0 + n, (m0 * n0 + mean * n) / (n0 + n))
+    cells = 721 * 1440
+    cal = "k_precip_blend"
+    traffic = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, no stats/sys-trace; scripts/profile_round.sh) "
+                       "of `bench.py --no-cpu-baseline --no-ecology-leg --steps 12 --warmup 4`; mean per dispatch, counters in KiB.  Correction per "
+                       "MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half the bytes of a coalesced streaming read -> x2, re-calibrated on "
+                       "k_precip_blend (reads two fields, writes one).  Memory-side (fabric) requests: Infinity-Cache hits are counted.",
+               "calibration": {"kernel": cal, "known_read_KiB": 2 * cells * 8 / 1024.0, "FETCH_SIZE_KiB": f[cal]["FETCH_SIZE"],
+                               "known_write_KiB": cells * 8 / 1024.0, "WRITE_SIZE_KiB": w[cal]["WRITE_SIZE"]}, "kernels": {}}
+    for k in f:
+        if k.startswith("__amd"):
+            continue
+        rd = f[k]["FETCH_SIZE"] * 1024 * 2; wr = w.get(k, {}).get("WRITE_SIZE", 0) * 1024
+        traffic["kernels"][k] = {"read_bytes": rd, "write_bytes": wr, "traffic_bytes": rd + wr, "dispatches": f[k]["_dispatches"]}
+    json.dump(traffic, open(os.path.join(P, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+    sq = {"_how": "rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU "
+                  "SQ_INSTS_SALU SQ_INSTS_VMEM_RD (own pass), mean per dispatch.  SQ cycle counters are in quad-cycles; WAIT_ANY (parked on "
+                  "s_waitcnt) + WAIT_INST_ANY (issue stall) + ACTIVE_INST_ANY ~ WAVE_CYCLES.  TCC_* (when present) from a further pass "
+                  "(--pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum), 128-B requests.", "kernels": {}}
+    for k in s:
+        if "stream" in k or "tail" in k:
+            e = {a: round(b) for a, b in s[k].items() if not a.startswith("_")}
+            e.update({a: round(b) for a, b in t.get(k, {}).items() if not a.startswith("_")})
+            sq["kernels"][k] = e
+    json.dump(sq, open(os.path.join(P, f"{tag}_pmc_sq.json"), "w"), indent=1)
+    fk = {"grid": [721, 1440], "source": f"rocprofv3 kernel trace + FETCH_SIZE / WRITE_SIZE passes of bench.py (scripts/profile_round.sh {tag}, "
+                                         f"scripts/assemble_profiles.py); profiles/README.md", "kernels": {}}
+    dyn = next(k for k in tr if "k_dyn_stream" in k)
+    for grp, kn in (("k_dyn_hyper", dyn), ("k_ocn_hyper", "k_ocn_stream"), ("ocean_tail", "k_ocn_tail_stream")):
+        fk["kernels"][grp] = {"trace_kernel": kn, "traffic_bytes": traffic["kernels"][kn]["traffic_bytes"],
+                              "read_bytes": traffic["kernels"][kn]["read_bytes"], "write_bytes": traffic["kernels"][kn]["write_bytes"],
+                              "avg_kernel_ms_rocprof": tr[kn][1] / 1e3, "launches_in_trace": tr[kn][0]}
+    json.dump(fk, open(os.path.join(P, f"{tag}_fused_kernels.json"), "w"), indent=1)
+    print(json.dumps(fk, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -25,7 +25,10 @@ def main():
     dev.sync()
     k = 24
     for R in rs:
-        os.environ["QD_STREAM_R"] = str(R)
+        if R > 0:
+            os.environ["QD_STREAM_R"] = str(R)
+        else:
+            os.environ.pop("QD_STREAM_R", None)                  # 0: the library's own choice
         dev.timing(select="k_dyn_hyper,k_ocn_hyper")
         t0 = time.perf_counter()
         dev.step_n(stars[k:k + 12], dt, with_ocean=True, with_physics=True, pass_albedo=True)
