@@ -250,6 +250,7 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
     { const char* ef = std::getenv("QD_FUSED"); if (ef && ef[0] == '0') c->use_fused = 0; }
     { const char* ef = std::getenv("QD_FUSED_FAST"); if (ef) c->fused_fast = std::atoi(ef); }
     { const char* ef = std::getenv("QD_STREAM_R"); if (ef) c->stream_rows = std::max(1, std::atoi(ef)); }
+    { const char* ef = std::getenv("QD_TAIL_ACC"); if (ef) c->tail_acc = std::atoi(ef); }
     { const char* ef = std::getenv("QD_SHAPIRO_STREAM"); if (ef) c->shapiro_stream = std::atoi(ef); }
     { const char* ef = std::getenv("QD_OCN_TAIL"); if (ef) c->ocn_tail = std::atoi(ef); }   // 0: two launches (k_cont_sstadv, k_sst_outlier_fused); 1: k_ocn_tail_stream (default); 2: LDS-tiled k_ocn_tail
     c->geo = QdGeom{d->n_lat, d->n_lon, d->row0, d->n_rows, d->halo, full ? 1 : 0, d->row0 - d->halo, d->n_rows + 2 * d->halo};
@@ -279,6 +280,8 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
     if ((e = hipMalloc(&c->red_partial, (size_t)c->red_blocks * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc(&c->dscal, QD_S_COUNT * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc(&c->dcount, 32 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc(&c->eta_acc, 512 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+    hipMemsetAsync(c->eta_acc, 0, 512 * sizeof(unsigned long long), c->stream);
     if ((e = hipMalloc(&c->hist, 2 * QD_HIST_BINS * sizeof(unsigned int))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc(&c->sel_state, 8 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
     hipMemsetAsync(c->dscal, 0, QD_S_COUNT * sizeof(double), c->stream);
@@ -336,6 +339,7 @@ extern "C" int qd_destroy(qd_handle c) {
     if (c->land) hipFree(c->land); if (c->icemask) hipFree(c->icemask);
     if (c->k4_atm) hipFree(c->k4_atm); if (c->k4_ocn) hipFree(c->k4_ocn); for (int k = 0; k < 2; ++k) if (c->qs_tab[k]) hipFree(c->qs_tab[k]);
     if (c->red_partial) hipFree(c->red_partial); if (c->dscal) hipFree(c->dscal);
+    if (c->eta_acc) hipFree(c->eta_acc);
     if (c->dcount) hipFree(c->dcount); if (c->hist) hipFree(c->hist); if (c->sel_state) hipFree(c->sel_state);
     if (c->zonal_tw) hipFree(c->zonal_tw);
     if (c->bands) hipFree(c->bands);

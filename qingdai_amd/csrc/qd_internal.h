@@ -200,6 +200,8 @@ struct qd_ctx {
     int use_fused = 1;              // QD_FUSED=0 selects the unfused reference-order kernels
     int fused_fast = 1;             // QD_FUSED_FAST: 1 row-streaming kernels (qd_stream.hip), FAST variant with per-wave EXACT fallback; 2 the same kernels,
                                     // every wave EXACT; 0 LDS-tiled kernels (qd_fused.hip), every tile EXACT; 3 LDS-tiled kernels with their FAST path
+    int tail_acc = 1;               // QD_TAIL_ACC=0: the eta mean of a sub-step from k_eta_mean_tail instead of the tail kernel's own last workgroup
+    unsigned long long* eta_acc = nullptr;   // accumulator + tickets of the tail kernel's strip sums (qd_wave.h: QD_ACC_WORDS)
     int shapiro_stream = 1;         // QD_SHAPIRO_STREAM=0: one k_shapiro_pass launch per pass
     int ocn_tail = 1;               // QD_OCN_TAIL=0: continuity + SST + outlier filter as the two launches of qd_ocean.hip
     int stream_rows = 0;            // QD_STREAM_R: strip height of the row-streaming kernels (0 = pick per launch)

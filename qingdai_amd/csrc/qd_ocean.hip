@@ -691,6 +691,9 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
     // two-level tickets (+12 us per sub-step: ticket round trips, acquire fence and read-back form a serial chain at the very end
     // of the launch); every wave of the next momentum kernel adding the ~1100 sums itself (+3.7 us per launch).
     const bool use_tail = c->use_fused && !band && defer_eta && G0.nlon >= 64 && c->ocn_tail;
+    // QD_TAIL_ACC (default): the streaming tail kernel reduces its own strip sums (fixed-point atomics + spread tickets, qd_wave.h)
+    // and its last workgroup writes the mean -- no k_eta_mean_tail launch (4.5 us of launch floor per sub-step)
+    const bool tail_acc = use_tail && c->ocn_tail == 1 && c->tail_acc;
     for (int s = 0; s < n_sub; ++s) {
         if (do_diff && c->use_fused && p.ocean_k4_nsub == 1) {
             const int m = qd_plan(c, {QD_IN(F[QD_F_ETA], 5), QD_IN(F[QD_F_UO], 4), QD_IN(F[QD_F_VO], 4), QD_IN(taux, 4),
@@ -752,8 +755,10 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
             A.use_q = HP.use_q; A.has_ice = HP.has_ice; A.mean4 = p.ocean_outlier == 0 ? 1 : 0;
             A.r_a = 1.0 / p.a; A.r_dlon = 1.0 / c->dlon; A.r_dlat = 1.0 / c->dlat; A.r_2dlon = 1.0 / (2 * c->dlon); A.r_2dlat = 1.0 / (2 * c->dlat);
             A.r_rcH = 1.0 / HP.rcH;
+            A.acc = tail_acc ? c->eta_acc : nullptr; A.mean_out = c->dscal + QD_S_ETA_MEAN; A.wsum = c->wsum_ocean;
             if (qd_launch_ocn_tail(c, Gown, A)) return -1;
-            hipLaunchKernelGGL(k_eta_mean_tail, dim3(1), dim3(256), 0, c->stream, c->red_partial, qd_ocn_tail_tiles(c, Gown), c->wsum_ocean,
+            if (!tail_acc)
+                hipLaunchKernelGGL(k_eta_mean_tail, dim3(1), dim3(256), 0, c->stream, c->red_partial, qd_ocn_tail_tiles(c, Gown), c->wsum_ocean,
                                    c->dscal + QD_S_ETA_MEAN);
             qd_swap(c, QD_F_SST, 1); qd_swap(c, QD_F_UO, 2); qd_swap(c, QD_F_VO, 3);
         } else if (c->use_fused) {

@@ -6,6 +6,9 @@ struct QdTailArgs {
     const double *uo, *vo, *Ts, *qnet;
     const uint8_t *land, *ice;
     double *eta, *Ts_out, *uo_out, *vo_out, *partial;
+    unsigned long long* acc;                                 // fixed-point accumulator + tickets of the strip sums (qd_wave.h), or nullptr
+    double* mean_out;                                        // acc != nullptr: the last workgroup writes sum / (wsum + 1e-15) here
+    double wsum;
     double a, dlat, dlon, sub_dt, msdtH, alpha, K_h, rcH, ice_qfac, cap;
     double r_a, r_dlon, r_dlat, r_2dlon, r_2dlat, r_rcH;     // correctly rounded reciprocals of a, dlon, dlat, 2 dlon, 2 dlat, rcH (host)
     int use_q, has_ice, mean4, ntc, R, pad_;                 // R: strip height of the streaming form

@@ -390,7 +390,14 @@ k_ocn_tail_stream(QdGeom G, QdTabs T, QdTailArgs P) {
     if (wv == 1) { __builtin_amdgcn_s_setprio(2); qt_sst_wave(G, T, P, W); return; }      // the SST wave is the long one
     double acc = qt_currents_wave(T, P, W);
     acc = qt_wave_sum(acc);
-    if (W.lane == 0) P.partial[w] = acc;
+    if (W.lane == 0) __hip_atomic_store(P.partial + w, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // coherent: the finisher may read it
+    if (P.acc) {                                             // eta mean inside this launch: the last workgroup to arrive finishes it
+        const bool last = W.lane == 0 && qd_acc_arrive(P.acc, w, gridDim.x, acc);
+        if (__builtin_amdgcn_ballot_w64(last) != 0ull) {
+            const double m = qd_acc_finish(P.acc, P.partial, (int)gridDim.x, P.wsum);
+            if (W.lane == 0) *P.mean_out = m;
+        }
+    }
 }
 
 // Strip height of the streaming form.  Measured (rocprofv3 kernel trace, 721 x 1440): R = 4 / 6 / 8 / 10 / 12 / 16 / 24 ->
