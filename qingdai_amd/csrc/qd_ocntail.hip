@@ -263,12 +263,15 @@ __device__ __forceinline__ double qt_currents_wave(const QdTabs& T, const QdTail
         // outliers + caps
         double u = qd_nn(uc), v = qd_nn(vc);
         const double cap = P.cap, s2 = u * u + v * v;
+        // the lane neighbours are taken OUTSIDE the branch: a DPP move reads 0 from a lane that is not executing, and a spike
+        // usually takes this branch alone in its wavefront
+        const double ue = qd_east(uc), uw = qd_west(uc), ve = qd_east(vc), vw = qd_west(vc);
         if (!(s2 < 0.81 * (cap * cap))) {
             const double speed = sqrt(s2);
             if (P.mean4) {
                 if (speed > cap) {
-                    u = 0.25 * (qd_nn(un) + qd_nn(us) + qd_nn(qd_east(uc)) + qd_nn(qd_west(uc)));
-                    v = 0.25 * (qd_nn(vn) + qd_nn(vs) + qd_nn(qd_east(vc)) + qd_nn(qd_west(vc)));
+                    u = 0.25 * (qd_nn(un) + qd_nn(us) + qd_nn(ue) + qd_nn(uw));
+                    v = 0.25 * (qd_nn(vn) + qd_nn(vs) + qd_nn(ve) + qd_nn(vw));
                 }
                 const double sp2 = sqrt(u * u + v * v);
                 const double sc2 = (sp2 > cap) ? cap / (sp2 + 1e-12) : 1.0;

@@ -306,3 +306,41 @@ def test_one_launch_shapiro_equals_one_launch_per_pass(gpu, shape, monkeypatch):
             got = dev.op_shapiro(F, n)
             assert np.array_equal(got, want[n]), (R, n, np.argwhere(got != want[n])[:5])
         dev.close()
+
+
+@pytest.mark.parametrize("outlier", ["mean4", "clamp"])
+def test_ocean_tail_outlier_filter_with_isolated_spikes(gpu, monkeypatch, outlier):
+    """The velocity outlier filter of the ocean sub-step (ocean.py:409-434) with ISOLATED spikes: a cell faster than QD_OCEAN_MAX_U
+    whose four neighbours are slow takes the `mean4` branch alone in its wavefront, so its east / west neighbours must not come
+    from lanes that skipped the branch.  Streaming tail kernel (lane neighbours) against the two-launch form (neighbours from
+    memory) and against the oracle, spikes in the interior, on the seam, next to a pole and in adjacent columns."""
+    import qd_oracle as qo
+    from qingdai_amd.device import Device
+    nlat, nlon = 91, 144
+    qa, grid, mask, alb, fric, p = _setup(nlat, nlon, dict(energy_w=1.0, ocean_cfl=0.05, ocean_outlier=outlier))
+    r = np.random.default_rng(8)
+    ocean = mask == 0
+    uo = r.normal(0, 0.2, (nlat, nlon)) * ocean
+    vo = r.normal(0, 0.2, (nlat, nlon)) * ocean
+    cells = [(i, j) for i, j in [(45, 70), (45, 71), (30, 0), (30, nlon - 1), (1, 40), (nlat - 2, 100), (60, 63), (60, 64), (20, 20)] if ocean[i, j]]
+    assert len(cells) >= 5
+    for k, (i, j) in enumerate(cells):
+        uo[i, j] = 9.0 * (-1) ** k
+        vo[i, j] = 7.0
+    st = _seed_state(nlat, nlon, 9)
+    st.update({"UO": uo, "VO": vo, "ETA": np.zeros((nlat, nlon)), "SST": np.full((nlat, nlon), 288.0)})
+    forcing = qa.ThermalForcing(qa.SphericalGrid(nlat, nlon), qa.OrbitalSystem())
+    stars = forcing.star_table([0.0])
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("QD_OCN_TAIL", mode)
+        dev = Device(qa.SphericalGrid(nlat, nlon), p)
+        for k, v in {"LAND_MASK": mask, "FRICTION": fric, "BASE_ALBEDO": alb, **st}.items():
+            dev.upload_now(k, v)
+        dev.step_n(stars, 300.0, with_ocean=True, with_physics=False, pass_albedo=True)
+        out[mode] = {k: dev.get(k).copy() for k in ("UO", "VO", "ETA", "SST")}
+        dev.close()
+    for k in out["0"]:
+        e = relerr(out["1"][k], out["0"][k])
+        bad = np.argwhere(np.abs(out["1"][k] - out["0"][k]) > 1e-9)
+        assert e < 1e-12, (outlier, k, e, sorted(set(int(b[0]) for b in bad))[:12], [tuple(b) for b in bad if 0 < b[0] < nlat - 1][:12])
