@@ -338,6 +338,7 @@ def test_ocean_tail_outlier_filter_with_isolated_spikes(gpu, monkeypatch, outlie
         for k, v in {"LAND_MASK": mask, "FRICTION": fric, "BASE_ALBEDO": alb, **st}.items():
             dev.upload_now(k, v)
         dev.step_n(stars, 300.0, with_ocean=True, with_physics=False, pass_albedo=True)
+        assert dev.last_ocean_nsub() >= 2
         out[mode] = {k: dev.get(k).copy() for k in ("UO", "VO", "ETA", "SST")}
         dev.close()
     for k in out["0"]:
