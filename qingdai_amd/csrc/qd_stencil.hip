@@ -166,38 +166,67 @@ k_shapiro_stream(QdGeom G, QdFieldList fl, int scrub, int R, int ntc, int nstrip
     for (int k = 0; k < QD_SH_PF; ++k) pf[k] = qd_buf_ld(src, row_off(t0 + k), vo);
 #pragma unroll
     for (int p = 0; p < NP; ++p) h1[p] = h2[p] = 0.0;
+    // ticks on which every stage takes a real row, emits a wanted row and is past its priming row: [t_lo, t_hi].  They run as
+    // straight-line blocks of four (no branch inside: a wave-uniform branch in the unrolled body splits its basic block, and the
+    // loads in flight are then drained by a full s_waitcnt at every block edge); the pipeline fill, the drain and the rows next to a
+    // pole go through the general tick.
+    int t_lo = t0, t_hi = t1;
+#pragma unroll
+    for (int p = 1; p <= NP; ++p) { t_lo = max(t_lo, a[p] + p); t_hi = min(t_hi, min(min(b[p] + 1, b[p - 1]), n - 1) + (p - 1)); }
+    auto tick = [&](int t, double cur) {                        // the general tick
+        if (t > t1) return;
+        if (scrub) cur = qd_nn(cur);
+        bool live = false;                                      // did the last stage emit a row on this tick
+#pragma unroll
+        for (int p = 1; p <= NP; ++p) {
+            const int rp = t - (p - 1);                         // the row arriving at stage p on this tick
+            live = false;
+            if (rp < a[p - 1] || rp > b[p - 1] + (b[p - 1] == n - 1 ? 1 : 0)) continue;    // filling / drained
+            const double l = rp <= n - 1 ? (qd_west(cur) * 0.25 + cur * 0.5) + qd_east(cur) * 0.25 : h1[p - 1];
+            if (rp == a[p - 1]) { h1[p - 1] = l; h2[p - 1] = l; continue; }
+            const double o = (h2[p - 1] * 0.25 + h1[p - 1] * 0.5) + l * 0.25;       // row rp - 1 of pass p
+            h2[p - 1] = h1[p - 1]; h1[p - 1] = l;
+            live = rp - 1 >= a[p] && rp - 1 <= b[p];
+            if (live) cur = o;
+        }
+        if (live) qd_buf_st(dst, row_off(t - NP), vs, cur);
+    };
+    auto tick_all = [&](int t, double cur) {                    // every stage live, no conditions
+        cur = scrub ? qd_nn(cur) : cur;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const double l = (qd_west(cur) * 0.25 + cur * 0.5) + qd_east(cur) * 0.25;
+            const double o = (h2[p] * 0.25 + h1[p] * 0.5) + l * 0.25;
+            h2[p] = h1[p]; h1[p] = l;
+            cur = o;
+        }
+        qd_buf_st(dst, row_off(t - NP), vs, cur);
+    };
+    static_assert(QD_SH_PF == 8, "the tick loop is written as two half-rings of four");
     for (int tb = t0; tb <= t1; tb += QD_SH_PF) {
+        if (tb >= t_lo && tb + 3 <= t_hi) {
 #pragma unroll
-        for (int k = 0; k < QD_SH_PF; ++k) {
-            const int t = tb + k;
-            double cur = pf[k];
-            pf[k] = qd_buf_ld(src, row_off(t + QD_SH_PF), vo);
-            if (t > t1) continue;
-            if (scrub) cur = qd_nn(cur);
-            bool live = false;                                  // did the last stage emit a row on this tick
+            for (int k = 0; k < 4; ++k) { const double cur = pf[k]; pf[k] = qd_buf_ld(src, row_off(tb + k + QD_SH_PF), vo); tick_all(tb + k, cur); }
+        } else {
 #pragma unroll
-            for (int p = 1; p <= NP; ++p) {
-                const int rp = t - (p - 1);                     // the row arriving at stage p on this tick
-                live = false;
-                if (rp < a[p - 1] || rp > b[p - 1] + (b[p - 1] == n - 1 ? 1 : 0)) continue;    // filling / drained
-                const double l = rp <= n - 1 ? (qd_west(cur) * 0.25 + cur * 0.5) + qd_east(cur) * 0.25 : h1[p - 1];
-                if (rp == a[p - 1]) { h1[p - 1] = l; h2[p - 1] = l; continue; }
-                const double o = (h2[p - 1] * 0.25 + h1[p - 1] * 0.5) + l * 0.25;       // row rp - 1 of pass p
-                h2[p - 1] = h1[p - 1]; h1[p - 1] = l;
-                live = rp - 1 >= a[p] && rp - 1 <= b[p];
-                if (live) cur = o;
-            }
-            if (live) qd_buf_st(dst, row_off(t - NP), vs, cur);
+            for (int k = 0; k < 4; ++k) { const double cur = pf[k]; pf[k] = qd_buf_ld(src, row_off(tb + k + QD_SH_PF), vo); tick(tb + k, cur); }
+        }
+        if (tb + 4 >= t_lo && tb + 7 <= t_hi) {
+#pragma unroll
+            for (int k = 4; k < 8; ++k) { const double cur = pf[k]; pf[k] = qd_buf_ld(src, row_off(tb + k + QD_SH_PF), vo); tick_all(tb + k, cur); }
+        } else {
+#pragma unroll
+            for (int k = 4; k < 8; ++k) { const double cur = pf[k]; pf[k] = qd_buf_ld(src, row_off(tb + k + QD_SH_PF), vo); tick(tb + k, cur); }
         }
     }
 }
 
 // strip height of the one-launch Shapiro filter (QD_SHAPIRO_R: tuning override).  rocprofv3 kernel trace, u v h at 721 x 1440, two
-// passes: R = 6 / 8 / 12 / 16 / 24 / 32 -> 17.1 / 15.8 / 16.1 / 17.1 / 18.9 / 19.7 us (two k_shapiro_pass launches: 42 us);
-// 4 instead of 8 rows in flight: +1 us.
+// passes, R = 8 / 12 / 16 / 24 / 32: 14.4 / 14.1 / 14.4 / 14.9 / 15.2 us with the straight-line steady-state blocks (15.8 / 16.1 / 17.1 /
+// 18.9 / 19.7 with the general tick everywhere; two k_shapiro_pass launches: 42 us); 4 instead of 8 rows in flight: +1 us.
 static int qd_shapiro_rows() {
     if (const char* e = std::getenv("QD_SHAPIRO_R")) { const int r = std::atoi(e); if (r > 0) return r; }
-    return 8;
+    return 12;
 }
 
 int qd_shapiro_fields(qd_ctx* c, double** fields, int n, int npass, int m_out) {
