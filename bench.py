@@ -343,6 +343,12 @@ def main():
                     if e.get("avg_kernel_ms_rocprof"):
                         out[key]["frac_rocprof"] = (out[key]["bytes_per_cell"] * cells / 1e9) / (e["avg_kernel_ms_rocprof"] / 1e3) / HBM_PEAK_GBS
                     out[key]["profile_source"] = "profiles/r02_fused_kernels.json (" + pj.get("source", "") + ")"
+                    # the committed profile carries a hash of the kernel sources it was measured on: say so when they have changed since
+                    import hashlib
+                    cs = os.path.join(os.path.dirname(os.path.abspath(__file__)), "qingdai_amd", "csrc")
+                    stale = [f for f, h in pj.get("kernel_sources_sha256_16", {}).items()
+                             if not os.path.exists(os.path.join(cs, f)) or hashlib.sha256(open(os.path.join(cs, f), "rb").read()).hexdigest()[:16] != h]
+                    out[key]["profile_stale"] = bool(stale)
     except Exception:
         pass
     # supplementary, outside the timed region: the same grid with the driver's full iteration (+ hydrology commit) and the

@@ -54,7 +54,10 @@ def main():
             e.update({a: round(b) for a, b in t.get(k, {}).items() if not a.startswith("_")})
             sq["kernels"][k] = e
     json.dump(sq, open(os.path.join(P, f"{tag}_pmc_sq.json"), "w"), indent=1)
-    fk = {"grid": [721, 1440], "source": f"rocprofv3 kernel trace + FETCH_SIZE / WRITE_SIZE passes of bench.py (scripts/profile_round.sh {tag}, "
+    import hashlib
+    srcs = ["qd_stream.hip", "qd_ocntail.hip", "qd_wave.h"]
+    stamp = {f: hashlib.sha256(open(os.path.join(ROOT, "qingdai_amd", "csrc", f), "rb").read()).hexdigest()[:16] for f in srcs}
+    fk = {"grid": [721, 1440], "kernel_sources_sha256_16": stamp, "source": f"rocprofv3 kernel trace + FETCH_SIZE / WRITE_SIZE passes of bench.py (scripts/profile_round.sh {tag}, "
                                          f"scripts/assemble_profiles.py); profiles/README.md", "kernels": {}}
     dyn = next(k for k in tr if "k_dyn_stream" in k)
     for grp, kn in (("k_dyn_hyper", dyn), ("k_ocn_hyper", "k_ocn_stream"), ("ocean_tail", "k_ocn_tail_stream")):
