@@ -488,6 +488,9 @@ k_med_hist(QdGeom G, const double* __restrict__ x, int transform, double tparam,
         pred[8] = __longlong_as_double((long long)lo_b);
         pred[9] = __longlong_as_double((long long)hi_b);
         pred[11] = 1.0;
+        // no positive entry at all (whole-globe handles): the bracket pass has nothing to collect or recount -- its workgroups return
+        // at once, and the finisher, which finds the count it left at zero, writes the default
+        pred[10] = (mode == 0 && m == 0ull) ? 1.0 : 0.0;
         __hip_atomic_store(&st[6], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     for (int k = t; k < QD_HIST_BINS + 2; k += QD_BLOCK) __hip_atomic_store(&hist[k], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -500,6 +503,7 @@ __global__ void k_med_seed(double* pred, const double* out, const unsigned long 
 __global__ void __launch_bounds__(QD_BLOCK)
 k_med_bracket(QdGeom G, const double* __restrict__ x, int transform, double tparam, const double* __restrict__ pred,
               unsigned long long* st, double* __restrict__ cand, unsigned int* __restrict__ ccount, unsigned int cap) {
+    if (pred[10] != 0.0) return;                                              // k_med_hist counted no positive entry
     const bool valid = pred[3] != 0.0;
     const double lo = valid ? pred[0] : 0.0, hi = valid ? pred[1] : -1.0;     // invalid: empty bracket, the finisher falls back
     const int t = threadIdx.x, lane = t & 63;
