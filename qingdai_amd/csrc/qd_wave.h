@@ -57,19 +57,6 @@ __device__ __forceinline__ unsigned qd_xcd_chunk(unsigned L, unsigned nb) {
     return x * per + (x < rem ? x : rem) + (L >> 3);
 }
 
-// area-weighted mean of eta from the tile sums of k_ocn_tail: every wave that needs the mean adds the (~1000) partial sums itself,
-// in one fixed order (lane-strided, then a shuffle tree), so all waves of all consumers get the same bits -- cheaper than a
-// launch of its own between two sub-steps for one scalar
-__device__ __forceinline__ double qd_partial_mean(const double* __restrict__ p, int n, double wsum) {
-    const int lane = threadIdx.x & 63;
-    double a = 0.0;
-    for (int k = lane; k < n; k += 64) a += p[k];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
-    a = __shfl(a, 0, 64);
-    return a / (wsum + 1e-15);
-}
-
 // ---- sum of a few thousand per-workgroup partial sums inside the launch that produces them ---------------------------------------
 // Each workgroup adds its partial sum as a FIXED-POINT number (integer part + fraction scaled by 2^50, two int64) to one of 64 slots
 // with agent-scope atomics; integer addition commutes, so the total does not depend on the order the workgroups finish in.  Who is
@@ -77,7 +64,7 @@ __device__ __forceinline__ double qd_partial_mean(const double* __restrict__ p, 
 // ticket of the launch, and the last one of those (qd_acc_arrive returns true for exactly one workgroup) reads the 64 slots, converts
 // once and clears everything for the next launch.  Resolution 2^-50 per partial (finer than the rounding of an f64 tree over the same
 // values).  A partial that is not finite or not below 2^62 raises a flag instead; the finisher then adds the stored partials itself
-// (qd_partial_mean), so NaN / inf propagate as they would through the f64 sum.
+// (coherent loads), so NaN / inf propagate as they would through the f64 sum.
 // Measured (k_ocn_tail_stream, 2184 workgroups, 721 x 1440): the two adds on one slot 23.9 -> 71.6 us (atomics on one word
 // serialise at ~90 per us -- that is also what a single ticket word costs); 64 slots of 16 B 27.1; of 32 B 24.2; of 64 B 24.1.
 #define QD_ACC_SLOTS 64
