@@ -345,3 +345,20 @@ def test_ocean_tail_outlier_filter_with_isolated_spikes(gpu, monkeypatch, outlie
         e = relerr(out["1"][k], out["0"][k])
         bad = np.argwhere(np.abs(out["1"][k] - out["0"][k]) > 1e-9)
         assert e < 1e-12, (outlier, k, e, sorted(set(int(b[0]) for b in bad))[:12], [tuple(b) for b in bad if 0 < b[0] < nlat - 1][:12])
+
+
+@pytest.mark.parametrize("over", [dict(K_h=0.0), dict(ocean_use_qnet=0), dict(ocean_ice_qfac=0.0), dict(ocean_adv_alpha=1.0),
+                                  dict(ocean_adv_alpha=0.0, K_h=2.0e4), dict(eta_cap=0.05), dict(ocean_cfl=0.9)],
+                         ids=lambda o: ",".join(f"{k}={v}" for k, v in o.items()))
+def test_ocean_tail_kernel_parameter_branches(gpu, monkeypatch, over):
+    """The wave-uniform switches of the streaming tail kernel (no diffusion, no Q_net heating, no heating under ice, pure advection /
+    no advection, a tight eta clip, one sub-step per step) against the two-launch form, 2 coupled steps at 91 x 144."""
+    base = dict(energy_w=1.0, ocean_cfl=0.05)
+    base.update(over)
+    monkeypatch.setenv("QD_OCN_TAIL", "0")
+    two, _ = _run(1, 91, 144, 2, base, True, True)
+    monkeypatch.setenv("QD_OCN_TAIL", "1")
+    one, _ = _run(1, 91, 144, 2, base, True, True)
+    for k in one:
+        e = relerr(one[k], two[k])
+        assert e < 1e-12, (over, k, e)
