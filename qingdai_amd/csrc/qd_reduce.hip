@@ -503,7 +503,7 @@ __global__ void k_med_seed(double* pred, const double* out, const unsigned long 
 __global__ void __launch_bounds__(QD_BLOCK)
 k_med_bracket(QdGeom G, const double* __restrict__ x, int transform, double tparam, const double* __restrict__ pred,
               unsigned long long* st, double* __restrict__ cand, unsigned int* __restrict__ ccount, unsigned int cap) {
-    if (pred[10] != 0.0) return;                                              // k_med_hist counted no positive entry
+    if (pred[2] != 0.0) return;                                               // k_med_hist counted no positive entry (its pred[10]: this kernel gets pred + 8)
     const bool valid = pred[3] != 0.0;
     const double lo = valid ? pred[0] : 0.0, hi = valid ? pred[1] : -1.0;     // invalid: empty bracket, the finisher falls back
     const int t = threadIdx.x, lane = t & 63;
