@@ -395,40 +395,45 @@ k_gauss_fused(QdGeom G, const double* __restrict__ in, double* __restrict__ out,
 // per output row), forms the axis-0 result of all QD_GB rows from them, and the axis-1 pass reads those from LDS.
 // Identical arithmetic and tap order to k_gauss_fused / the two-kernel form.
 #define QD_GB 8
+// A workgroup owns QD_BLOCK - 2 RR columns and loads QD_BLOCK (its own + RR halo columns per side): one column per thread, one
+// pass -- with QD_BLOCK owned columns the 2 RR halo columns were a second, serialised pass of a few threads (10.3 us per launch).
 template <int RR>
 __global__ void __launch_bounds__(QD_BLOCK)
 k_gauss_rows(QdGeom G, const double* __restrict__ in, double* __restrict__ out, QdGaussW W, int mode_wrap, int clip01,
              const double* __restrict__ scale_p, double scale_k) {
-    __shared__ double sm[QD_GB][QD_BLOCK + 2 * RR];
+    constexpr int OWN = QD_BLOCK - 2 * RR;
+    __shared__ double sm[QD_GB][QD_BLOCK];
     const int i0 = G.row0 + (int)blockIdx.y * QD_GB;
     const int nvalid = min(QD_GB, G.row0 + G.nrows - i0);                  // rows of this block inside the launch
-    const int jbase = (int)blockIdx.x * QD_BLOCK;
+    const int jbase = (int)blockIdx.x * OWN;
     const double sc = scale_p ? *scale_p : scale_k;
     double w[RR + 1];
 #pragma unroll
     for (int k = 0; k <= RR; ++k) w[k] = W.w[k];
-    for (int s = threadIdx.x; s < QD_BLOCK + 2 * RR; s += QD_BLOCK) {
+    {
+        const int s = threadIdx.x;
         const int jj = jbase - RR + s;
-        if (jj >= G.nlon + RR) break;
-        const int j = qd_ext(jj, G.nlon, mode_wrap);
-        double x[QD_GB + 2 * RR];
+        if (jj < G.nlon + RR) {
+            const int j = qd_ext(jj, G.nlon, mode_wrap);
+            double x[QD_GB + 2 * RR];
 #pragma unroll
-        for (int q = 0; q < QD_GB + 2 * RR; ++q) {
-            const int qq = q < nvalid + 2 * RR ? q : nvalid + 2 * RR - 1;   // never beyond the rows the valid outputs need
-            x[q] = in[(size_t)qd_lrow(G, qd_ext(i0 - RR + qq, G.nlat, mode_wrap)) * G.nlon + j] * sc;
-        }
+            for (int q = 0; q < QD_GB + 2 * RR; ++q) {
+                const int qq = q < nvalid + 2 * RR ? q : nvalid + 2 * RR - 1;   // never beyond the rows the valid outputs need
+                x[q] = in[(size_t)qd_lrow(G, qd_ext(i0 - RR + qq, G.nlat, mode_wrap)) * G.nlon + j] * sc;
+            }
 #pragma unroll
-        for (int k = 0; k < QD_GB; ++k) {
-            double tmp = x[k + RR] * w[0];
+            for (int k = 0; k < QD_GB; ++k) {
+                double tmp = x[k + RR] * w[0];
 #pragma unroll
-            for (int q = RR; q >= 1; --q) tmp += (x[k + RR - q] + x[k + RR + q]) * w[q];
-            sm[k][s] = tmp;
+                for (int q = RR; q >= 1; --q) tmp += (x[k + RR - q] + x[k + RR + q]) * w[q];
+                sm[k][s] = tmp;
+            }
         }
     }
     __syncthreads();
-    const int j = jbase + threadIdx.x;
-    if (j >= G.nlon) return;
-    const int c0 = threadIdx.x + RR;
+    const int c0 = threadIdx.x;
+    const int j = jbase + c0 - RR;
+    if (c0 < RR || c0 >= QD_BLOCK - RR || j >= G.nlon) return;
 #pragma unroll
     for (int k = 0; k < QD_GB; ++k) {
         if (k >= nvalid) break;
@@ -443,7 +448,8 @@ k_gauss_rows(QdGeom G, const double* __restrict__ in, double* __restrict__ out, 
 template <int RR>
 static void qd_launch_gauss_rows(qd_ctx* c, const double* in, double* out, const QdGaussW& W, int mode_wrap, int clip01,
                                  const double* scale_p, double scale_k, int m_out) {
-    QD_ROWS(c, m_out, G, hipLaunchKernelGGL(k_gauss_rows<RR>, dim3((G.nlon + QD_BLOCK - 1) / QD_BLOCK, (G.nrows + QD_GB - 1) / QD_GB),
+    constexpr int OWN = QD_BLOCK - 2 * RR;
+    QD_ROWS(c, m_out, G, hipLaunchKernelGGL(k_gauss_rows<RR>, dim3((G.nlon + OWN - 1) / OWN, (G.nrows + QD_GB - 1) / QD_GB),
                                             dim3(QD_BLOCK), 0, c->stream, G, in, out, W, mode_wrap, clip01, scale_p, scale_k));
 }
 
