@@ -482,8 +482,9 @@ __device__ __forceinline__ bool qs_del4_stream(SRC& S, const QdGeom& G, const Qs
     return bad;
 }
 
-// strip of this workgroup -> wave context.  Strips have R rows; the last one of a row segment also takes the remainder
-// (so that no strip ends within four rows of a pole without holding it).
+// strip of this workgroup -> wave context.  The nrs strips of a row segment split its rows evenly (heights differ by at most one row:
+// a last strip that also took the remainder ran 1.5-2x as long as the others at some grid sizes and set the launch time); strips
+// are at least 12 rows high, so none ends within four rows of a pole without holding it.
 __device__ __forceinline__ void qs_strip(const QdGeom& G, int R, int ntc, int nrs, QsW& W) {
     const unsigned w = qd_xcd_chunk(blockIdx.x, gridDim.x);
     const int rs = (int)(w / (unsigned)ntc), cs = (int)(w % (unsigned)ntc);
@@ -495,8 +496,9 @@ __device__ __forceinline__ void qs_strip(const QdGeom& G, int R, int ntc, int nr
     W.vo = (unsigned)W.j * 8u; W.vo8 = (unsigned)W.j; W.vs = col_ok ? (unsigned)jraw * 8u : QS_OOB;
     W.slab_bytes = (unsigned)(G.lrows_ + QD_PAD_ROWS) * (unsigned)G.nlon * 8u;
     W.west_edge = W.j == 0; W.east_edge = W.j == G.nlon - 1;
-    W.o0 = G.row0 + rs * R;
-    W.o1 = rs == nrs - 1 ? G.row0 + G.nrows : W.o0 + R;
+    (void)R;
+    W.o0 = G.row0 + (rs * G.nrows) / nrs;
+    W.o1 = G.row0 + ((rs + 1) * G.nrows) / nrs;
 }
 
 template <bool PRIM, int V>
@@ -575,10 +577,12 @@ static int qs_wgs_per_cu(qd_ctx* c, int which) {
     return nb;
 }
 
-// Strip height.  Measured on MI355X (rocprofv3 kernel trace, 721 x 1440): the launch is fastest with about three waves per
-// SIMD (k_dyn_stream: R = 24 -> 750 workgroups, 24 us; 16 -> 27 us; 32 -> 33 us; k_ocn_stream: R = 16 -> 1125 workgroups,
-// 19.4 us) -- fewer waves leave the memory pipeline idle between a wave's rows, more waves recompute more halo rows (8 per
-// strip) and evict each other's rows from L2.  Larger grids keep the cap and run several rounds.
+// Number of strips per column of strips.  Measured on MI355X (rocprofv3 kernel trace, 721 x 1440): the launch is fastest with about
+// three waves per SIMD (k_dyn_stream: 30 strips of 24 rows -> 750 workgroups, 24 us; 16 rows -> 27 us; 32 -> 33 us; k_ocn_stream:
+// 45 strips of 16 rows -> 1125 workgroups, 18.6 us) -- fewer waves leave the memory pipeline idle between a wave's rows, more waves
+// recompute more halo rows (8 per strip) and evict each other's rows from L2.  The same workgroup counts hold at 1441 x 2880 (one
+// round of taller strips: k_dyn_stream 79-89 us = 0.52-0.58 of the HBM peak with 15-20 strips of 72-96 rows, against 91-124 us for
+// strip heights that leave a long last strip or fall between two rounds).  QD_STREAM_R* give a strip height instead.
 struct QsShape { int R, nrs; };
 static QsShape qs_shape(qd_ctx* c, int nrows, int nlon, int which) {
     const int ntc = (nlon + QS_TC - 1) / QS_TC;
@@ -586,14 +590,14 @@ static QsShape qs_shape(qd_ctx* c, int nrows, int nlon, int which) {
     if (const char* e = std::getenv(which == 2 ? "QD_STREAM_R_OCN" : "QD_STREAM_R_DYN")) R = std::atoi(e);    // tuning overrides, read per launch
     if (R <= 0) if (const char* e = std::getenv("QD_STREAM_R")) R = std::atoi(e);
     if (R <= 0) R = c->stream_rows;
-    if (R <= 0) {
-        const long target = which == 2 ? 1150 : 760;         // workgroups in flight
-        const int rmax = which == 2 ? 24 : 32;
-        R = rmax;
-        for (int r = 12; r <= rmax; r += 4) { if ((long)std::max(1, nrows / r) * ntc <= target) { R = r; break; } }
+    int nrs;
+    if (R > 0) nrs = std::max(1, nrows / std::max(R, 5));
+    else {
+        const long target = which == 2 ? 1125 : 760;         // workgroups in flight
+        nrs = (int)std::max(1L, (target + ntc / 2) / ntc);
     }
-    R = std::max(R, 5);
-    return QsShape{R, std::max(1, nrows / R)};
+    nrs = std::max(1, std::min(nrs, nrows / 12));            // strips of at least 12 rows
+    return QsShape{(nrows + nrs - 1) / nrs, nrs};
 }
 
 static int host_lrow(const QdGeom& G, int g) {
