@@ -579,7 +579,7 @@ static int qs_wgs_per_cu(qd_ctx* c, int which) {
 
 // Number of strips per column of strips.  Measured on MI355X (rocprofv3 kernel trace, 721 x 1440): the launch is fastest with about
 // three waves per SIMD (k_dyn_stream: 30 strips of 24 rows -> 750 workgroups, 24 us; 16 rows -> 27 us; 32 -> 33 us; k_ocn_stream:
-// 45 strips of 16 rows -> 1125 workgroups, 18.6 us) -- fewer waves leave the memory pipeline idle between a wave's rows, more waves
+// 40 strips of 18 rows -> 1000 workgroups, 18.6 us; 1125 -> 19.2; 750 -> 21.2; 1500 -> 20.0) -- fewer waves leave the memory pipeline idle between a wave's rows, more waves
 // recompute more halo rows (8 per strip) and evict each other's rows from L2.  The same workgroup counts hold at 1441 x 2880 (one
 // round of taller strips: k_dyn_stream 79-89 us = 0.52-0.58 of the HBM peak with 15-20 strips of 72-96 rows, against 91-124 us for
 // strip heights that leave a long last strip or fall between two rounds).  QD_STREAM_R* give a strip height instead.
@@ -593,7 +593,7 @@ static QsShape qs_shape(qd_ctx* c, int nrows, int nlon, int which) {
     int nrs;
     if (R > 0) nrs = std::max(1, nrows / std::max(R, 5));
     else {
-        const long target = which == 2 ? 1125 : 760;         // workgroups in flight
+        const long target = which == 2 ? 1000 : 760;         // workgroups in flight
         nrs = (int)std::max(1L, (target + ntc / 2) / ntc);
     }
     nrs = std::max(1, std::min(nrs, nrows / 12));            // strips of at least 12 rows
