@@ -403,13 +403,14 @@ k_ocn_tail_stream(QdGeom G, QdTabs T, QdTailArgs P) {
     }
 }
 
-// Strip height of the streaming form.  Measured (rocprofv3 kernel trace, 721 x 1440): R = 4 / 6 / 8 / 10 / 12 / 16 / 24 ->
-// 27.0 / 26.2 / 23.9 / 25.4 / 27.4 / 32.7 / 41.3 us (a wave is a serial chain of rows, shorter strips mean more of them in
-// parallel; below 8 the SST wave's four halo rows dominate); one-wave workgroups with separate strip heights for the two roles:
-// 24.6 us at best.  QD_TAIL_R: tuning override, read per launch.
+// Strip height of the streaming form.  Measured (rocprofv3 kernel trace, 721 x 1440), with the eta mean finished inside the launch:
+// R = 6 / 7 / 8 / 9 / 10 / 12 -> 29.2 / 24.6 / 26.3 / 26.3 / 26.9 / 28.5 us (without it R = 4 / 6 / 8 / 10 / 12 / 16 / 24 -> 27.0 / 26.2 / 23.9 /
+// 25.4 / 27.4 / 32.7 / 41.3): a wave is a serial chain of rows, shorter strips mean more of them in parallel; below 7 the SST wave's
+// four halo rows dominate; one-wave workgroups with separate strip heights for the two roles: 24.6 us at best.
+// QD_TAIL_R: tuning override, read per launch.
 static int qt_rows(const qd_ctx* c) {
     if (const char* e = std::getenv("QD_TAIL_R")) { const int r = std::atoi(e); if (r > 0) return r; }
-    return 8;
+    return 8;                                               // (7 is 1.5 us faster in the trace, 0.3 % of the step: not worth a second summation order in the tests)
 }
 
 // number of eta partial sums the launch leaves in P.partial
