@@ -465,7 +465,8 @@ k_sst_outlier_fused(QdGeom G, QdTabs T, double dlat, double dlon, double a, QdHe
     uo_out[o] = u; vo_out[o] = v;
     // eta -= area-weighted ocean mean (ocean.py:375), then nan_to_num + clip (ocean.py:436-443)
     if (mean_out) return;
-    const double e = eta_mean ? eta[o] - *eta_mean : eta[o];
+    // pcount < 0: *eta_mean is the RAW all-reduced sum of the bands (no launch of its own for one division)
+    const double e = eta_mean ? eta[o] - (pcount < 0 ? *eta_mean / (wsum + 1e-15) : *eta_mean) : eta[o];
     eta[o] = qd_clip(qd_nn(e), -eta_cap, eta_cap);
 }
 
@@ -763,6 +764,7 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
             qd_swap(c, QD_F_SST, 1); qd_swap(c, QD_F_UO, 2); qd_swap(c, QD_F_VO, 3);
         } else if (c->use_fused) {
             QdScope sc(c, "ocean_cont_sst");
+            bool band_raw_mean = false;
             const int m = qd_plan(c, {QD_IN(F[QD_F_UO], 1), QD_IN(F[QD_F_VO], 1), QD_IN(F[QD_F_ETA], 0), QD_IN(F[QD_F_SST], Ro)});
             if (m < 0) return -1;
             double* T1 = qd_scratch(c, 0);
@@ -796,7 +798,9 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
                 } else {
                 hipLaunchKernelGGL(k_eta_mean, dim3(1), blk, 0, c->stream, c->red_partial, (int)off, -1.0, c->dscal + QD_S_ETA_MEAN);
                 if (qd_allreduce_f64(c, c->dscal + QD_S_ETA_MEAN, 1, 0)) return -1;
-                hipLaunchKernelGGL(k_eta_mean_post, dim3(1), dim3(64), 0, c->stream, c->dscal + QD_S_ETA_MEAN, c->wsum_ocean);
+                band_raw_mean = !defer_eta;      // the SST kernel divides the raw sum itself: no k_eta_mean_post launch (4.5 us per sub-step)
+                if (!band_raw_mean)
+                    hipLaunchKernelGGL(k_eta_mean_post, dim3(1), dim3(64), 0, c->stream, c->dscal + QD_S_ETA_MEAN, c->wsum_ocean);
                 }
             }
             qd_mark(c, {T1, F[QD_F_ETA]}, m);
@@ -811,7 +815,7 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
                                                  F[QD_F_UO], F[QD_F_VO], u2, v2, F[QD_F_ETA], p.ocean_max_u, p.eta_cap,
                                                  p.ocean_outlier == 0 ? 1 : 0,
                                                  has_ocean ? c->dscal + QD_S_ETA_MEAN : (const double*)nullptr,
-                                                 c->red_partial, band_defer ? 0 : (int)(qd_grid2d(Gown).x * qd_grid2d(Gown).y), c->wsum_ocean,
+                                                 c->red_partial, band_defer ? 0 : (band_raw_mean ? -1 : (int)(qd_grid2d(Gown).x * qd_grid2d(Gown).y)), c->wsum_ocean,
                                                  band_defer ? c->dscal + QD_S_TMP1 : (defer_eta ? c->dscal + QD_S_ETA_MEAN : (double*)nullptr)));
             qd_mark(c, {T2, u2, v2, F[QD_F_ETA]}, m2);
             if (band_defer) {
