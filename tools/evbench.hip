@@ -55,5 +55,46 @@ int main() {
                    timing ? "default" : "disable-timing", reps, one, two, ovl);
         }
     }
+    // the overlapped pattern captured into a hipGraph (20 iterations per graph) and replayed
+    {
+        hipEvent_t e1[2], e2[2], ej;
+        for (int k = 0; k < 2; ++k) { CK(hipEventCreateWithFlags(&e1[k], hipEventDisableTiming)); CK(hipEventCreateWithFlags(&e2[k], hipEventDisableTiming)); }
+        CK(hipEventCreateWithFlags(&ej, hipEventDisableTiming));
+        for (int reps : {1, 200}) {
+            const int PER = 20;
+            hipGraph_t g; hipGraphExec_t ge;
+            CK(hipStreamBeginCapture(s1, hipStreamCaptureModeGlobal));
+            for (int it = 0; it < PER; ++it) {
+                if (it >= 2) CK(hipStreamWaitEvent(s1, e2[it & 1], 0));
+                hipLaunchKernelGGL(k_work, dim3(n / 256), dim3(256), 0, s1, a, n, reps);
+                CK(hipEventRecord(e1[it & 1], s1)); CK(hipStreamWaitEvent(s2, e1[it & 1], 0));
+                hipLaunchKernelGGL(k_work, dim3(n / 256), dim3(256), 0, s2, b, n, reps);
+                CK(hipEventRecord(e2[it & 1], s2));
+            }
+            CK(hipEventRecord(ej, s2)); CK(hipStreamWaitEvent(s1, ej, 0));      // join the side stream before the capture ends
+            CK(hipStreamEndCapture(s1, &g));
+            CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            CK(hipGraphLaunch(ge, s1)); CK(hipDeviceSynchronize());
+            auto t0 = std::chrono::steady_clock::now();
+            for (int it = 0; it < N / PER; ++it) CK(hipGraphLaunch(ge, s1));
+            CK(hipDeviceSynchronize());
+            const double gr = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / N * 1e6;
+            // the same kernels on ONE stream in a graph
+            hipGraph_t g1; hipGraphExec_t ge1;
+            CK(hipStreamBeginCapture(s1, hipStreamCaptureModeGlobal));
+            for (int it = 0; it < PER; ++it) {
+                hipLaunchKernelGGL(k_work, dim3(n / 256), dim3(256), 0, s1, a, n, reps);
+                hipLaunchKernelGGL(k_work, dim3(n / 256), dim3(256), 0, s1, b, n, reps);
+            }
+            CK(hipStreamEndCapture(s1, &g1));
+            CK(hipGraphInstantiate(&ge1, g1, nullptr, nullptr, 0));
+            CK(hipGraphLaunch(ge1, s1)); CK(hipDeviceSynchronize());
+            t0 = std::chrono::steady_clock::now();
+            for (int it = 0; it < N / PER; ++it) CK(hipGraphLaunch(ge1, s1));
+            CK(hipDeviceSynchronize());
+            const double gr1 = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / N * 1e6;
+            printf("hipGraph            kernel reps %3d: one-stream graph %6.2f us/iter   overlapped two-stream graph %6.2f\n", reps, gr1, gr);
+        }
+    }
     return 0;
 }
