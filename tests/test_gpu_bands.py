@@ -362,3 +362,25 @@ def test_ocean_tail_kernel_parameter_branches(gpu, monkeypatch, over):
     for k in one:
         e = relerr(one[k], two[k])
         assert e < 1e-12, (over, k, e)
+
+
+@pytest.mark.parametrize("shape", [(25, 64), (37, 130), (50, 200), (97, 257), (13, 70)])
+def test_streaming_kernels_at_awkward_grid_sizes(gpu, shape, monkeypatch):
+    """Strip geometry of the row-streaming kernels where nothing divides evenly: a single strip per column of strips, strips of
+    12-13 rows, a last column strip of a few columns, an odd number of longitudes, the smallest grid the streaming path accepts.
+    Streaming momentum + del^4 kernels against the LDS-tile kernels' EXACT path bit for bit; streaming ocean tail (with the eta mean
+    finished inside the launch) against the two-launch form to the rounding of the eta sum; 3 coupled steps with driver physics."""
+    nlat, nlon = shape
+    over = dict(energy_w=1.0, ocean_cfl=0.05)
+    monkeypatch.setenv("QD_OCN_TAIL", "0")
+    monkeypatch.setenv("QD_FUSED_FAST", "0")
+    lds, _ = _run(1, nlat, nlon, 3, over, True, True)
+    monkeypatch.setenv("QD_FUSED_FAST", "1")
+    stream, _ = _run(1, nlat, nlon, 3, over, True, True)
+    for k in lds:
+        assert np.array_equal(stream[k], lds[k]), (shape, k, relerr(stream[k], lds[k]))
+    monkeypatch.setenv("QD_OCN_TAIL", "1")
+    tail, _ = _run(1, nlat, nlon, 3, over, True, True)
+    for k in lds:
+        e = relerr(tail[k], lds[k])
+        assert e < 1e-11, (shape, k, e)
