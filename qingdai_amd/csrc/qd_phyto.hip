@@ -145,7 +145,8 @@ int qd_phyto_step_impl(qd_ctx* c, double dt) {
                                          c->dlon, F[QD_F_UO], F[QD_F_VO], P.stack[0], P.stack[1], P.stride, P.alpha, has_diff));
     for (int s = 0; s < P.S; ++s) qd_mark(c, {P.tmp[s]}, m1);
     in.clear();
-    for (int s = 0; s < P.S; ++s) in.push_back(QD_IN(P.tmp[s], has_diff ? 1 : 0));
+    // qd_lap_point<true> reads rows i-2 .. i+2 (qd_dphi at rows i+-1; qd_device.h:23-55), like the SST path (qd_ocean.hip, QD_IN(T1s, 2))
+    for (int s = 0; s < P.S; ++s) in.push_back(QD_IN(P.tmp[s], has_diff ? 2 : 0));
     const int m2 = qd_plan(c, in.data(), (int)in.size());
     if (m2 < 0) return -1;
     QD_ROWS(c, m2, G, hipLaunchKernelGGL(k_phyto_diffuse, qd_grid2d(G, P.S), blk, 0, c->stream, G, c->tabs.cos05, c->dlat, c->dlon,

@@ -5,7 +5,7 @@
 //   k_ocn_stream   ocean sub-step: grad(eta) + Coriolis + wind stress + drag + land mask + polar sponge
 //                  (ocean.py:306-336) -> del^4 of uo, vo, eta (ocean.py:341-356).
 //
-// Same arithmetic, bit for bit, as the LDS-tiled kernels of qd_fused.hip (which stay as the EXACT reference path and
+// Same arithmetic on every owned cell, bit for bit, as the LDS-tiled kernels of qd_fused.hip (which stay as the EXACT reference path and
 // for grids narrower than one wavefront); different machine mapping:
 //   * A WAVEFRONT owns one field of one strip: 58 owned columns (64 lanes, 3 halo lanes each side; lane l is global
 //     column 58*cs-3+l, so every global access is one coalesced 512-byte row segment) x R owned rows, and marches down
@@ -29,9 +29,32 @@
 #include "qd_fused.h"
 #include "qd_wave.h"
 #include <cstdlib>
+#include <cstdio>
+#include <vector>
 #include <algorithm>
 
 #define QS_TC 58                 // owned columns per strip (lanes 3..60)
+
+// Diagnostic build only (-DQS_STAMPS, tools/build_variant.sh): every wave of k_dyn_stream writes {s_memrealtime at entry, after its
+// prologue, at exit; HW_ID; XCC_ID} to a buffer the launcher dumps to $QD_STAMPS_FILE -- the per-wave timeline of one launch.
+#ifdef QS_STAMPS
+__device__ unsigned long long* qs_stamp_buf;
+__device__ __forceinline__ void qs_stamp(int slot) {
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        qs_stamp_buf[(size_t)wid * 8 + slot] = __builtin_amdgcn_s_memrealtime();
+        if (slot == 0) {
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            qs_stamp_buf[(size_t)wid * 8 + 4] = hw; qs_stamp_buf[(size_t)wid * 8 + 5] = xcc;
+        }
+    }
+}
+#define QS_STAMP(k) qs_stamp(k)
+#else
+#define QS_STAMP(k) ((void)0)
+#endif
 
 // what ONE wave needs of its field; read from the kernarg segment with the wave's (uniform) field index, so that the
 // records of the other fields never occupy SGPRs.  tab: packed rows {lapA[r+1], lapP[r], lapQ[r], k4[r]} of the field.
@@ -42,7 +65,7 @@ struct QsDynArgs {
     const double *poleA, *c8, *c9;             // c8 / c9: mom_cu, mom_cv (geostrophic) | mom_px, fcor (primitive)
     const double *h, *fric;
     double dt, inv_dlon, inv_2dlon, inv_dlat, inv_2dlat, pgf_y;
-    int R, ntc, nrs, exact;
+    int vb, ntc, nrs, exact;
     QsRec rec[5];                              // u v h q cloud; aux = the other momentum component (primitive scheme)
 };
 
@@ -53,7 +76,7 @@ struct QsOcnArgs {
     const uint8_t* land;
     const double* eta_mean;                    // deferred end of the previous sub-step (see QdOcnArgs)
     double eta_cap, sub_dt, g, r_bot, inv_2dlon, inv_2dlat, inv_a, inv_rhoH;
-    int R, ntc, nrs, exact;
+    int vb, ntc, nrs, exact;
     QsRec rec[3];                              // uo vo eta; aux = taux | tauy
 };
 
@@ -93,13 +116,17 @@ __device__ __forceinline__ unsigned qs_off_roll(const QdGeom& G, int g) {
     return qs_off(G, g);
 }
 
-// rows of every input a wave keeps in flight ahead of the row it is working on: plain fields (1 load per row) / momentum
-// sources (3-5 loads per row)
-#ifndef QS_PDP
-#define QS_PDP 3
+// Rows of every input a wave keeps in flight ahead of the row it is working on.  The depth equals the unroll factor of the row
+// loop, and row g of an input always lives in slot g mod 4 of a register array: a slot is read (step K of the unrolled body) and
+// at once re-issued for the row four steps later, so a register that a load is still writing is never shifted or copied.  (The
+// first version kept the rows in a shift chain of depth 2-3: after an unrolled body of four steps the chain is rotated against the
+// registers, the allocator repairs that with v_mov copies at the loop edge, a copy has to wait for the load it copies, and the
+// loop drained vmcnt once per body -- every fourth row paid a full memory round trip whatever the depth; round-3 ISA reading.)
+#ifndef QS_PD_DYN
+#define QS_PD_DYN 4               // atmosphere kernel
 #endif
-#ifndef QS_PDM
-#define QS_PDM 2
+#ifndef QS_PD_OCN
+#define QS_PD_OCN 4               // ocean kernel (its momentum waves hold five inputs per row)
 #endif
 
 struct QsW {                      // what a wave knows about its strip (everything but lane / v* is wave-uniform)
@@ -122,44 +149,59 @@ template <int V> __device__ __forceinline__ double qs_clip200(double x, bool& ba
 }
 
 // ---------------------------------------------------------------- row sources: F[g] of one field, one row per call
-// A source holds the inputs of rows g .. g+PD-1 in registers (the later ones still in flight); get(g) turns row g into
-// F[g], shifts, and issues the loads of row g+PD at the running row offset `ro`.  In the unrolled row loop the shifts are
-// register renames.  get_edge(g) is get(g) for a pole row (one-sided np.gradient / np.roll across the pole).
-template <int V> struct QsSrcPlain {                  // h, q, cloud: the field itself
-    qs_rsrc p; const QdGeom& G; const QsW& W; double q[QS_PDP]; unsigned ro;
+// A source holds the inputs of rows g .. g+3 in four register slots (the later ones still in flight); get<K>(g) -- K = the step's
+// position in the unrolled row loop = (g - first row) mod 4, a template argument so that every slot index is static -- turns row
+// g into F[g]; refill<K>(), called at the END of the row step (behind a scheduling barrier: QS_REFILL), issues the loads of row
+// g+4 into the slot the step has read, at the running row offset `ro` -- every instruction that reads the old contents has been
+// issued by then, so the allocator can give the new row the same registers and nothing is copied at the loop edge.  get_edge<K>(g) is
+// get<K>(g) for a pole row (one-sided np.gradient / np.roll across the pole).  K is never a run-time value: a select over the
+// four slots is folded back into an indexed access by the compiler, and an indexed register array lives in scratch memory.
+
+// A loaded row that lives on as it is (a plain field's F row, the h / eta rows of a three-row window) must LEAVE its slot: while
+// the value sits in the slot's registers the refill needs other registers, and the slots rotate after all.  An opaque move (the
+// compiler would coalesce a plain copy away) ends the slot's life at the step that reads it.
+__device__ __forceinline__ double qs_own(double x) {
+#if QS_OWN_ASM
+    double y;
+    asm("v_mov_b64 %0, %1" : "=v"(y) : "v"(x));
+    return y;
+#else
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0xE4, 0xf, 0xf, true);      // quad_perm:[0,1,2,3]: the identity
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0xE4, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+#endif
+}
+
+template <int V, int PD> struct QsSrcPlain {                  // h, q, cloud: the field itself
+    qs_rsrc p; const QdGeom& G; const QsW& W; double q[PD]; unsigned ro;
     __device__ __forceinline__ void start(int g0, bool&) {
         ro = qs_off(G, g0);
 #pragma unroll
-        for (int k = 0; k < QS_PDP; ++k) { q[k] = qs_ld(p, ro, W.vo); ro += W.nlon; }
+        for (int k = 0; k < PD; ++k) { q[k] = qs_ld(p, ro, W.vo); ro += W.nlon; }
     }
-    __device__ __forceinline__ double get(int, bool&) {
-        const double c = q[0];
-#pragma unroll
-        for (int k = 0; k + 1 < QS_PDP; ++k) q[k] = q[k + 1];
-        q[QS_PDP - 1] = qs_ld(p, ro, W.vo); ro += W.nlon;
-        return c;
-    }
-    __device__ __forceinline__ double get_edge(int g, bool& bad) { return get(g, bad); }
+    template <int K> __device__ __forceinline__ double get(int, bool&) { return qs_own(q[K % PD]); }
+    template <int K> __device__ __forceinline__ double get_edge(int g, bool& bad) { return get<K>(g, bad); }
+    template <int K> __device__ __forceinline__ void refill() { q[K % PD] = qs_ld(p, ro, W.vo); ro += W.nlon; }
 };
 
 // momentum component that needs dh/dphi: u of the geostrophic scheme, v of the primitive one (dynamics.py:488-530)
-template <bool PRIM, int V> struct QsSrcLat {
+template <bool PRIM, int V, int PD> struct QsSrcLat {
     const QsDynArgs& A; const QsW& W;
     qs_rsrc H, FR, X, Y;                                              // h, friction, own component, the other one (PRIM)
-    double hh[QS_PDM + 2], x[QS_PDM], y[QS_PDM], fr[QS_PDM];          // hh: h rows g-1 .. g+PD
-    unsigned ro;                                                      // row g+PD
+    double hm, hc, hq[PD], x[PD], y[PD], fr[PD];          // h rows g-1, g (arrived); hq: h rows g+1 .. g+4
+    unsigned ro;                                                      // row g+4
     __device__ __forceinline__ void start(int g0, bool&) {
-        hh[0] = qs_ld(H, qs_off(A.G, g0 - 1), W.vo);                  // row -1 does not exist: clamped, never used
+        hm = qs_ld(H, qs_off(A.G, g0 - 1), W.vo);                     // row -1 does not exist: clamped, never used
         ro = qs_off(A.G, g0);
+        hc = qs_ld(H, ro, W.vo);
 #pragma unroll
-        for (int k = 0; k < QS_PDM; ++k) {
-            hh[k + 1] = qs_ld(H, ro, W.vo); x[k] = qs_ld(X, ro, W.vo); fr[k] = qs_ld(FR, ro, W.vo); y[k] = PRIM ? qs_ld(Y, ro, W.vo) : 0.0;
+        for (int k = 0; k < PD; ++k) {
+            x[k] = qs_ld(X, ro, W.vo); fr[k] = qs_ld(FR, ro, W.vo); y[k] = PRIM ? qs_ld(Y, ro, W.vo) : 0.0;
             ro += W.nlon;
+            hq[k] = qs_ld(H, ro, W.vo);
         }
-        hh[QS_PDM + 1] = qs_ld(H, ro, W.vo);
     }
-    template <int EDGE> __device__ __forceinline__ double step(int g, bool& bad) {
-        const double hm = hh[0], hc = hh[1], hn = hh[2], x0 = x[0], y0 = y[0], f0 = fr[0];
+    template <int EDGE> __device__ __forceinline__ double eval(int g, double hn, double x0, double y0, double f0, bool& bad) {
         double dh = (hn - hm) * A.inv_2dlat;
         if (EDGE) { if (g == 0) dh = (hn - hc) * A.inv_dlat; if (g == W.n - 1) dh = (hc - hm) * A.inv_dlat; }
         double val;
@@ -171,42 +213,42 @@ template <bool PRIM, int V> struct QsSrcLat {
             const double ur = x0 * 0.8 + u_g * 0.2;
             val = ur + (-f0 * ur) * A.dt;
         }
-        // lanes 0 and 63 have no east / west neighbour: the reference path zeroes them, keep the planes identical
-        if (W.lane == 0 || W.lane == 63) val = 0.0;
-#pragma unroll
-        for (int k = 0; k + 1 < QS_PDM + 2; ++k) hh[k] = hh[k + 1];
-#pragma unroll
-        for (int k = 0; k + 1 < QS_PDM; ++k) { x[k] = x[k + 1]; fr[k] = fr[k + 1]; y[k] = y[k + 1]; }
-        x[QS_PDM - 1] = qs_ld(X, ro, W.vo); fr[QS_PDM - 1] = qs_ld(FR, ro, W.vo); if (PRIM) y[QS_PDM - 1] = qs_ld(Y, ro, W.vo);
-        ro += W.nlon;
-        hh[QS_PDM + 1] = qs_ld(H, ro, W.vo);
+        // (lanes 0 and 63 have no east / west neighbour; what they hold only reaches halo columns: see QS_TC)
+        hm = hc; hc = hn;                                             // arrived values: plain register moves
         return val;
     }
-    __device__ __forceinline__ double get(int g, bool& bad) { return step<0>(g, bad); }
-    __device__ __forceinline__ double get_edge(int g, bool& bad) { return step<1>(g, bad); }
+    template <int K> __device__ __forceinline__ double get(int g, bool& bad) { return eval<0>(g, qs_own(hq[K % PD]), x[K % PD], y[K % PD], fr[K % PD], bad); }
+    template <int K> __device__ __forceinline__ double get_edge(int g, bool& bad) { return eval<1>(g, qs_own(hq[K % PD]), x[K % PD], y[K % PD], fr[K % PD], bad); }
+    template <int K> __device__ __forceinline__ void refill() {
+        x[K % PD] = qs_ld(X, ro, W.vo); fr[K % PD] = qs_ld(FR, ro, W.vo); if (PRIM) y[K % PD] = qs_ld(Y, ro, W.vo);
+        ro += W.nlon;
+        hq[K % PD] = qs_ld(H, ro, W.vo);
+    }
 };
 
 // momentum component that needs dh/dlambda: v of the geostrophic scheme, u of the primitive one
-template <bool PRIM, int V> struct QsSrcLon {
+// EC: the strip holds longitude 0 or n_lon - 1, where np.gradient is one-sided (the first and the last column of strips only)
+template <bool PRIM, int V, int PD, bool EC> struct QsSrcLon {
     const QsDynArgs& A; const QsW& W;
     qs_rsrc H, FR, X, Y;
-    double hh[QS_PDM], x[QS_PDM], y[QS_PDM], fr[QS_PDM];
+    double hh[PD], x[PD], y[PD], fr[PD];
     unsigned ro;
-    __device__ __forceinline__ void load(int k) {
-        hh[k] = qs_ld(H, ro, W.vo); x[k] = qs_ld(X, ro, W.vo); fr[k] = qs_ld(FR, ro, W.vo); y[k] = PRIM ? qs_ld(Y, ro, W.vo) : 0.0;
+    template <int K> __device__ __forceinline__ void load() {
+        hh[K % PD] = qs_ld(H, ro, W.vo); x[K % PD] = qs_ld(X, ro, W.vo); fr[K % PD] = qs_ld(FR, ro, W.vo); y[K % PD] = PRIM ? qs_ld(Y, ro, W.vo) : 0.0;
         ro += W.nlon;
     }
     __device__ __forceinline__ void start(int g0, bool&) {
         ro = qs_off(A.G, g0);
-#pragma unroll
-        for (int k = 0; k < QS_PDM; ++k) load(k);
+        load<0>(); if (PD > 1) load<1>(); if (PD > 2) { load<2>(); load<3>(); }
     }
-    __device__ __forceinline__ double get(int g, bool& bad) {
-        const double hc = hh[0], x0 = x[0], y0 = y[0], f0 = fr[0];
+    __device__ __forceinline__ double eval(int g, double hc, double x0, double y0, double f0, bool& bad) {
         const double hw = qd_west(hc), he = qd_east(hc);
         // np.gradient is one-sided at both ends of the longitude axis (not periodic: SURVEY 0.6)
-        const double inv_lon = (W.west_edge || W.east_edge) ? A.inv_dlon : A.inv_2dlon;
-        const double dh = ((W.east_edge ? hc : he) - (W.west_edge ? hc : hw)) * inv_lon;
+        double dh;
+        if (EC) {
+            const double inv_lon = (W.west_edge || W.east_edge) ? A.inv_dlon : A.inv_2dlon;
+            dh = ((W.east_edge ? hc : he) - (W.west_edge ? hc : hw)) * inv_lon;
+        } else dh = (he - hw) * A.inv_2dlon;
         double val;
         if (PRIM) {
             const double ux = x0 + (qd_sload(A.c8, g) * dh + qd_sload(A.c9, g) * y0 - f0 * x0) * A.dt;
@@ -216,111 +258,98 @@ template <bool PRIM, int V> struct QsSrcLon {
             const double vr = x0 * 0.8 + v_g * 0.2;
             val = vr + (-f0 * vr) * A.dt;
         }
-        if (W.lane == 0 || W.lane == 63) val = 0.0;
-#pragma unroll
-        for (int k = 0; k + 1 < QS_PDM; ++k) { hh[k] = hh[k + 1]; x[k] = x[k + 1]; fr[k] = fr[k + 1]; y[k] = y[k + 1]; }
-        load(QS_PDM - 1);
         return val;
     }
-    __device__ __forceinline__ double get_edge(int g, bool& bad) { return get(g, bad); }
+    template <int K> __device__ __forceinline__ double get(int g, bool& bad) { return eval(g, hh[K % PD], x[K % PD], y[K % PD], fr[K % PD], bad); }
+    template <int K> __device__ __forceinline__ double get_edge(int g, bool& bad) { return get<K>(g, bad); }
+    template <int K> __device__ __forceinline__ void refill() { load<K>(); }
 };
 
-// ocean: eta as the kernel sees it = the deferred "eta -= mean; nan_to_num; clip" of the previous sub-step applied on load
+// ocean: eta as the kernel sees it = the deferred "eta -= mean; nan_to_num; clip" of the previous sub-step applied on load.
+// FAST: no branch on `defer` inside the row loops -- a handle without a deferred mean passes em = 0, cap = +inf (x - 0 and the two
+// clamps are the identity on every finite x; a non-finite x raises `bad` and the strip is redone by the EXACT variant)
 template <int V> __device__ __forceinline__ double qs_eta(double raw, bool defer, double em, double cap, bool& bad) {
-    if (!defer) return raw;
+    if (V == QS_EXACT) {
+        if (!defer) return raw;
+        return qd_clip(qd_nn(raw - em), -cap, cap);
+    }
     const double e = raw - em;
-    if (V == QS_EXACT) return qd_clip(qd_nn(e), -cap, cap);
     bad |= qd_nonfinite(e);
     return fmin(fmax(e, -cap), cap);
 }
 
-template <int V> struct QsSrcEta {
-    const QsOcnArgs& A; const QsW& W; qs_rsrc E; bool defer; double em; double q[QS_PDP]; unsigned ro;
+template <int V, int PD> struct QsSrcEta {
+    const QsOcnArgs& A; const QsW& W; qs_rsrc E; bool defer; double em, cap; double q[PD]; unsigned ro;
     __device__ __forceinline__ void start(int g0, bool&) {
         ro = qs_off(A.G, g0);
 #pragma unroll
-        for (int k = 0; k < QS_PDP; ++k) { q[k] = qs_ld(E, ro, W.vo); ro += W.nlon; }
+        for (int k = 0; k < PD; ++k) { q[k] = qs_ld(E, ro, W.vo); ro += W.nlon; }
     }
-    __device__ __forceinline__ double get(int, bool& bad) {
-        const double c = qs_eta<V>(q[0], defer, em, A.eta_cap, bad);
-#pragma unroll
-        for (int k = 0; k + 1 < QS_PDP; ++k) q[k] = q[k + 1];
-        q[QS_PDP - 1] = qs_ld(E, ro, W.vo); ro += W.nlon;
-        return c;
-    }
-    __device__ __forceinline__ double get_edge(int g, bool& bad) { return get(g, bad); }
+    template <int K> __device__ __forceinline__ double get(int, bool& bad) { return qs_eta<V>(qs_own(q[K % PD]), defer, em, cap, bad); }
+    template <int K> __device__ __forceinline__ double get_edge(int g, bool& bad) { return get<K>(g, bad); }
+    template <int K> __device__ __forceinline__ void refill() { q[K % PD] = qs_ld(E, ro, W.vo); ro += W.nlon; }
 };
 
 // uo: zonal pressure gradient (ocean.py:306-336)
-template <int V> struct QsSrcOcnU {
-    const QsOcnArgs& A; const QsW& W; qs_rsrc E, U, Vv, T, L; bool defer; double em;
-    double e[QS_PDM], u0[QS_PDM], v0[QS_PDM], tx[QS_PDM]; int ld[QS_PDM]; unsigned ro;
-    __device__ __forceinline__ void load(int k) {
-        e[k] = qs_ld(E, ro, W.vo); u0[k] = qs_ld(U, ro, W.vo); v0[k] = qs_ld(Vv, ro, W.vo); tx[k] = qs_ld(T, ro, W.vo);
-        ld[k] = qs_ld8(L, ro, W.vo8);
+template <int V, int PD> struct QsSrcOcnU {
+    const QsOcnArgs& A; const QsW& W; qs_rsrc E, U, Vv, T, L; bool defer; double em, cap;
+    double e[PD], u0[PD], v0[PD], tx[PD]; int ld[PD]; unsigned ro;
+    template <int K> __device__ __forceinline__ void load() {
+        e[K % PD] = qs_ld(E, ro, W.vo); u0[K % PD] = qs_ld(U, ro, W.vo); v0[K % PD] = qs_ld(Vv, ro, W.vo); tx[K % PD] = qs_ld(T, ro, W.vo);
+        ld[K % PD] = qs_ld8(L, ro, W.vo8);
         ro += W.nlon;
     }
     __device__ __forceinline__ void start(int g0, bool&) {
         ro = qs_off(A.G, g0);
-#pragma unroll
-        for (int k = 0; k < QS_PDM; ++k) load(k);
+        load<0>(); if (PD > 1) load<1>(); if (PD > 2) { load<2>(); load<3>(); }
     }
-    __device__ __forceinline__ double get(int g, bool& bad) {
-        const double ec = qs_eta<V>(e[0], defer, em, A.eta_cap, bad);
+    __device__ __forceinline__ double eval(int g, double eraw, double u, double v, double t, int land, bool& bad) {
+        const double ec = qs_eta<V>(eraw, defer, em, cap, bad);
         const double f = qd_sload(A.fcor, g);
         const double gx = ((qd_east(ec) - qd_west(ec)) * A.inv_2dlon) * qd_sload(A.igx, g);
-        const double du = (f * v0[0] - A.g * gx + tx[0] * A.inv_rhoH - A.r_bot * u0[0]);
-        double un = u0[0] + A.sub_dt * du;
-        if (ld[0] == 1) un = 0.0;
+        const double du = (f * v - A.g * gx + t * A.inv_rhoH - A.r_bot * u);
+        double un = u + A.sub_dt * du;
+        if (land == 1) un = 0.0;
         const double sx = A.sub_dt * qd_sload(A.rx, g);
-        double val = un - sx * un;
-        if (W.lane == 0 || W.lane == 63) val = 0.0;
-#pragma unroll
-        for (int k = 0; k + 1 < QS_PDM; ++k) { e[k] = e[k + 1]; u0[k] = u0[k + 1]; v0[k] = v0[k + 1]; tx[k] = tx[k + 1]; ld[k] = ld[k + 1]; }
-        load(QS_PDM - 1);
-        return val;
+        return un - sx * un;
     }
-    __device__ __forceinline__ double get_edge(int g, bool& bad) { return get(g, bad); }
+    template <int K> __device__ __forceinline__ double get(int g, bool& bad) { return eval(g, e[K % PD], u0[K % PD], v0[K % PD], tx[K % PD], ld[K % PD], bad); }
+    template <int K> __device__ __forceinline__ double get_edge(int g, bool& bad) { return get<K>(g, bad); }
+    template <int K> __device__ __forceinline__ void refill() { load<K>(); }
 };
 
 // vo: meridional pressure gradient; eta rows wrap across the poles (np.roll(axis=0), ocean.py:308)
-template <int V> struct QsSrcOcnV {
-    const QsOcnArgs& A; const QsW& W; qs_rsrc E, U, Vv, T, L; bool defer; double em;
-    double es, ec, en[QS_PDM], u0[QS_PDM], v0[QS_PDM], ty[QS_PDM]; int ld[QS_PDM];  // es, ec: eta rows g-1, g (as the kernel sees them); en: raw rows g+1 ..
-    unsigned ro;                                                                   // row g+PD
-    __device__ __forceinline__ void load(int k) {
-        u0[k] = qs_ld(U, ro, W.vo); v0[k] = qs_ld(Vv, ro, W.vo); ty[k] = qs_ld(T, ro, W.vo);
-        ld[k] = qs_ld8(L, ro, W.vo8);
+template <int V, int PD> struct QsSrcOcnV {
+    const QsOcnArgs& A; const QsW& W; qs_rsrc E, U, Vv, T, L; bool defer; double em, cap;
+    double es, ec, en[PD], u0[PD], v0[PD], ty[PD]; int ld[PD];  // es, ec: eta rows g-1, g (as the kernel sees them); en: raw rows g+1 .. g+4
+    unsigned ro;                                                               // row g+4
+    template <int K> __device__ __forceinline__ void load() {
+        u0[K % PD] = qs_ld(U, ro, W.vo); v0[K % PD] = qs_ld(Vv, ro, W.vo); ty[K % PD] = qs_ld(T, ro, W.vo);
+        ld[K % PD] = qs_ld8(L, ro, W.vo8);
         ro += W.nlon;
-        en[k] = qs_ld(E, ro, W.vo);
+        en[K % PD] = qs_ld(E, ro, W.vo);
     }
     __device__ __forceinline__ void start(int g0, bool& bad) {
-        es = qs_eta<V>(qs_ld(E, qs_off_roll(A.G, g0 - 1), W.vo), defer, em, A.eta_cap, bad);      // g0 = 0: the other pole's row
+        es = qs_eta<V>(qs_ld(E, qs_off_roll(A.G, g0 - 1), W.vo), defer, em, cap, bad);      // g0 = 0: the other pole's row
         ro = qs_off(A.G, g0);
-        ec = qs_eta<V>(qs_ld(E, ro, W.vo), defer, em, A.eta_cap, bad);
-#pragma unroll
-        for (int k = 0; k < QS_PDM; ++k) load(k);
+        ec = qs_eta<V>(qs_ld(E, ro, W.vo), defer, em, cap, bad);
+        load<0>(); if (PD > 1) load<1>(); if (PD > 2) { load<2>(); load<3>(); }
     }
-    template <int EDGE> __device__ __forceinline__ double step(int g, bool& bad) {
-        double enr = en[0];
+    template <int EDGE> __device__ __forceinline__ double eval(int g, double enr, double u, double v, double t, int land, bool& bad) {
         if (EDGE) { if (g == W.n - 1) enr = qs_ld(E, qs_off_roll(A.G, g + 1), W.vo); }            // row n is row 0
-        const double enc = qs_eta<V>(enr, defer, em, A.eta_cap, bad);
+        const double enc = qs_eta<V>(enr, defer, em, cap, bad);
         const double f = qd_sload(A.fcor, g);
         const double gy = ((enc - es) * A.inv_2dlat) * A.inv_a;
-        const double dv = (-f * u0[0] - A.g * gy + ty[0] * A.inv_rhoH - A.r_bot * v0[0]);
-        double vn = v0[0] + A.sub_dt * dv;
-        if (ld[0] == 1) vn = 0.0;
+        const double dv = (-f * u - A.g * gy + t * A.inv_rhoH - A.r_bot * v);
+        double vn = v + A.sub_dt * dv;
+        if (land == 1) vn = 0.0;
         const double sx = A.sub_dt * qd_sload(A.rx, g);
-        double val = vn - sx * vn;
-        if (W.lane == 0 || W.lane == 63) val = 0.0;
         es = ec; ec = enc;
-#pragma unroll
-        for (int k = 0; k + 1 < QS_PDM; ++k) { en[k] = en[k + 1]; u0[k] = u0[k + 1]; v0[k] = v0[k + 1]; ty[k] = ty[k + 1]; ld[k] = ld[k + 1]; }
-        load(QS_PDM - 1);
-        return val;
+        return vn - sx * vn;
     }
-    __device__ __forceinline__ double get(int g, bool& bad) { return step<0>(g, bad); }
-    __device__ __forceinline__ double get_edge(int g, bool& bad) { return step<1>(g, bad); }
+    template <int K> __device__ __forceinline__ double get(int g, bool& bad) { return eval<0>(g, qs_own(en[K % PD]), u0[K % PD], v0[K % PD], ty[K % PD], ld[K % PD], bad); }
+    template <int K> __device__ __forceinline__ double get_edge(int g, bool& bad) { return eval<1>(g, qs_own(en[K % PD]), u0[K % PD], v0[K % PD], ty[K % PD], ld[K % PD], bad); }
+    template <int K> __device__ __forceinline__ void refill() { load<K>(); }
 };
 
 // ---------------------------------------------------------------- del^4 of a row stream
@@ -356,13 +385,26 @@ struct QsPipe {                   // what a wave carries from row to row
     double d1, d2;                // D rows gg-3, gg-4
     double gd1, gd2;              // Gb of D for rows gg-5, gg-6
     unsigned so;                  // element offset of the row the next store goes to
+    qd_cptr kp;                   // coefficient row gg-4 of the next full step (rows gg-4 and gg-2 are in range there: no clamp, no index arithmetic)
 };
 
-// one row step.  STAGE: 0 F only; 1 + Gb(F); 2 + D; 3 + Gb(D); 4 + lap(D) and the store
-template <int STAGE, int V, class SRC>
+// the scheduler must not lift the refill loads over the arithmetic that still reads the slot (see the row sources)
+#ifndef QS_SCHED_BARRIER
+#define QS_SCHED_BARRIER 1
+#endif
+#if QS_SCHED_BARRIER
+#define QS_REFILL(S, K) do { __builtin_amdgcn_sched_barrier(0); (S).template refill<K>(); } while (0)
+#else
+#define QS_REFILL(S, K) (S).template refill<K>()
+#endif
+
+// one row step.  STAGE: 0 F only; 1 + Gb(F); 2 + D; 3 + Gb(D); 4 + lap(D) and the store.  K: the row's slot in the source (see QS_PD)
+template <int STAGE, int K, int V, class SRC>
 __device__ __forceinline__ void qs_step(SRC& S, QsPipe& p, int gg, const QsW& W, const double* tab, double dt, qs_rsrc out, bool& bad) {
-    const QsCoef k0 = qs_coef(tab, STAGE >= 1 ? gg - 2 : 0, W.n), k2 = qs_coef(tab, STAGE >= 3 ? gg - 4 : 0, W.n);
-    const double x = qs_nn<V>(S.get(gg, bad));                           // _hyperdiffuse starts from nan_to_num(F)
+    QsCoef k0, k2;
+    if (STAGE >= 4) { k2 = QsCoef{p.kp[0], p.kp[1], p.kp[2], p.kp[3]}; k0 = QsCoef{p.kp[8], p.kp[9], p.kp[10], p.kp[11]}; p.kp += 4; }
+    else { k0 = qs_coef(tab, STAGE >= 1 ? gg - 2 : 0, W.n); k2 = qs_coef(tab, STAGE >= 3 ? gg - 4 : 0, W.n); }
+    const double x = qs_nn<V>(S.template get<K>(gg, bad));               // _hyperdiffuse starts from nan_to_num(F)
     double gb = 0.0, dn = 0.0, gb2 = 0.0;
     if (STAGE >= 1) {
         gb = k0.a * (x - p.f2);                                          // Gb(gg-2) = A[gg-1] (F[gg] - F[gg-2])
@@ -382,6 +424,7 @@ __device__ __forceinline__ void qs_step(SRC& S, QsPipe& p, int gg, const QsW& W,
     if (STAGE >= 1) { p.gf2 = p.gf1; p.gf1 = gb; }
     if (STAGE >= 2) { p.d2 = p.d1; p.d1 = dn; }
     if (STAGE >= 3) { p.gd2 = p.gd1; p.gd1 = gb2; }
+    QS_REFILL(S, K);
 }
 
 template <int V, class SRC>
@@ -393,54 +436,73 @@ __device__ __forceinline__ bool qs_del4_stream(SRC& S, const QdGeom& G, const Qs
     if (fp->skip) {                                          // k4 <= 0 early-out of _hyperdiffuse: the field passes through
         unsigned so = qs_off(G, o0);
         S.start(o0, bad);
-        for (int g = o0; g < o1; ++g) {
-            const double x = (g == 0 || g == n - 1) ? S.get_edge(g, bad) : S.get(g, bad);
-            qs_st(out, so, W.vs, x); so += W.nlon;
-        }
+#define QS_PASS(K) if (g + K < o1) { const int gg = g + K; \
+            const double x = (gg == 0 || gg == n - 1) ? S.template get_edge<K>(gg, bad) : S.template get<K>(gg, bad); \
+            qs_st(out, so, W.vs, x); so += W.nlon; QS_REFILL(S, K); }
+        for (int g = o0; g < o1; g += 4) { QS_PASS(0) QS_PASS(1) QS_PASS(2) QS_PASS(3) }
+#undef QS_PASS
         return bad;
     }
     const double* __restrict__ tab = fp->tab;
     const bool top = o0 == 0, bot = o1 == n;
-    QsPipe p{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, qs_off(G, o0)};
+    QsPipe p{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, qs_off(G, o0), (qd_cptr)(unsigned long long)tab + 4u * (unsigned)o0};
     if (!top) {
         // rows o0-4 .. o0+3: four rows of F, then two with Gb, two with D, two with Gb(D)
         S.start(o0 - 4, bad);
-        qs_step<0, V>(S, p, o0 - 4, W, tab, dt, out, bad);
-        qs_step<0, V>(S, p, o0 - 3, W, tab, dt, out, bad);
-        qs_step<1, V>(S, p, o0 - 2, W, tab, dt, out, bad);
-        qs_step<1, V>(S, p, o0 - 1, W, tab, dt, out, bad);
-        qs_step<2, V>(S, p, o0, W, tab, dt, out, bad);
-        qs_step<2, V>(S, p, o0 + 1, W, tab, dt, out, bad);
-        qs_step<3, V>(S, p, o0 + 2, W, tab, dt, out, bad);
-        qs_step<3, V>(S, p, o0 + 3, W, tab, dt, out, bad);
+        qs_step<0, 0, V>(S, p, o0 - 4, W, tab, dt, out, bad);
+        qs_step<0, 1, V>(S, p, o0 - 3, W, tab, dt, out, bad);
+        qs_step<1, 2, V>(S, p, o0 - 2, W, tab, dt, out, bad);
+        qs_step<1, 3, V>(S, p, o0 - 1, W, tab, dt, out, bad);
+        qs_step<2, 0, V>(S, p, o0, W, tab, dt, out, bad);
+        qs_step<2, 1, V>(S, p, o0 + 1, W, tab, dt, out, bad);
+        qs_step<3, 2, V>(S, p, o0 + 2, W, tab, dt, out, bad);
+        qs_step<3, 3, V>(S, p, o0 + 3, W, tab, dt, out, bad);
     } else {
         // south pole: rows 0 .. 3; the one-sided difference pA0 (X_1 - X_0) stands in for Ga of rows 0 and 1, in both stages
         const double pA0 = qd_sload(poleA, 0);
         S.start(0, bad);
-        const double x0 = qs_nn<V>(S.get_edge(0, bad));
-        const double x1 = qs_nn<V>(S.get(1, bad));
+        const double x0 = qs_nn<V>(S.template get_edge<0>(0, bad));
+        QS_REFILL(S, 0);
+        const double x1 = qs_nn<V>(S.template get<1>(1, bad));
+        QS_REFILL(S, 1);
         p.f2 = x0; p.f1 = x1;
         p.gf1 = pA0 * (x1 - x0); p.gf2 = p.gf1;
-        qs_step<2, V>(S, p, 2, W, tab, dt, out, bad);       // D[0]
+        qs_step<2, 2, V>(S, p, 2, W, tab, dt, out, bad);    // D[0]
         const double dd0 = p.d1;
-        qs_step<2, V>(S, p, 3, W, tab, dt, out, bad);       // D[1]
+        qs_step<2, 3, V>(S, p, 3, W, tab, dt, out, bad);    // D[1]
         p.gd1 = pA0 * (p.d1 - dd0); p.gd2 = p.gd1;
     }
+    QS_STAMP(1);
+    // both prologues end on slot 3: the row loop starts on slot 0
     const int gEnd = bot ? n - 1 : o1 + 4;                   // north pole: the loop stops before row n-1
     int g = o0 + 4;
-    for (; g + 4 <= gEnd; g += 4) {                          // 4 = period of the F shift register: the shifts are renames; straight-line body
-        qs_step<4, V>(S, p, g, W, tab, dt, out, bad);
-        qs_step<4, V>(S, p, g + 1, W, tab, dt, out, bad);
-        qs_step<4, V>(S, p, g + 2, W, tab, dt, out, bad);
-        qs_step<4, V>(S, p, g + 3, W, tab, dt, out, bad);
+    // The loop is entered with nothing in flight.  The compiler's s_waitcnt at the loop head covers BOTH ways in (prologue and
+    // back edge) and takes the stricter count: with the prologue's loads still pending it came out as vmcnt(0) -- a full drain
+    // per four rows; after one explicit drain here the waits inside the loop are the back edge's exact counts.
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0)
+    for (; g + 4 <= gEnd; g += 4) {                          // 4 = period of the F shift register and a multiple of the source slots; straight-line body
+        qs_step<4, 0, V>(S, p, g, W, tab, dt, out, bad);
+        qs_step<4, 1, V>(S, p, g + 1, W, tab, dt, out, bad);
+        qs_step<4, 2, V>(S, p, g + 2, W, tab, dt, out, bad);
+        qs_step<4, 3, V>(S, p, g + 3, W, tab, dt, out, bad);
     }
-    for (; g < gEnd; ++g) qs_step<4, V>(S, p, g, W, tab, dt, out, bad);
+    const int rem = gEnd - g;                                // 0 .. 3 rows left; the source's next slot afterwards
+    if (rem > 0) qs_step<4, 0, V>(S, p, g, W, tab, dt, out, bad);
+    if (rem > 1) qs_step<4, 1, V>(S, p, g + 1, W, tab, dt, out, bad);
+    if (rem > 2) qs_step<4, 2, V>(S, p, g + 2, W, tab, dt, out, bad);
     if (bot) {
         // north pole: rows n-1 (last row of F) .. n+3; pA5 (X_{n-1} - X_{n-2}) stands in for Gb of rows n-2 and n-1
         const double pA5 = qd_sload(poleA, 5);
         {   // gg = n-1
             const QsCoef k0 = qs_coef(tab, n - 3, n), k2 = qs_coef(tab, n - 5, n);
-            const double x = qs_nn<V>(S.get_edge(n - 1, bad));
+            double xe;                                                      // row n-1 sits in slot `rem`
+            switch (rem) {
+            case 0: xe = S.template get_edge<0>(n - 1, bad); break;
+            case 1: xe = S.template get_edge<1>(n - 1, bad); break;
+            case 2: xe = S.template get_edge<2>(n - 1, bad); break;
+            default: xe = S.template get_edge<3>(n - 1, bad); break;
+            }
+            const double x = qs_nn<V>(xe);
             const double e1 = pA5 * (x - p.f1);
             const double gb = k0.a * (x - p.f2);
             const double dn = qs_nn<V>(k0.p * (gb - p.gf2) + k0.q * qs_d2<V>(p.f2));          // D[n-3]
@@ -484,8 +546,14 @@ __device__ __forceinline__ bool qs_del4_stream(SRC& S, const QdGeom& G, const Qs
 
 // strip of this workgroup -> wave context.  The nrs strips of a row segment split its rows evenly (heights differ by at most one row:
 // a last strip that also took the remainder ran 1.5-2x as long as the others at some grid sizes and set the launch time); strips
-// are at least 12 rows high, so none ends within four rows of a pole without holding it.
-__device__ __forceinline__ void qs_strip(const QdGeom& G, int R, int ntc, int nrs, QsW& W) {
+// are at least 12 rows high, so none ends within four rows of a pole without holding it.  `vb` (host: qs_shape) = rows by which the
+// strip that ENDS at the north pole is shorter than an even share: its five epilogue steps are a serial chain behind a drained
+// pipeline, and it is the last strip to be dispatched -- at an even share its waves ended 3.5 us after everybody else's
+// (per-wave s_memrealtime stamps, round 3: median end 18.2 us, strip 29 of 30 at 21.7 us, launch over at 22.8 us).
+__host__ __device__ __forceinline__ int qs_cut(int nrows, int nrs, int vb, int rs) {
+    return rs >= nrs ? nrows : (int)(((long long)rs * (nrows + vb)) / nrs);
+}
+__device__ __forceinline__ void qs_strip(const QdGeom& G, int vb, int ntc, int nrs, QsW& W) {
     const unsigned w = qd_xcd_chunk(blockIdx.x, gridDim.x);
     const int rs = (int)(w / (unsigned)ntc), cs = (int)(w % (unsigned)ntc);
     W.n = G.nlat; W.nlon = G.nlon;
@@ -496,9 +564,8 @@ __device__ __forceinline__ void qs_strip(const QdGeom& G, int R, int ntc, int nr
     W.vo = (unsigned)W.j * 8u; W.vo8 = (unsigned)W.j; W.vs = col_ok ? (unsigned)jraw * 8u : QS_OOB;
     W.slab_bytes = (unsigned)(G.lrows_ + QD_PAD_ROWS) * (unsigned)G.nlon * 8u;
     W.west_edge = W.j == 0; W.east_edge = W.j == G.nlon - 1;
-    (void)R;
-    W.o0 = G.row0 + (rs * G.nrows) / nrs;
-    W.o1 = G.row0 + ((rs + 1) * G.nrows) / nrs;
+    W.o0 = G.row0 + qs_cut(G.nrows, nrs, vb, rs);
+    W.o1 = G.row0 + qs_cut(G.nrows, nrs, vb, rs + 1);
 }
 
 template <bool PRIM, int V>
@@ -508,11 +575,18 @@ __device__ __forceinline__ bool qs_dyn_wave(const QsDynArgs& A, const QsW& W, in
     const unsigned sb = W.slab_bytes;
     if (wv <= 1) {
         const qs_rsrc H = qs_make_rsrc(A.h, sb), FR = qs_make_rsrc(A.fric, sb), X = qs_make_rsrc(fp->in, sb), Y = qs_make_rsrc(fp->aux, sb);
-        if ((wv == 0) == PRIM) { QsSrcLon<PRIM, V> S{A, W, H, FR, X, Y}; return qs_del4_stream<V>(S, A.G, W, A.poleA, fp, A.dt); }
-        QsSrcLat<PRIM, V> S{A, W, H, FR, X, Y};
+        if ((wv == 0) == PRIM) {
+            if (__builtin_amdgcn_ballot_w64(W.west_edge || W.east_edge) != 0ull) {
+                QsSrcLon<PRIM, V, QS_PD_DYN, true> S{A, W, H, FR, X, Y};
+                return qs_del4_stream<V>(S, A.G, W, A.poleA, fp, A.dt);
+            }
+            QsSrcLon<PRIM, V, QS_PD_DYN, false> S{A, W, H, FR, X, Y};
+            return qs_del4_stream<V>(S, A.G, W, A.poleA, fp, A.dt);
+        }
+        QsSrcLat<PRIM, V, QS_PD_DYN> S{A, W, H, FR, X, Y};
         return qs_del4_stream<V>(S, A.G, W, A.poleA, fp, A.dt);
     }
-    QsSrcPlain<V> S{qs_make_rsrc(fp->in, sb), A.G, W};
+    QsSrcPlain<V, QS_PD_DYN> S{qs_make_rsrc(fp->in, sb), A.G, W};
     return qs_del4_stream<V>(S, A.G, W, A.poleA, fp, A.dt);
 }
 
@@ -522,15 +596,16 @@ __device__ __forceinline__ bool qs_ocn_wave(const QsOcnArgs& A, const QsW& W, in
     const QsRec QD_CONST* fp = &Ak->rec[wv];
     const bool defer = A.eta_mean != nullptr;
     const double em = defer ? *A.eta_mean : 0.0;
+    const double cap = (V == QS_EXACT || defer) ? A.eta_cap : __builtin_inf();
     const unsigned sb = W.slab_bytes;
     const qs_rsrc E = qs_make_rsrc(A.eta, sb);
     if (wv <= 1) {
         const qs_rsrc U = qs_make_rsrc(A.uo, sb), Vv = qs_make_rsrc(A.vo, sb), T = qs_make_rsrc(fp->aux, sb), L = qs_make_rsrc(A.land, sb / 8u);
-        if (wv == 0) { QsSrcOcnU<V> S{A, W, E, U, Vv, T, L, defer, em}; return qs_del4_stream<V>(S, A.G, W, A.poleA, fp, A.sub_dt); }
-        QsSrcOcnV<V> S{A, W, E, U, Vv, T, L, defer, em};
+        if (wv == 0) { QsSrcOcnU<V, QS_PD_OCN> S{A, W, E, U, Vv, T, L, defer, em, cap}; return qs_del4_stream<V>(S, A.G, W, A.poleA, fp, A.sub_dt); }
+        QsSrcOcnV<V, QS_PD_OCN> S{A, W, E, U, Vv, T, L, defer, em, cap};
         return qs_del4_stream<V>(S, A.G, W, A.poleA, fp, A.sub_dt);
     }
-    QsSrcEta<V> S{A, W, E, defer, em};
+    QsSrcEta<V, QS_PD_OCN> S{A, W, E, defer, em, cap};
     return qs_del4_stream<V>(S, A.G, W, A.poleA, fp, A.sub_dt);
 }
 
@@ -539,11 +614,13 @@ template <bool PRIM>
 __global__ void __launch_bounds__(320)
 k_dyn_stream(QsDynArgs A) {
     QsW W;
-    qs_strip(A.G, A.R, A.ntc, A.nrs, W);
+    qs_strip(A.G, A.vb, A.ntc, A.nrs, W);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (wv <= 1) __builtin_amdgcn_s_setprio(2);             // the momentum waves are the long ones of a strip (measured: -5 % on k_ocn_stream)
+    QS_STAMP(0);
     if (!A.exact) {
         const bool bad = qs_dyn_wave<PRIM, QS_FAST>(A, W, wv);
+        QS_STAMP(2);
         if (__builtin_amdgcn_ballot_w64(bad) == 0ull) return;
     }
     qs_dyn_wave<PRIM, QS_EXACT>(A, W, wv);
@@ -552,7 +629,7 @@ k_dyn_stream(QsDynArgs A) {
 __global__ void __launch_bounds__(192)
 k_ocn_stream(QsOcnArgs A) {
     QsW W;
-    qs_strip(A.G, A.R, A.ntc, A.nrs, W);
+    qs_strip(A.G, A.vb, A.ntc, A.nrs, W);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (wv <= 1) __builtin_amdgcn_s_setprio(2);             // the momentum waves are the long ones of a strip (measured: -5 % on k_ocn_stream)
     if (!A.exact) {
@@ -583,8 +660,8 @@ static int qs_wgs_per_cu(qd_ctx* c, int which) {
 // recompute more halo rows (8 per strip) and evict each other's rows from L2.  The same workgroup counts hold at 1441 x 2880 (one
 // round of taller strips: k_dyn_stream 79-89 us = 0.52-0.58 of the HBM peak with 15-20 strips of 72-96 rows, against 91-124 us for
 // strip heights that leave a long last strip or fall between two rounds).  QD_STREAM_R* give a strip height instead.
-struct QsShape { int R, nrs; };
-static QsShape qs_shape(qd_ctx* c, int nrows, int nlon, int which) {
+struct QsShape { int R, nrs, vb; };
+static QsShape qs_shape(qd_ctx* c, int nrows, int nlon, int which, bool north_pole) {
     const int ntc = (nlon + QS_TC - 1) / QS_TC;
     int R = 0;
     if (const char* e = std::getenv(which == 2 ? "QD_STREAM_R_OCN" : "QD_STREAM_R_DYN")) R = std::atoi(e);    // tuning overrides, read per launch
@@ -597,7 +674,13 @@ static QsShape qs_shape(qd_ctx* c, int nrows, int nlon, int which) {
         nrs = (int)std::max(1L, (target + ntc / 2) / ntc);
     }
     nrs = std::max(1, std::min(nrs, nrows / 12));            // strips of at least 12 rows
-    return QsShape{(nrows + nrs - 1) / nrs, nrs};
+    int vb = 0;
+    if (north_pole && nrs > 1) {
+        vb = 6;
+        if (const char* e = std::getenv("QD_STREAM_VB")) vb = std::max(0, std::atoi(e));             // tuning override, read per launch
+        while (vb > 0 && nrows - qs_cut(nrows, nrs, vb, nrs - 1) < 12) --vb;                         // the pole strip keeps >= 12 rows
+    }
+    return QsShape{(nrows + nrs - 1) / nrs, nrs, vb};
 }
 
 static int host_lrow(const QdGeom& G, int g) {
@@ -661,11 +744,25 @@ int qd_launch_dyn_stream(qd_ctx* c, const QdDynArgs& P, int margin) {
     A.dt = P.dt; A.inv_dlon = P.inv_dlon; A.inv_2dlon = P.inv_2dlon; A.inv_dlat = P.inv_dlat; A.inv_2dlat = P.inv_2dlat; A.pgf_y = P.pgf_y;
     A.exact = c->fused_fast == 2;
     QdScope sc(c, "k_dyn_hyper", c->geo.full != 0);          // whole globe: one launch, timed by the dispatch itself
+#ifdef QS_STAMPS
+    static unsigned long long* stamps = nullptr;
+    const size_t stamp_words = (size_t)8 * 5 * 4096;
+    if (!stamps) { hipMalloc(&stamps, stamp_words * 8); hipMemcpyToSymbol(HIP_SYMBOL(qs_stamp_buf), &stamps, sizeof(stamps)); }
+    hipMemsetAsync(stamps, 0, stamp_words * 8, c->stream);
+#endif
     QD_ROWS(c, margin, G,
-            const QsShape sh = qs_shape(c, G.nrows, G.nlon, P.primitive ? 1 : 0);
-            A.G = G; A.R = sh.R; A.nrs = sh.nrs; A.ntc = (G.nlon + QS_TC - 1) / QS_TC;
+            const QsShape sh = qs_shape(c, G.nrows, G.nlon, P.primitive ? 1 : 0, G.row0 + G.nrows == G.nlat);
+            A.G = G; A.vb = sh.vb; A.nrs = sh.nrs; A.ntc = (G.nlon + QS_TC - 1) / QS_TC;
             if (P.primitive) QD_LAUNCH_TIMED(sc, k_dyn_stream<true>, dim3(A.nrs * A.ntc), dim3(320), c->stream, A);
             else QD_LAUNCH_TIMED(sc, k_dyn_stream<false>, dim3(A.nrs * A.ntc), dim3(320), c->stream, A));
+#ifdef QS_STAMPS
+    if (const char* f = std::getenv("QD_STAMPS_FILE")) {     // the LAST launch's stamps stay in the file
+        std::vector<unsigned long long> h(stamp_words);
+        hipStreamSynchronize(c->stream);
+        hipMemcpy(h.data(), stamps, stamp_words * 8, hipMemcpyDeviceToHost);
+        if (FILE* fp = std::fopen(f, "wb")) { std::fwrite(h.data(), 8, stamp_words, fp); std::fclose(fp); }
+    }
+#endif
     return 0;
 }
 
@@ -698,8 +795,8 @@ int qd_launch_ocn_stream(qd_ctx* c, const QdOcnArgs& P, int margin) {
     A.exact = c->fused_fast == 2;
     QdScope sc(c, "k_ocn_hyper", c->geo.full != 0);
     QD_ROWS(c, margin, G,
-            const QsShape sh = qs_shape(c, G.nrows, G.nlon, 2);
-            A.G = G; A.R = sh.R; A.nrs = sh.nrs; A.ntc = (G.nlon + QS_TC - 1) / QS_TC;
+            const QsShape sh = qs_shape(c, G.nrows, G.nlon, 2, G.row0 + G.nrows == G.nlat);
+            A.G = G; A.vb = sh.vb; A.nrs = sh.nrs; A.ntc = (G.nlon + QS_TC - 1) / QS_TC;
             QD_LAUNCH_TIMED(sc, k_ocn_stream, dim3(A.nrs * A.ntc), dim3(192), c->stream, A));
     return 0;
 }
