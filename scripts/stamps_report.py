@@ -10,6 +10,9 @@ base = t0.min()
 us = lambda t: (t - base) / 100.0          # s_memrealtime: 100 MHz
 print(f"waves {len(a)}  launch span {us(t2.max()):.2f} us")
 print(f"start   : min {us(t0).min():.2f} p50 {np.median(us(t0)):.2f} p90 {np.percentile(us(t0), 90):.2f} max {us(t0).max():.2f}")
+if a.shape[1] > 3 and (a[:, 3] > 0).any():
+    t3 = a[:, 3].astype(np.int64)
+    print(f"stamp1 - stamp0 p50 {np.median((t1 - t0) / 100.0):.2f}  stamp3 - stamp1 p50 {np.median((t3 - t1) / 100.0):.2f}  stamp2 - stamp3 p50 {np.median((t2 - t3) / 100.0):.2f} us")
 print(f"prologue: p10 {np.percentile((t1 - t0) / 100.0, 10):.2f} p50 {np.median((t1 - t0) / 100.0):.2f} p90 {np.percentile((t1 - t0) / 100.0, 90):.2f} us")
 print(f"lifetime: p10 {np.percentile((t2 - t0) / 100.0, 10):.2f} p50 {np.median((t2 - t0) / 100.0):.2f} p90 {np.percentile((t2 - t0) / 100.0, 90):.2f} max {((t2 - t0) / 100.0).max():.2f} us")
 print(f"end     : p10 {np.percentile(us(t2), 10):.2f} p50 {np.median(us(t2)):.2f} p90 {np.percentile(us(t2), 90):.2f} max {us(t2).max():.2f}")
