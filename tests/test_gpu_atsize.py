@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 from util import relerr
+from test_oracle_polar_noise_cpu import POLAR_ROWS, atsize_wind
 
 pytestmark = pytest.mark.gpu
 
@@ -35,10 +36,10 @@ def _build(with_ocean):
     m = qa.SpectralModel(grid, friction, H=8000, tau_rad=10 * 24 * 3600, greenhouse_factor=0.40, C_s_map=csmap, land_mask=mask,
                          Cs_ocean=Cs_ocean, Cs_land=3e6, Cs_ice=5e6, params=qa.QdParams(**over))
     oc = qa.WindDrivenSlabOcean(grid, mask, 50.0, init_Ts=np.full((nlat, nlon), 288.0)) if with_ocean else None
-    # a spun-up wind field (the bench reaches it after its warm-up steps): |V| up to ~280 m/s puts the slab ocean at the
-    # 8-13 sub-steps per step the benchmark runs with; a cold start would only see n_sub = 2-5
+    # a spun-up wind field (the bench reaches it after its warm-up steps): it puts the slab ocean at the 12-13 sub-steps per step
+    # the benchmark runs with; a cold start would only see n_sub = 2-5.  Shared with the CPU test that measures the polar noise.
     lat = np.deg2rad(grid.lat_mesh); lon = np.deg2rad(grid.lon_mesh)
-    u0 = 185.0 * np.cos(lat) * (1.0 + 0.08 * np.sin(3 * lon)); v0 = 150.0 * np.sin(2 * lat) * np.cos(2 * lon)
+    u0, v0 = atsize_wind(lat, lon)
     m.u, m.v = u0, v0
     m._dev.upload_now("BASE_ALBEDO", base_albedo)
     forcing = qa.ThermalForcing(grid, qa.OrbitalSystem())
@@ -70,20 +71,24 @@ def test_config2_atmosphere_and_driver_physics_vs_oracle_at_721x1440(gpu):
 
 
 def test_config2_coupled_loop_vs_oracle_at_721x1440(gpu):
-    """The same loop with the slab ocean coupled in (8-10 sub-steps per step: k_ocn_stream + k_ocn_tail), two steps.
+    """The same loop with the slab ocean coupled in (13 sub-steps per step: k_ocn_stream + k_ocn_tail_stream), two steps.
 
     What can be compared: at this resolution the two polar ocean rows are violently unstable IN THE REFERENCE ARITHMETIC ITSELF --
-    eta sits at its +-5 m clip and flips sign there: the oracle against the oracle with the wind perturbed by 1e-15 differs by
-    O(1) (eta: 2.0 relative, uo: 0.4) on rows 0-8 and 712-720 after ONE step, and by < 1e-9 everywhere else (measured in the
-    authoring container; the stencils carry the difference at most ~7 rows per sub-step).  So the coupled fields are compared on
-    |lat| <= 65 deg after the first step and on |lat| <= 30 deg after the second, which the polar noise cannot have reached, at the usual bounds; the sub-step counts must
-    agree exactly, and the SST written back into T_s couples the two models everywhere inside the band.  eta gets a wider bound:
-    every sub-step subtracts the area-weighted GLOBAL mean of eta, which carries the polar rows' O(1) noise (at cos-latitude
-    weight) into every cell as a uniform shift of ~1e-7 of the clip value."""
+    eta sits at its +-5 m clip and flips sign there.  tests/test_oracle_polar_noise_cpu.py measures it (the oracle against the oracle
+    with the wind perturbed by 1e-15): after ONE coupled step the two runs differ by O(1) on rows 0-7 and 713-720 and agree to
+    2e-10 (currents) / 3e-14 (atmosphere) everywhere else.  So after the first step every row but POLAR_ROWS = 16 next to each pole
+    is compared -- that includes the second pole-side strip of k_ocn_stream and every strip of the tail kernel but the first two --
+    and after the second step every row but 48 next to each pole (the noise travels at most ~8 rows per step through the stencils
+    that read it).  The pole strips themselves are compared with the oracle by test_ocean_single_substep_every_row_vs_oracle_at_
+    721x1440 below, before the instability has anything to amplify.  The sub-step counts must agree exactly, and the SST written
+    back into T_s couples the two models everywhere inside the window.  eta gets a wider bound: every sub-step subtracts the
+    area-weighted GLOBAL mean of eta, which carries the polar rows' O(1) noise (at cos-latitude weight) into every cell as a
+    uniform shift of ~1e-7 of the clip value."""
     m, oc, forcing, om, oo, d = _build(True)
     nsteps, dt = 2, 300.0
     stars = forcing.star_table([i * dt for i in range(nsteps)])
     nsubs = []
+    n = 721
 
     def compare(rows, what):
         pairs = {"u": (m.u, om.u), "v": (m.v, om.v), "h": (m.h, om.h), "T_s": (m.T_s, om.T_s), "q": (m.q, om.q),
@@ -94,19 +99,61 @@ def test_config2_coupled_loop_vs_oracle_at_721x1440(gpu):
         for k, e in errs.items():
             assert e < (1e-6 if k == "eta" else OCN_TOL if k in ("uo", "vo") else ATM_TOL), (what, k, e)
 
-    # step 1: everything but the polar caps (the noise of rows 0-8 / 712-720 has travelled at most ~7 rows per sub-step of ONE step
-    # through the stencils that read it as input; measured reach of the O(1) differences after one step: rows 0-8, 712-720)
     m._dev.step_n(stars[:1], dt, with_ocean=True, with_physics=True, pass_albedo=True)
     d.step(0.0, dt, pass_albedo=True, commit=False)
     nsubs.append(oo.last_n_sub)
     assert m._dev.last_ocean_nsub() == nsubs[-1]
-    compare(slice(100, 621), "after step 1, |lat| <= 65 deg:")
-    # step 2: |lat| <= 30 deg
+    compare(slice(POLAR_ROWS, n - POLAR_ROWS), f"after step 1, rows {POLAR_ROWS} .. {n - POLAR_ROWS - 1}:")
     m._dev.step_n(stars[1:2], dt, with_ocean=True, with_physics=True, pass_albedo=True)
     d.step(dt, dt, pass_albedo=True, commit=False)
     nsubs.append(oo.last_n_sub)
-    assert m._dev.last_ocean_nsub() == nsubs[-1] and min(nsubs) >= 8, nsubs       # the sub-step counts the bench runs with
-    compare(slice(240, 481), "after step 2, |lat| <= 30 deg:")
+    assert m._dev.last_ocean_nsub() == nsubs[-1] and min(nsubs) >= 12, nsubs      # the sub-step counts the bench runs with
+    compare(slice(48, n - 48), f"after step 2, rows 48 .. {n - 49}:")
+
+
+def test_ocean_single_substep_every_row_vs_oracle_at_721x1440(gpu):
+    """The pole-side strips of k_ocn_stream / k_ocn_tail_stream at the benchmark size, compared with the oracle on EVERY row: one
+    ocean step of 20 s (one sub-step: nothing has been amplified yet) from a smooth, fast state -- currents up to the 3 m/s cap so
+    that the outlier filter and its np.roll neighbours across the poles are exercised, eta inside its clip, a warm-pool SST, wind
+    stress from a 250 m/s jet, Q_net heating with an ice mask -- then a second step that applies the deferred "eta - mean, clip" of
+    the first on load.  Bounds: 1e-12 of each field's max-norm (operators agree to rounding; one step has no time to grow it)."""
+    import qd_oracle as qo
+    import qingdai_amd as qa
+    from qingdai_amd.topography import create_land_sea_mask
+    nlat, nlon = 721, 1440
+    grid = qa.SphericalGrid(nlat, nlon)
+    mask = create_land_sea_mask(grid)
+    ocean = mask == 0
+    lat = np.deg2rad(grid.lat_mesh); lon = np.deg2rad(grid.lon_mesh)
+    r = np.random.default_rng(5)
+    uo = (2.6 * np.cos(lat) ** 0.25 * np.sin(2 * lon + lat) + 0.6 * r.standard_normal((nlat, nlon))) * ocean
+    vo = (2.2 * np.cos(3 * lon) * np.cos(lat) ** 0.25 + 0.6 * r.standard_normal((nlat, nlon))) * ocean
+    uo[[0, 1, -2, -1]] = 4.0 * ocean[[0, 1, -2, -1]]        # fast pole rows: mean4 reads row -1 as row n-1 and row n as row 0 (np.roll)
+    vo[[0, -1]] = -3.0 * ocean[[0, -1]]
+    eta = (3.0 * np.sin(3 * lat) * np.cos(2 * lon) + 0.5 * r.standard_normal((nlat, nlon))) * ocean
+    sst = 288.0 + 12.0 * np.cos(lat) ** 2 + 1.5 * np.sin(4 * lon)
+    u_atm = 250.0 * np.cos(lat) * (1.0 + 0.1 * np.sin(3 * lon)); v_atm = 60.0 * np.sin(2 * lat) * np.cos(2 * lon)
+    qnet = 150.0 * np.cos(lat) - 60.0 + 20.0 * r.standard_normal((nlat, nlon))
+    ice = (np.abs(np.rad2deg(lat)) > 72.0) & ocean
+    P = qo.defaults()
+    oo = qo.OceanOracle(qo.Grid(nlat, nlon), mask, P, init_Ts=sst.copy())
+    oo.uo, oo.vo, oo.eta = uo.copy(), vo.copy(), eta.copy()
+    oc = qa.WindDrivenSlabOcean(grid, mask, 50.0, init_Ts=sst)
+    oc.uo, oc.vo, oc.eta = uo, vo, eta
+    for k in range(2):
+        oc.step(20.0, u_atm, v_atm, Q_net=qnet, ice_mask=ice)
+        oo.step(20.0, u_atm, v_atm, Q_net=qnet, ice_mask=ice)
+        assert oc.last_n_sub == oo.last_n_sub == 1
+        errs = {kk: relerr(a, b) for kk, (a, b) in {"uo": (oc.uo, oo.uo), "vo": (oc.vo, oo.vo), "eta": (oc.eta, oo.eta), "SST": (oc.Ts, oo.Ts)}.items()}
+        capped = int(np.sum(np.hypot(oo.uo, oo.vo) > 2.999))
+        print(f"ocean step {k}: {errs}, cells at the velocity cap: {capped}, pole rows at the cap: "
+              f"{int(np.sum(np.hypot(oo.uo[[0, -1]], oo.vo[[0, -1]]) > 2.999))}")
+        assert capped > 1000
+        for kk, e in errs.items():
+            assert e < 1e-12, (k, kk, e)
+        for rows in (slice(0, 9), slice(nlat - 9, nlat)):
+            for kk, (a, b) in {"uo": (oc.uo, oo.uo), "vo": (oc.vo, oo.vo), "eta": (oc.eta, oo.eta), "SST": (oc.Ts, oo.Ts)}.items():
+                assert relerr(a[rows], b[rows]) < 1e-12, (k, kk, rows)
 
 
 @pytest.mark.parametrize("use_ocean,ka", [

@@ -338,19 +338,29 @@ def test_ocean_tail_outlier_filter_with_isolated_spikes(gpu, monkeypatch, outlie
         uo[i, j] = 9.0 * (-1) ** k
         vo[i, j] = 7.0
     st = _seed_state(nlat, nlon, 9)
-    st.update({"UO": uo, "VO": vo, "ETA": np.zeros((nlat, nlon)), "SST": np.full((nlat, nlon), 288.0)})
-    forcing = qa.ThermalForcing(qa.SphericalGrid(nlat, nlon), qa.OrbitalSystem())
-    stars = forcing.star_table([0.0])
+    lat = np.linspace(-np.pi / 2, np.pi / 2, nlat)[:, None]
+    sst = 288.0 + 8.0 * np.cos(lat) ** 2 + r.normal(0, 0.3, (nlat, nlon))
     out = {}
     for mode in ("0", tail):
         monkeypatch.setenv("QD_OCN_TAIL", mode)
-        dev = Device(qa.SphericalGrid(nlat, nlon), p)
-        for k, v in {"LAND_MASK": mask, "FRICTION": fric, "BASE_ALBEDO": alb, **st}.items():
-            dev.upload_now(k, v)
-        dev.step_n(stars, 300.0, with_ocean=True, with_physics=False, pass_albedo=True)
-        assert dev.last_ocean_nsub() >= 2
-        out[mode] = {k: dev.get(k).copy() for k in ("UO", "VO", "ETA", "SST")}
-        dev.close()
+        oc = qa.WindDrivenSlabOcean(qa.SphericalGrid(nlat, nlon), mask, 50.0, init_Ts=sst, params=p)
+        oc.uo, oc.vo, oc.eta = uo, vo, np.zeros((nlat, nlon))
+        oc.step(300.0, st["U"], st["V"])
+        assert oc.last_n_sub >= 2
+        out[mode] = {"UO": oc.uo.copy(), "VO": oc.vo.copy(), "ETA": oc.eta.copy(), "SST": oc.Ts.copy()}
+        oc._dev.close()
+    # third party: the oracle's ocean step from the same state and winds -- the bug this test was written for lived in one of the
+    # two DEVICE forms
+    oo = qo.OceanOracle(qo.Grid(nlat, nlon), mask, qo.defaults(energy_w=1.0, ocean_cfl=0.05, ocean_outlier=outlier), init_Ts=sst.copy())
+    oo.uo, oo.vo, oo.eta = uo.copy(), vo.copy(), np.zeros((nlat, nlon))
+    oo.step(300.0, st["U"], st["V"])
+    assert oo.last_n_sub >= 2
+    want = {"UO": oo.uo, "VO": oo.vo, "ETA": oo.eta, "SST": oo.Ts}
+    assert np.max(np.hypot(want["UO"], want["VO"])) <= 3.0 + 1e-9             # nothing is left above QD_OCEAN_MAX_U
+    for k in want:
+        for mode in ("0", tail):
+            e = relerr(out[mode][k], want[k])
+            assert e < 1e-10, ("vs oracle", outlier, mode, k, e)
     for k in out["0"]:
         e = relerr(out[tail][k], out["0"][k])
         bad = np.argwhere(np.abs(out[tail][k] - out["0"][k]) > 1e-9)
