@@ -37,7 +37,10 @@ QdScope::QdScope(qd_ctx* c_, const char* n, bool attach_) : c(c_), name(n), atta
     if (on) { e0 = qd_get_event(c); e1 = qd_get_event(c); if (!attach) hipEventRecord(e0, c->stream); }
 }
 QdScope::~QdScope() {
-    if (on) { if (!attach) hipEventRecord(e1, c->stream); c->pending.push_back({e0, e1, name}); }
+    if (!on) return;
+    if (attach && !used) { c->ev_free.push_back(e0); c->ev_free.push_back(e1); return; }   // never recorded: nothing to resolve
+    if (!attach) hipEventRecord(e1, c->stream);
+    c->pending.push_back({e0, e1, name});
 }
 static void qd_resolve_timers(qd_ctx* c) {
     if (c->pending.empty()) return;

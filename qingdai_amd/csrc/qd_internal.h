@@ -254,6 +254,7 @@ int qd_fail(qd_ctx* c, const char* what, hipError_t e = hipSuccess);
 
 struct QdScope {               // optional per-kernel-group timing with hipEvents on the handle's stream
     qd_ctx* c; const char* name; hipEvent_t e0 = nullptr, e1 = nullptr; bool on = false, attach = false;
+    bool used = false;          // attach: a launch has taken the events (an early return between the scope and its launch leaves them unrecorded)
     // attach_ = true: the group is ONE launch and the caller hands e0 / e1 to hipExtLaunchKernelGGL (QD_LAUNCH_TIMED), which takes
     // the start / stop time from the dispatch itself (what the rocprofv3 kernel trace reports); otherwise the events are recorded
     // around the group, and the pair also brackets the dispatch gaps on either side (~3.5 us per bracket on this stack)
@@ -261,7 +262,7 @@ struct QdScope {               // optional per-kernel-group timing with hipEvent
     ~QdScope();
 };
 #define QD_LAUNCH_TIMED(sc, kernel, grid, block, stream, ...) do { \
-    if ((sc).on && (sc).attach) hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, (sc).e0, (sc).e1, 0, __VA_ARGS__); \
+    if ((sc).on && (sc).attach) { (sc).used = true; hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, (sc).e0, (sc).e1, 0, __VA_ARGS__); } \
     else hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__); } while (0)
 
 // ---- latitude-band planning (qd_band.hip) ----------------------------------------------------

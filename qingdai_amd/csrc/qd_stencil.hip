@@ -160,7 +160,9 @@ k_shapiro_stream(QdGeom G, QdFieldList fl, int scrub, int R, int ntc, int nstrip
 #pragma unroll
     for (int p = NP; p > 0; --p) { a[p - 1] = max(0, a[p] - 1); b[p - 1] = min(n - 1, b[p] + 1); }
     const int t0 = a[0], t1 = b[NP] + NP;       // the last owned row leaves the cascade NP ticks after it was read
-    auto row_off = [&](int g) { return (unsigned)qd_lrow(G, min(g, n - 1)) * (unsigned)G.nlon; };
+    // the prefetch runs up to 15 rows past the strip: clamp into the domain AND into the slab (a band's slab ends lrows_ rows in;
+    // the row offset sits in the SGPR offset of the buffer access, which the range check of the resource does not see)
+    auto row_off = [&](int g) { return (unsigned)min(qd_lrow(G, min(g, n - 1)), G.lrows_ - 1) * (unsigned)G.nlon; };
     double pf[QD_SH_PF], h1[NP], h2[NP];
 #pragma unroll
     for (int k = 0; k < QD_SH_PF; ++k) pf[k] = qd_buf_ld(src, row_off(t0 + k), vo);

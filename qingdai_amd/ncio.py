@@ -79,3 +79,31 @@ def read_nc(path, names=None):
         for k, val in ds._attributes.items():
             attrs[k] = val.decode() if isinstance(val, bytes) else (float(val) if np.ndim(val) == 0 else val)
     return out, attrs
+
+
+def read_nc_full(path):
+    """-> (dims {name: size}, variables {name: (dtype code, dim names, native-endian ndarray)}, attrs): everything a file holds, in
+    the shape write_nc takes -- used to carry the variables this build does not own through a rewrite of a shared file."""
+    dims, out, attrs = {}, {}, {}
+    if backend() == "netCDF4":
+        from netCDF4 import Dataset
+        with Dataset(path, "r") as ds:
+            for d, dim in ds.dimensions.items():
+                dims[d] = len(dim)
+            for name, var in ds.variables.items():
+                a = np.array(var[...])
+                out[name] = (a.dtype.str.lstrip("<>=|"), tuple(var.dimensions), a)
+            for k in ds.ncattrs():
+                attrs[k] = ds.getncattr(k)
+        return dims, out, attrs
+    from scipy.io import netcdf_file
+    with netcdf_file(path, "r", mmap=False) as ds:
+        for d, n in ds.dimensions.items():
+            dims[d] = int(n) if n is not None else 0
+        for name, var in ds.variables.items():
+            a = np.array(var[:]) if var.shape else np.array(var.getValue())
+            a = a.astype(a.dtype.newbyteorder("="))
+            out[name] = (a.dtype.str.lstrip("<>=|"), tuple(var.dimensions), a)
+        for k, val in ds._attributes.items():
+            attrs[k] = val.decode() if isinstance(val, bytes) else (float(val) if np.ndim(val) == 0 else val)
+    return dims, out, attrs

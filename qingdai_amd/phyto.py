@@ -93,15 +93,33 @@ class PhytoTracers:
 
     # -- data/plankton.nc, the tracer part of save_distribution_nc / load_distribution_nc (phyto.py:737-802)
     def save_distribution_nc(self, path, day_value=None):
+        """phyto.py:737-802.  This build owns the tracer part of plankton.nc (lat, lon, C_phyto_s, S, day).  The reference's file also
+        holds what its DAILY host code maintains (alpha_water_scalar, Kd_490, the prognostic nutrient pool N, alpha_water_bands,
+        bands_lambda_centers, the band dimension, H_mld_m, NB): when a file of the same grid and species count is already there --
+        a data directory shared with a reference run -- those variables and attributes are carried through the rewrite."""
         from . import ncio
         try:
             g = self.grid
+            dims = {"lat": g.n_lat, "lon": g.n_lon, "species": self.S}
             v = {"lat": ("f4", ("lat",), np.asarray(g.lat, np.float32)), "lon": ("f4", ("lon",), np.asarray(g.lon, np.float32)),
                  "C_phyto_s": ("f4", ("species", "lat", "lon"), self.C_phyto_s.astype(np.float32))}
             attrs = {"title": "Qingdai Phytoplankton Distributions", "S": int(self.S)}
+            if os.path.exists(path):
+                try:
+                    odims, ovars, oattrs = ncio.read_nc_full(path)
+                    if all(odims.get(k) == n for k, n in dims.items()):
+                        for d, n in odims.items():
+                            dims.setdefault(d, n)
+                        for name, rec in ovars.items():
+                            v.setdefault(name, rec)
+                        for k, val in oattrs.items():
+                            if k != "day":
+                                attrs.setdefault(k, val)
+                except Exception as e:                          # an unreadable old file is replaced, like the reference does
+                    print(f"[Phyto] plankton.nc: could not carry the existing variables through ({e}).")
             if day_value is not None:
                 attrs["day"] = float(day_value)
-            ncio.write_nc(path, {"lat": g.n_lat, "lon": g.n_lon, "species": self.S}, v, attrs)
+            ncio.write_nc(path, dims, v, attrs)
             return True
         except Exception as e:                                  # the reference logs and carries on
             print(f"[Phyto] save_distribution_nc failed: {e}")

@@ -180,5 +180,27 @@ def test_phyto_tracers_initial_state_and_plankton_nc(tmp_path, monkeypatch):
     ph2 = PhytoTracers(grid, mask)
     assert ph2.load_distribution_nc(path)
     assert np.allclose(ph2.C_phyto_s, ph.C_phyto_s, rtol=1e-6)
+    # a plankton.nc written by the REFERENCE (phyto.py:737-802) also holds what its daily host code maintains -- the prognostic
+    # nutrient pool N, Kd_490, the water albedo maps, the band axis: an autosave of this build must not drop them
+    nb = 4
+    ref_vars = {"lat": ("f4", ("lat",), np.asarray(grid.lat, np.float32)), "lon": ("f4", ("lon",), np.asarray(grid.lon, np.float32)),
+                "C_phyto_s": ("f4", ("species", "lat", "lon"), np.zeros((3, 19, 36), np.float32)),
+                "alpha_water_bands": ("f4", ("band", "lat", "lon"), np.full((nb, 19, 36), 0.06, np.float32)),
+                "alpha_water_scalar": ("f4", ("lat", "lon"), np.full((19, 36), 0.07, np.float32)),
+                "Kd_490": ("f4", ("lat", "lon"), np.full((19, 36), 0.11, np.float32)),
+                "N": ("f4", ("lat", "lon"), np.linspace(0, 1, 19 * 36, dtype=np.float32).reshape(19, 36)),
+                "bands_lambda_centers": ("f4", ("band",), np.array([400, 500, 600, 700], np.float32))}
+    shared = str(tmp_path / "shared" / "plankton.nc")
+    ncio.write_nc(shared, {"lat": 19, "lon": 36, "species": 3, "band": nb}, ref_vars,
+                  {"title": "Qingdai Phytoplankton Distributions", "H_mld_m": 50.0, "S": 3, "NB": nb, "day": 1.0})
+    assert ph.save_distribution_nc(shared, day_value=4.25)
+    dims, got, attrs = ncio.read_nc_full(shared)
+    assert dims == {"lat": 19, "lon": 36, "species": 3, "band": nb}
+    for name in ("alpha_water_bands", "alpha_water_scalar", "Kd_490", "N", "bands_lambda_centers"):
+        assert got[name][1] == ref_vars[name][1] and np.array_equal(got[name][2], ref_vars[name][2]), name
+    assert np.allclose(got["C_phyto_s"][2], ph.C_phyto_s, rtol=1e-6)        # ... while the tracers are the new ones
+    assert float(attrs["day"]) == 4.25 and float(attrs["H_mld_m"]) == 50.0 and int(attrs["NB"]) == nb
     monkeypatch.setenv("QD_PHYTO_NSPECIES", "2")
     assert not PhytoTracers(grid, mask).load_distribution_nc(path)          # species count mismatch: keep the current state
+    assert PhytoTracers(grid, mask).save_distribution_nc(shared, day_value=5.0)      # a file of another species count is replaced
+    assert ncio.read_nc_full(shared)[0] == {"lat": 19, "lon": 36, "species": 2}
