@@ -4,6 +4,7 @@ bench.py -- headline benchmark: simulated planet-days per wall-second at 721x144
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...          (no launcher: the script starts its N rank processes itself, before any HIP call)
 
 A "step" is one pass of the per-timestep grid update over the synthetic seed-42 planet:
 forcing (two-star insolation + Teq) -> SpectralModel.time_step(Teq, dt, albedo) with the explicit
@@ -193,6 +194,42 @@ def ecology_leg(dev, grid, mask, forcing, dt, W, K):
             "dtype": "f64", "note": "loop = driver iteration incl. hydrology commit; daily population dynamics are host code, not timed"}
 
 
+def spawn_ranks(n):
+    """`bench.py --gpus N` without a launcher: start the N rank processes as fresh children (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in their environment, like torch.distributed.run sets them) and exit with the worst of their codes.  This process has
+    not loaded libqingdai_hip.so or touched HIP at this point, and it never does."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:                               # a free port for the file rendezvous key (bands.exchange_unique_id)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for pr in procs:
+        rc = max(rc, abs(pr.wait()))
+    raise SystemExit(rc)
+
+
+def find_profile(nlat, nlon):
+    """The newest committed rocprofv3 summary (profiles/rNN*_fused_kernels.json, scripts/profile_round.sh + assemble_profiles.py) whose
+    grid is this run's; None when there is none."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_fused_kernels.json"))):
+        try:
+            with open(f) as fh:
+                pj = json.load(fh)
+        except Exception:
+            continue
+        if pj.get("grid") == [nlat, nlon]:
+            best = (f, pj)                                    # sorted by name: r03 after r02
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -209,6 +246,8 @@ def main():
     ap.add_argument("--timing-stride", type=int, default=-1,
                     help="bracket every n-th launch of the profiled kernels with HIP events (default: automatic, see below; "
                          "1 = every launch, 1000000 = practically none)")
+    ap.add_argument("--spawn-check", action="store_true",
+                    help="(test hook) every rank prints its launcher environment and exits before loading the library")
     ap.add_argument("--profile-kernel", default="k_dyn_hyper",
                     help="kernel whose HIP-event time feeds `roofline` (k_dyn_hyper: the fused dynamics + del^4 kernel)")
     args = ap.parse_args()
@@ -218,9 +257,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("QD_BENCH_ONE_DEVICE") == "1":     # rehearsal of the multi-rank flow on a 1-GPU box
         local_rank = 0
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)                                # never returns
+    if args.spawn_check:
+        print(json.dumps({k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}), flush=True)
+        return
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run / torchrun "
-                         f"(--nproc-per-node {args.gpus}); only the launcher's env vars are used, not torch")
+                         f"(--nproc-per-node {args.gpus}) or without any launcher; only the launcher's env vars are used, not torch")
 
     with_ocean = not args.no_ocean
     with_phys = not args.no_driver_physics
@@ -331,10 +375,9 @@ def main():
     #   traffic                 FETCH_SIZE (x2: gfx950 correction) + WRITE_SIZE per launch, bytes
     #   avg_kernel_ms_rocprof   the kernel-trace duration of the committed profile (the events above time the same interval live)
     try:
-        prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_fused_kernels.json")
-        with open(prof) as fh:
-            pj = json.load(fh)
-        if args.gpus == 1 and [args.nlat, args.nlon] == pj.get("grid"):
+        found = find_profile(args.nlat, args.nlon)
+        if args.gpus == 1 and found:
+            prof, pj = found
             for kname, key in ((args.profile_kernel, "roofline"), (also, "roofline_ocean_substep")):
                 if kname and key in out and kname in pj["kernels"]:
                     e = pj["kernels"][kname]
@@ -342,7 +385,7 @@ def main():
                     out[key]["avg_kernel_ms_rocprof"] = e.get("avg_kernel_ms_rocprof")
                     if e.get("avg_kernel_ms_rocprof"):
                         out[key]["frac_rocprof"] = (out[key]["bytes_per_cell"] * cells / 1e9) / (e["avg_kernel_ms_rocprof"] / 1e3) / HBM_PEAK_GBS
-                    out[key]["profile_source"] = "profiles/r02_fused_kernels.json (" + pj.get("source", "") + ")"
+                    out[key]["profile_source"] = "profiles/" + os.path.basename(prof) + " (" + pj.get("source", "") + ")"
                     # the committed profile carries a hash of the kernel sources it was measured on: say so when they have changed since
                     import hashlib
                     cs = os.path.join(os.path.dirname(os.path.abspath(__file__)), "qingdai_amd", "csrc")

@@ -2,7 +2,7 @@
 """Turns the output of scripts/profile_round.sh (gpurun_out/<tag>/) into the committed summaries profiles/<tag>_*:
 kernel stats / trace summary / step timeline / bench lines (copied), <tag>_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE per launch),
 <tag>_pmc_sq.json and <tag>_fused_kernels.json (what bench.py reads for roofline.traffic / avg_kernel_ms_rocprof).
-usage: assemble_profiles.py <tag> [tcc.json]"""
+usage: assemble_profiles.py <tag> [tcc.json]      (the grid of the run: QD_PROF_NLAT / QD_PROF_NLON, default 721 x 1440)"""
 import json
 import os
 import re
@@ -30,7 +30,8 @@ def main():
         name, n, mean = m.group(1).strip(), int(m.group(3)), float(m.group(4))
         n0, m0 = tr.get(name, (0, 0.0))
         tr[name] = (n0 + n, (m0 * n0 + mean * n) / (n0 + n))
-    cells = 721 * 1440
+    nlat, nlon = int(os.environ.get("QD_PROF_NLAT", "721")), int(os.environ.get("QD_PROF_NLON", "1440"))
+    cells = nlat * nlon
     cal = "k_precip_blend"
     traffic = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, no stats/sys-trace; scripts/profile_round.sh) "
                        "of `bench.py --no-cpu-baseline --no-ecology-leg --steps 12 --warmup 4`; mean per dispatch, counters in KiB.  Correction per "
@@ -55,9 +56,9 @@ def main():
             sq["kernels"][k] = e
     json.dump(sq, open(os.path.join(P, f"{tag}_pmc_sq.json"), "w"), indent=1)
     import hashlib
-    srcs = ["qd_stream.hip", "qd_ocntail.hip", "qd_wave.h"]
+    srcs = ["qd_stream.hip", "qd_stream.h", "qd_ocntail.hip", "qd_wave.h"]
     stamp = {f: hashlib.sha256(open(os.path.join(ROOT, "qingdai_amd", "csrc", f), "rb").read()).hexdigest()[:16] for f in srcs}
-    fk = {"grid": [721, 1440], "kernel_sources_sha256_16": stamp, "source": f"rocprofv3 kernel trace + FETCH_SIZE / WRITE_SIZE passes of bench.py (scripts/profile_round.sh {tag}, "
+    fk = {"grid": [nlat, nlon], "kernel_sources_sha256_16": stamp, "source": f"rocprofv3 kernel trace + FETCH_SIZE / WRITE_SIZE passes of bench.py (scripts/profile_round.sh {tag}, "
                                          f"scripts/assemble_profiles.py); profiles/README.md", "kernels": {}}
     dyn = next(k for k in tr if "k_dyn_stream" in k)
     for grp, kn in (("k_dyn_hyper", dyn), ("k_ocn_hyper", "k_ocn_stream"), ("ocean_tail", "k_ocn_tail_stream")):

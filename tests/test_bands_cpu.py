@@ -342,3 +342,27 @@ def test_library_planner_drives_gloo_halo_exchanges(world):
         assert bad == [], (rank, bad)
         assert 1 <= n_exch < 12, (rank, n_exch)                              # deep halos: fewer exchanges than launches
     assert len({r[2] for r in res}) == 1                                     # every rank decided on the same exchanges
+
+
+def test_bench_spawns_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment starts N fresh rank processes itself (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT like torch.distributed.run sets them) before anything touches HIP; with a launcher's
+    environment it is a rank.  --spawn-check makes every rank print that environment and stop before the library is loaded."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--spawn-check"], env=env, capture_output=True,
+                         text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    recs = sorted((json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")), key=lambda r: int(r["RANK"]))
+    assert [r["RANK"] for r in recs] == ["0", "1", "2"] and [r["LOCAL_RANK"] for r in recs] == ["0", "1", "2"]
+    assert {r["WORLD_SIZE"] for r in recs} == {"3"} and {r["MASTER_ADDR"] for r in recs} == {"127.0.0.1"}
+    assert len({r["MASTER_PORT"] for r in recs}) == 1
+    # under a launcher: one process, its own rank
+    env2 = dict(env, RANK="1", LOCAL_RANK="1", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    out2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--spawn-check"], env=env2, capture_output=True,
+                          text=True, timeout=120)
+    assert out2.returncode == 0 and json.loads(out2.stdout.strip())["RANK"] == "1"
