@@ -191,6 +191,10 @@ struct qd_ctx {
     double* med_pred = nullptr;      // [4 sites][16]: last median, valid flag, statistics, published bracket (see qd_reduce.hip): predicted median brackets (qd_reduce.hip)
     int med_predict = 1;             // QD_MEDIAN_PREDICT=0: always the two-histogram-pass select
     int med_seen[4] = {0, 0, 0, 0};  // call sites that have a window centre on the device
+    int med_one = 0;                 // QD_MEDIAN_ONE=1: the windowed median as ONE launch (k_med_one) instead of three -- measured equal
+                                     // (39.6 us against 17 + 13 + 11: the chain of flush / ticket / fence round trips is the cost, not the launches)
+    unsigned long long med_gen = 0;  // generation of k_med_one's bracket flag
+    unsigned int* med_err = nullptr; // raised by a k_med_one workgroup that gave up waiting (checked by qd_sync)
     double* med_gather = nullptr;    // band handles: [world][4 + 4092] gathered candidate segments of the windowed median
     double* hpin = nullptr;        // pinned host scalars
     double* hpin_rows = nullptr;   // pinned, 2 x slab rows: per-row partial maxima read back in one copy

@@ -373,9 +373,9 @@ k_sel_final(unsigned long long* st, const double* __restrict__ cand, unsigned in
 #define QD_MED_SITES 4
 #define QD_MED_BAND_CAP 4092u      // candidates per band in the gathered segments (4096 doubles each)
 #define QD_MED_WSHIFT 44
-__global__ void __launch_bounds__(QD_BLOCK)
-k_med_hist(QdGeom G, const double* __restrict__ x, int transform, double tparam, double* pred, unsigned long long* st,
-           unsigned int* hist, int mode) {
+// returns true in the workgroup that ran the scan and published the bracket (mode 0: the last one to finish; mode 2: the only one)
+__device__ __forceinline__ bool qd_med_hist_body(const QdGeom& G, const double* __restrict__ x, int transform, double tparam, double* pred,
+                                                 unsigned long long* st, unsigned int* hist, int mode, int nblk_x, int nblk_y, int bx, int by) {
     // mode 0: histogram + scan by the last workgroup (whole-globe handles)
     // mode 1: histogram only   mode 2: scan only (one workgroup) -- latitude bands all-reduce the histogram in between
     __shared__ unsigned int sh[QD_HIST_BINS + 2];             // + count of positives, + count below the window
@@ -390,11 +390,11 @@ k_med_hist(QdGeom G, const double* __restrict__ x, int transform, double tparam,
     if (mode != 2) {
     for (int k = t; k < QD_HIST_BINS + 2; k += QD_BLOCK) sh[k] = 0u;
     __syncthreads();
-    const int jstep = gridDim.x * QD_BLOCK;
+    const int jstep = nblk_x * QD_BLOCK;
     unsigned int n_pos = 0, n_below = 0;
-    for (int i = G.row0 + (int)blockIdx.y; i < G.row0 + G.nrows; i += (int)gridDim.y) {
+    for (int i = G.row0 + by; i < G.row0 + G.nrows; i += nblk_y) {
         const size_t b = (size_t)qd_lrow(G, i) * G.nlon;
-        for (int jb = blockIdx.x * QD_BLOCK; jb < G.nlon; jb += 8 * jstep) {
+        for (int jb = bx * QD_BLOCK; jb < G.nlon; jb += 8 * jstep) {
             double vbuf[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -426,14 +426,14 @@ k_med_hist(QdGeom G, const double* __restrict__ x, int transform, double tparam,
     __syncthreads();
     for (int k = t; k < QD_HIST_BINS + 2; k += QD_BLOCK) if (sh[k]) atomicAdd(&hist[k], sh[k]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (mode == 1) return;
+    if (mode == 1) return false;
     __syncthreads();
     if (t == 0) {
         const unsigned long long ticket = atomicAdd(&st[6], 1ull);
-        s_last = (ticket == (unsigned long long)(gridDim.x * gridDim.y) - 1ull) ? 1 : 0;
+        s_last = (ticket == (unsigned long long)(nblk_x * nblk_y) - 1ull) ? 1 : 0;
     }
     __syncthreads();
-    if (!s_last) return;
+    if (!s_last) return false;
     }   // mode != 2
     // ---- last workgroup: bins of the two middle ranks
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -494,25 +494,30 @@ k_med_hist(QdGeom G, const double* __restrict__ x, int transform, double tparam,
         __hip_atomic_store(&st[6], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     for (int k = t; k < QD_HIST_BINS + 2; k += QD_BLOCK) __hip_atomic_store(&hist[k], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
+
+__global__ void __launch_bounds__(QD_BLOCK)
+k_med_hist(QdGeom G, const double* __restrict__ x, int transform, double tparam, double* pred, unsigned long long* st,
+           unsigned int* hist, int mode) {
+    qd_med_hist_body(G, x, transform, tparam, pred, st, hist, mode, (int)gridDim.x, (int)gridDim.y, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 __global__ void k_med_seed(double* pred, const double* out, const unsigned long long* count) {
     if (threadIdx.x == 0 && blockIdx.x == 0) { pred[0] = *out; pred[3] = (*count > 0ull) ? 1.0 : 0.0; }
 }
 
-__global__ void __launch_bounds__(QD_BLOCK)
-k_med_bracket(QdGeom G, const double* __restrict__ x, int transform, double tparam, const double* __restrict__ pred,
-              unsigned long long* st, double* __restrict__ cand, unsigned int* __restrict__ ccount, unsigned int cap) {
-    if (pred[2] != 0.0) return;                                               // k_med_hist counted no positive entry (its pred[10]: this kernel gets pred + 8)
-    const bool valid = pred[3] != 0.0;
-    const double lo = valid ? pred[0] : 0.0, hi = valid ? pred[1] : -1.0;     // invalid: empty bracket, the finisher falls back
+// lo > hi: empty bracket (the finisher falls back to the field itself)
+__device__ __forceinline__ void qd_med_bracket_body(const QdGeom& G, const double* __restrict__ x, int transform, double tparam, double lo, double hi,
+                                                    unsigned long long* st, double* __restrict__ cand, unsigned int* __restrict__ ccount,
+                                                    unsigned int cap, int nblk_x, int nblk_y, int bx, int by) {
     const int t = threadIdx.x, lane = t & 63;
-    const int jstep = gridDim.x * QD_BLOCK;
+    const int jstep = nblk_x * QD_BLOCK;
     const unsigned long long lt = (1ull << lane) - 1ull;
     unsigned int n_pos = 0, n_below = 0;
-    for (int i = G.row0 + (int)blockIdx.y; i < G.row0 + G.nrows; i += (int)gridDim.y) {
+    for (int i = G.row0 + by; i < G.row0 + G.nrows; i += nblk_y) {
         const size_t b = (size_t)qd_lrow(G, i) * G.nlon;
-        for (int jb = blockIdx.x * QD_BLOCK; jb < G.nlon; jb += 8 * jstep) {
+        for (int jb = bx * QD_BLOCK; jb < G.nlon; jb += 8 * jstep) {
             double vbuf[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -553,6 +558,15 @@ k_med_bracket(QdGeom G, const double* __restrict__ x, int transform, double tpar
     }
 }
 
+__global__ void __launch_bounds__(QD_BLOCK)
+k_med_bracket(QdGeom G, const double* __restrict__ x, int transform, double tparam, const double* __restrict__ pred,
+              unsigned long long* st, double* __restrict__ cand, unsigned int* __restrict__ ccount, unsigned int cap) {
+    if (pred[2] != 0.0) return;                                               // k_med_hist counted no positive entry (its pred[10]: this kernel gets pred + 8)
+    const bool valid = pred[3] != 0.0;
+    const double lo = valid ? pred[0] : 0.0, hi = valid ? pred[1] : -1.0;     // invalid: empty bracket, the finisher falls back
+    qd_med_bracket_body(G, x, transform, tparam, lo, hi, st, cand, ccount, cap, (int)gridDim.x, (int)gridDim.y, (int)blockIdx.x, (int)blockIdx.y);
+}
+
 // value of element k of the select source: the candidate list, or (fallback) the transformed field; non-positive = skip
 // src 0: candidate list; 1: the field; 2: the gathered per-band segments [world][4 + cap] = {m_r, c_lo_r, M_r, -, candidates}
 __device__ __forceinline__ double qd_med_src(const double* __restrict__ list, const double* __restrict__ field, int src,
@@ -572,18 +586,19 @@ __global__ void k_med_pack(unsigned long long* st, unsigned int* ccount, double*
     }
 }
 
-__global__ void __launch_bounds__(QD_FIN_BLOCK)
-k_med_final(unsigned long long* st, const double* __restrict__ cand, unsigned int* ccount, double* pred,
-            const double* __restrict__ field, unsigned long long n_field, int transform, double tparam, double dflt, double* out,
-            unsigned long long* count_out, int world, unsigned int cap, double* miss_flag) {
+template <int NT>
+__device__ __forceinline__ void qd_med_final_body(unsigned long long* st, const double* __restrict__ cand, unsigned int* ccount, double* pred,
+                                                  const double* __restrict__ field, unsigned long long n_field, int transform, double tparam,
+                                                  double dflt, double* out, unsigned long long* count_out, int world, unsigned int cap,
+                                                  double* miss_flag) {
     // world > 0: latitude bands -- `cand` holds the all-gathered segments; counts are the sums of their headers; when the
     // ranks are not inside the gathered lists (a band overflowed its capacity, or the window missed) nothing is written but
     // *miss_flag = 1 and the host falls back to the digit-by-digit select on every band
     __shared__ unsigned int sh[QD_HIST_BINS];
-    __shared__ unsigned int wtot[QD_FIN_BLOCK / 64];
+    __shared__ unsigned int wtot[NT / 64];
     __shared__ unsigned long long s_prefix, s_rank;
-    __shared__ double s_min[QD_FIN_BLOCK / 64];
-    __shared__ unsigned int s_cnt[QD_FIN_BLOCK / 64];
+    __shared__ double s_min[NT / 64];
+    __shared__ unsigned int s_cnt[NT / 64];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     unsigned long long m, c_lo;
     unsigned int M;
@@ -637,18 +652,20 @@ k_med_final(unsigned long long* st, const double* __restrict__ cand, unsigned in
             __syncthreads();
             continue;
         }
-        for (int k = t; k < QD_HIST_BINS; k += QD_FIN_BLOCK) sh[k] = 0u;
+        for (int k = t; k < QD_HIST_BINS; k += NT) sh[k] = 0u;
         __syncthreads();
         const unsigned long long pre = up >= 64 ? 0ull : (s_prefix >> up), r = s_rank;
-        for (size_t k = t; k < N; k += QD_FIN_BLOCK) {
+        for (size_t k = t; k < N; k += NT) {
             const double v = qd_med_src(cand, field, src, k, transform, tparam, cap);
             if (!(v > 0.0)) continue;
             const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
             if (up >= 64 || (bits >> up) == pre) atomicAdd(&sh[(unsigned int)((bits >> shift) & ((1u << width) - 1u))], 1u);
         }
         __syncthreads();
-        const unsigned int h0 = sh[2 * t], h1 = sh[2 * t + 1];
-        const unsigned int mine = h0 + h1;
+        constexpr int PER = QD_HIST_BINS / NT;                            // bins per thread
+        unsigned int mine = 0;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) mine += sh[PER * t + q];
         unsigned int inc = mine;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const unsigned int y = __shfl_up(inc, o, 64); if (lane >= o) inc += y; }
@@ -658,9 +675,11 @@ k_med_final(unsigned long long* st, const double* __restrict__ cand, unsigned in
         for (int k = 0; k < wv; ++k) base += wtot[k];
         const unsigned long long excl = (unsigned long long)base + inc - mine;
         if (mine > 0 && r >= excl && r < excl + mine) {
-            const int d = (r < excl + h0) ? 2 * t : 2 * t + 1;
+            unsigned long long cum = excl;
+            int d = PER * t;
+            for (; d < PER * t + PER - 1; ++d) { const unsigned int hv = sh[d]; if (cum + hv > r) break; cum += hv; }
             s_prefix = s_prefix | ((unsigned long long)d << shift);
-            s_rank = r - (d == 2 * t ? excl : excl + h0);
+            s_rank = r - cum;
         }
         __syncthreads();
     }
@@ -671,7 +690,7 @@ k_med_final(unsigned long long* st, const double* __restrict__ cand, unsigned in
         // of the target inside its run of equal values (0-based), so the run must be longer than s_rank + 1.
         unsigned int c_eq = 0;
         double mn = DBL_MAX;
-        for (size_t k = t; k < N; k += QD_FIN_BLOCK) {
+        for (size_t k = t; k < N; k += NT) {
             const double v = qd_med_src(cand, field, src, k, transform, tparam, cap);
             if (!(v > 0.0)) continue;
             c_eq += (v == v1) ? 1u : 0u;
@@ -683,7 +702,7 @@ k_med_final(unsigned long long* st, const double* __restrict__ cand, unsigned in
         __syncthreads();
         if (t == 0) {
             unsigned int ce = 0; double mm = DBL_MAX;
-            for (int k = 0; k < QD_FIN_BLOCK / 64; ++k) { ce += s_cnt[k]; mm = s_min[k] < mm ? s_min[k] : mm; }
+            for (int k = 0; k < NT / 64; ++k) { ce += s_cnt[k]; mm = s_min[k] < mm ? s_min[k] : mm; }
             v2 = ((unsigned long long)ce > s_rank + 1ull) ? v1 : mm;
         }
     }
@@ -697,6 +716,84 @@ k_med_final(unsigned long long* st, const double* __restrict__ cand, unsigned in
         pred[hit ? 4 : 5] += 1.0; pred[6] = (double)M; pred[7] = (double)m;      // statistics (QD_MEDIAN_DEBUG)
         if (world > 0) *miss_flag = 0.0; else { st[0] = 0ull; st[1] = 0ull; ccount[0] = 0u; }
     }
+}
+
+__global__ void __launch_bounds__(QD_FIN_BLOCK)
+k_med_final(unsigned long long* st, const double* __restrict__ cand, unsigned int* ccount, double* pred,
+            const double* __restrict__ field, unsigned long long n_field, int transform, double tparam, double dflt, double* out,
+            unsigned long long* count_out, int world, unsigned int cap, double* miss_flag) {
+    qd_med_final_body<QD_FIN_BLOCK>(st, cand, ccount, pred, field, n_field, transform, tparam, dflt, out, count_out, world, cap, miss_flag);
+}
+
+// ------------------------------------------------------------------ the windowed median in ONE launch (whole-globe handles)
+// k_med_hist -> k_med_bracket -> k_med_final are three launches of ~17 + 13 + 11 us, each mostly a chain of dependent round trips
+// (flush, ticket, fence, scan) plus its own ramp and boundary; three medians per step were 12 % of the step.  Here the same three
+// bodies run inside one launch of QD_MED_ONE_BLOCKS co-resident workgroups: everybody histograms, the last one scans and publishes
+// the bracket and then RELEASES a generation flag; everybody else waits on that flag (one lane polls, relaxed load + s_sleep,
+// then an agent acquire), collects its candidates, and the last one to finish that selects the ranks from the list.
+// Co-residency: 256 workgroups of 256 threads and 9 KB of LDS fit any gfx950 several times over, and the launch is alone on the device
+// (whole-globe handles run one stream; the in-process band groups never take this path).  The wait is bounded all the same: a
+// workgroup that does not see the flag after QD_MED_SPIN polls writes NaN to the result, raises *err and leaves.
+// MEASURED (rocprofv3 kernel trace, 721 x 1440): 39.6 us per median -- the same as the three launches.  What a median costs is the
+// chain of dependent round trips (LDS histogram -> flush atomics -> ticket -> acquire -> 2050 atomic loads -> scan -> release ->
+// flag -> acquire -> collect -> release -> ticket -> acquire -> six select passes), ~2 us each, not the launch boundaries.  Kept
+// behind QD_MEDIAN_ONE=1 (tests/test_gpu_parity.py runs both forms); the three-launch form stays the default.
+#define QD_MED_ONE_BLOCKS 256
+#define QD_MED_SPIN 400000
+__global__ void __launch_bounds__(QD_BLOCK)
+k_med_one(QdGeom G, const double* __restrict__ x, int transform, double tparam, double* pred, unsigned long long* st, unsigned int* hist,
+          double* __restrict__ cand, unsigned int* ccount, unsigned int cap, unsigned long long gen, unsigned long long n_field,
+          double dflt, double* out, unsigned long long* count_out, unsigned int* err) {
+    __shared__ int s_flag;
+    const int t = threadIdx.x;
+    const int nby = (int)gridDim.y, by = (int)blockIdx.y;
+    // ---- phase 1: windowed histogram; the last workgroup publishes pred[8..11]
+    const bool scanned = qd_med_hist_body(G, x, transform, tparam, pred, st, hist, 0, 1, nby, 0, by);
+    if (scanned) {                                           // (uniform per workgroup)
+        __syncthreads();                                     // thread 0's bracket stores and everybody's histogram resets are issued
+        if (t == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&st[7], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // ---- wait for the bracket
+    if (t == 0) {
+        int ok = 0;
+        for (int it = 0; it < QD_MED_SPIN; ++it) {
+            if (__hip_atomic_load(&st[7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) { ok = 1; break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_flag = ok;
+    }
+    __syncthreads();
+    if (!s_flag) {                                           // never seen on a healthy device: say so loudly instead of hanging
+        if (t == 0) { atomicExch(err, 1u); *out = __longlong_as_double(0x7FF8000000000000ll); }
+        return;
+    }
+    const double lo = __hip_atomic_load(&pred[8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double hi = __hip_atomic_load(&pred[9], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool none = __hip_atomic_load(&pred[10], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0;     // no positive entry at all
+    const bool okb = __hip_atomic_load(&pred[11], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0;
+    // ---- phase 2: candidates of the bracket + recount
+    if (!none) qd_med_bracket_body(G, x, transform, tparam, okb ? lo : 0.0, okb ? hi : -1.0, st, cand, ccount, cap, 1, nby, 0, by);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this workgroup's counter adds and list stores are complete
+    __syncthreads();
+    if (t == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the candidate list is plain stores: publish them before the ticket
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long ticket = atomicAdd(&st[5], 1ull);
+        s_flag = (ticket == (unsigned long long)nby - 1ull) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_flag) return;
+    // ---- the last workgroup: select the ranks from the list
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (t == 0) __hip_atomic_store(&st[5], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    qd_med_final_body<QD_BLOCK>(st, cand, ccount, pred, x, n_field, transform, tparam, dflt, out, count_out, 0, 0u, (double*)nullptr);
 }
 
 // result + reset of the select state for the next call; `count_out` (optional) keeps the count
@@ -725,6 +822,13 @@ int qd_median_positive_dev(qd_ctx* c, const double* x, double dflt, int slot, in
     if (c->geo.full && c->sel_cand && c->med_pred && c->med_predict && site >= 0 && site < QD_MED_SITES) {
         // windowed histogram around the site's last median, one collecting pass, one finishing workgroup
         double* pred = c->med_pred + 16 * site;
+        if (c->med_seen[site] && c->med_one) {
+            const dim3 g1(1, std::min(G.nrows, QD_MED_ONE_BLOCKS));
+            hipLaunchKernelGGL(k_med_one, g1, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, pred, c->sel_state, c->hist, c->sel_cand,
+                               c->sel_ccount, (unsigned int)c->geo.cells(), ++c->med_gen, (unsigned long long)c->geo.cells(), dflt,
+                               c->dscal + slot, c->dcount, c->med_err);
+            return 0;
+        }
         if (c->med_seen[site]) {
             hipLaunchKernelGGL(k_med_hist, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, pred, c->sel_state, c->hist, 0);
             hipLaunchKernelGGL(k_med_bracket, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, pred + 8, c->sel_state,

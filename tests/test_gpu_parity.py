@@ -235,8 +235,14 @@ def test_median_predicted_bracket(gpu, monkeypatch):
     got = [dev.op_median_positive(x, 1e-6) for x in seq]
     for k, (g, x) in enumerate(zip(got, seq)):
         assert g == want(x), (k, g, want(x))
-    monkeypatch.setenv("QD_MEDIAN_PREDICT", "0")
     p = qa.QdParams(); p.has_csmap = 0
+    monkeypatch.setenv("QD_MEDIAN_ONE", "1")                         # the same three bodies inside one launch (k_med_one)
+    dev1 = Device(qa.SphericalGrid(181, 300), p)
+    assert [dev1.op_median_positive(x, 1e-6) for x in seq] == got
+    dev1.sync()                                                      # (qd_sync reports a workgroup that gave up waiting)
+    dev1.close()
+    monkeypatch.delenv("QD_MEDIAN_ONE")
+    monkeypatch.setenv("QD_MEDIAN_PREDICT", "0")
     dev0 = Device(qa.SphericalGrid(181, 300), p)
     assert [dev0.op_median_positive(x, 1e-6) for x in seq] == got
     dev0.close()
