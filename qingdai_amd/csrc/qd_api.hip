@@ -307,6 +307,7 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
         hipMemsetAsync(c->med_pred, 0, 64 * sizeof(double), c->stream);
         { const char* ef = std::getenv("QD_MEDIAN_PREDICT"); if (ef && ef[0] == '0') c->med_predict = 0; }
         { const char* ef = std::getenv("QD_MEDIAN_ONE"); if (ef) c->med_one = ef[0] == '1' ? 1 : 0; }
+        { const char* ef = std::getenv("QD_MERGE_POINTWISE"); if (ef) c->merge_pointwise = ef[0] == '0' ? 0 : 1; }
         if ((e = hipMalloc(&c->med_err, sizeof(unsigned int))) != hipSuccess) return bail("hipMalloc", e);
         hipMemsetAsync(c->med_err, 0, sizeof(unsigned int), c->stream);
     }
@@ -544,9 +545,12 @@ extern "C" int qd_step_n(qd_handle c, int n, double dt, int flags, const double*
         // EcologyAdapter.step_subdaily sits between the glacier mask and the base-albedo blend (run_simulation.py:2075-2104):
         // its clock / canopy / alpha part runs before the albedo kernel, its E_day += isr dt rides on this step's forcing launch
         if (with_eco && c->eco.p.albedo_couple) { if ((rc = qd_eco_canopy_impl(c, dt))) return rc; c->eco.eday_dt = c->eco.p.use_lai ? dt : 0.0; }
-        if (with_phys) { if ((rc = qd_driver_physics_impl(c, dt))) return rc; }
+        // whole-globe handles: the forcing rides on the last launch of the driver physics (k_snow_albedo_forcing)
+        const bool merged = with_phys && c->geo.full && c->merge_pointwise;
+        const QdForcingCall fc{st, st + 3, st[6]};
+        if (with_phys) { if ((rc = qd_driver_physics_impl(c, dt, merged ? &fc : nullptr))) return rc; }
         else if ((rc = qd_simple_albedo_impl(c, 0.08))) return rc;
-        if ((rc = qd_forcing_impl(c, st, st + 3, st[6], 1))) return rc;
+        if (!merged && (rc = qd_forcing_impl(c, st, st + 3, st[6], 1))) return rc;
         if ((rc = qd_atmos_step_impl(c, dt, pass_alb ? 1 : 0))) return rc;
         // bit4: energy-budget means of the FIRST step, taken where the reference driver takes them -- after time_step, on the
         // fluxes of the coupling block (run_simulation.py:2199-2246) -- and kept for qd_energy_diagnostics_last

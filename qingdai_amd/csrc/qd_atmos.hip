@@ -11,6 +11,7 @@
 //   k_shapiro_pass    every QD_SHAPIRO_EVERY steps (dynamics.py:610-626)
 //   k_final           cloud gather with the NEW winds, decay, 0.998 damp, nan_to_num (dynamics.py:642-667)
 #include "qd_internal.h"
+#include "qd_pointwise.h"
 #include "qd_device.h"
 
 #include "qd_fluxes.h"
@@ -211,32 +212,16 @@ k_final(QdGeom G, const double* __restrict__ cosl, double dt, double a, double d
     Ts[o] = qd_nn(Ts[o]);
 }
 
-// ------------------------------------------------------------------ forcing.py:78-165
-struct QdStar { double flux, sin_d, cos_d, alpha; };
-
+// ------------------------------------------------------------------ forcing.py:78-165 (body: qd_pointwise.h)
 __global__ void __launch_bounds__(QD_BLOCK)
-k_forcing(QdGeom G, QdTabs T, QdStar A, QdStar B, double theta, double sigma, int with_teq,
-          double* __restrict__ isrA, double* __restrict__ isrB, double* __restrict__ isr,
+k_forcing(QdGeom G, QdTabs T, QdForcingP P, double* __restrict__ isrA, double* __restrict__ isrB, double* __restrict__ isr,
           const double* __restrict__ albedo, double* __restrict__ Teq, double* __restrict__ eday, double eday_dt) {
     const QdTile tl = qd_tile();
     const int j = tl.seg * QD_BLOCK + threadIdx.x;
     if (j >= G.nlon) return;
     const int i = G.row0 + tl.row;
     const size_t o = (size_t)qd_lrow(G, i) * G.nlon + j;
-    const double sl = T.sin_raw[i], cl = T.cos_raw[i], lon = T.lon_rad[j];
-    const double hA = theta + lon - A.alpha;
-    const double hB = theta + lon - B.alpha;
-    const double czA = qd_max(0.0, sl * A.sin_d + cl * A.cos_d * cos(hA));
-    const double czB = qd_max(0.0, sl * B.sin_d + cl * B.cos_d * cos(hB));
-    const double a_ = A.flux * czA, b_ = B.flux * czB;
-    const double tot = a_ + b_;
-    isrA[o] = a_; isrB[o] = b_; isr[o] = tot;
-    if (eday) eday[o] += qd_nn(tot) * eday_dt;                 // PopulationManager.step_subdaily (population.py:267-268)
-    if (with_teq) {
-        double num = tot * (1 - albedo[o]);
-        if (num < 0) num = 0;
-        Teq[o] = sqrt(sqrt(num / sigma));          // (num / SIGMA) ** 0.25
-    }
+    qd_forcing_cell(T, P, i, j, o, P.with_teq ? albedo[o] : 0.0, isrA, isrB, isr, Teq, eday, eday_dt);
 }
 
 int qd_forcing_impl(qd_ctx* c, const double* sa, const double* sb, double theta, int with_teq) {
@@ -245,8 +230,9 @@ int qd_forcing_impl(qd_ctx* c, const double* sa, const double* sb, double theta,
     QdStar B{sb[0], std::sin(sb[1]), std::cos(sb[1]), sb[2]};
     const int m = with_teq ? qd_plan(c, {QD_IN(c->f[QD_F_ALBEDO], 0)}) : c->geo.halo;
     if (m < 0) return -1;
-    QD_ROWS(c, m, G, hipLaunchKernelGGL(k_forcing, qd_grid2d(G), dim3(QD_BLOCK), 0, c->stream, G, c->tabs, A, B, theta,
-                                        5.670374e-8, with_teq, c->f[QD_F_ISR_A], c->f[QD_F_ISR_B], c->f[QD_F_ISR],
+    const QdForcingP FP{A, B, theta, 5.670374e-8, with_teq};
+    QD_ROWS(c, m, G, hipLaunchKernelGGL(k_forcing, qd_grid2d(G), dim3(QD_BLOCK), 0, c->stream, G, c->tabs, FP,
+                                        c->f[QD_F_ISR_A], c->f[QD_F_ISR_B], c->f[QD_F_ISR],
                                         c->f[QD_F_ALBEDO], c->f[QD_F_TEQ], c->eco.eday_dt > 0 ? c->f[QD_F_ECO_EDAY] : (double*)nullptr,
                                         c->eco.eday_dt));
     c->eco.eday_dt = 0;

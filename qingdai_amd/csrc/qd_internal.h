@@ -191,6 +191,7 @@ struct qd_ctx {
     double* med_pred = nullptr;      // [4 sites][16]: last median, valid flag, statistics, published bracket (see qd_reduce.hip): predicted median brackets (qd_reduce.hip)
     int med_predict = 1;             // QD_MEDIAN_PREDICT=0: always the two-histogram-pass select
     int med_seen[4] = {0, 0, 0, 0};  // call sites that have a window centre on the device
+    int merge_pointwise = 1;         // QD_MERGE_POINTWISE=0: every pointwise stage of qd_step_n as a launch of its own
     int med_one = 0;                 // QD_MEDIAN_ONE=1: the windowed median as ONE launch (k_med_one) instead of three -- measured equal
                                      // (39.6 us against 17 + 13 + 11: the chain of flush / ticket / fence round trips is the cost, not the launches)
     unsigned long long med_gen = 0;  // generation of k_med_one's bracket flag
@@ -351,7 +352,9 @@ int qd_simple_albedo_impl(qd_ctx* c, double ocean_albedo);
 int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask, int inject_sst);
 
 // qd_physics.hip
-int qd_driver_physics_impl(qd_ctx* c, double dt);
+// fc != nullptr (whole-globe handles): the forcing of the same step (stars, rotation angle) rides on the last launch of the physics
+struct QdForcingCall { const double* sa; const double* sb; double theta; };
+int qd_driver_physics_impl(qd_ctx* c, double dt, const QdForcingCall* fc = nullptr);
 int qd_hydrology_commit_impl(qd_ctx* c, double dt);
 
 // qd_api.hip

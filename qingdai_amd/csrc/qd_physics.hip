@@ -13,6 +13,7 @@
 //   k_advect + blur   cloud tracer advection, cos floor 0.5, sigma = 0.2 wrap (run_simulation.py:1916-1934)
 //   k_cloud_albedo    alpha-blend + ice fraction + dynamic albedo       (physics.py:164-250)
 #include "qd_internal.h"
+#include "qd_pointwise.h"
 #include "qd_device.h"
 
 __device__ __forceinline__ double qd_wsum(double x) {
@@ -176,9 +177,7 @@ k_cloud_blend(QdGeom G, QdBlendP P, const double* __restrict__ cfp, const double
     cloud[o] = qd_clip(c, 0.0, 1.0);
 }
 
-struct QdAlbP { double alpha, hice_ref_safe, alpha_ice, alpha_cloud, alpha_water, alpha_snow, w_lai; int do_adv, use_topo, snow, eco, banded, water, eco_f32; };
-
-// cloud <- clip((1-a) cloud + a adv, 0, 1)  and  the dynamic albedo (physics.py:164-250)
+// cloud <- clip((1-a) cloud + a adv, 0, 1)  and  the dynamic albedo (physics.py:164-250); body: qd_pointwise.h
 __global__ void __launch_bounds__(QD_BLOCK)
 k_cloud_albedo(QdGeom G, QdAlbP P, const double* __restrict__ adv, double* __restrict__ cloud,
                const double* __restrict__ cloud_eff, const double* __restrict__ hice,
@@ -191,30 +190,10 @@ k_cloud_albedo(QdGeom G, QdAlbP P, const double* __restrict__ adv, double* __res
     const size_t o = (size_t)qd_lrow(G, G.row0 + tl.row) * G.nlon + j;
     double c = cloud[o];
     if (P.do_adv) { c = qd_clip((1.0 - P.alpha) * c + P.alpha * adv[o], 0.0, 1.0); cloud[o] = c; }
-    const double crad = cloud_eff ? cloud_eff[o] : c;
-    const double C = qd_clip(crad, 0.0, 1.0);
-    const double ice_frac = 1.0 - exp(-qd_max(hice[o], 0.0) / P.hice_ref_safe);
-    double fi = qd_clip(ice_frac, 0.0, 1.0);
-    fi = fi * ((land[o] == 0) ? 1.0 : 0.0);
-    double b0 = P.use_topo ? base[o] : P.alpha_water;
-    if (P.eco && land[o] == 1 && glacier[o] == 0.0) {        // run_simulation.py:2086-2100: ecology alpha, not on ice sheets
-        const double ae = P.eco_f32 ? (double)reinterpret_cast<const float*>(eco_alpha)[o] : eco_alpha[o];
-        if (fabs(ae) <= DBL_MAX) b0 = (1.0 - P.w_lai) * b0 + P.w_lai * ae;
-    }
-    if (P.banded && land[o] == 1) {                          // run_simulation.py:2107-2112: daily banded alpha
-        const double ab = P.eco_f32 ? (double)reinterpret_cast<const float*>(banded)[o] : banded[o];
-        if (fabs(ab) <= DBL_MAX) b0 = qd_clip(ab, 0.0, 1.0);
-    }
-    if (P.water && land[o] == 0) {                           // run_simulation.py:2121-2128: ocean colour
-        const double aw = water[o];
-        if (fabs(aw) <= DBL_MAX) b0 = qd_clip(aw, 0.0, 1.0);
-    }
-    if (P.snow && land[o] == 1) {                            // run_simulation.py:2130-2141: snow cover over land
-        const double cs = csnow[o];
-        b0 = qd_clip((1.0 - cs) * b0 + cs * P.alpha_snow, 0.0, 1.0);
-    }
-    const double surf = b0 * (1.0 - fi) + P.alpha_ice * fi;
-    albedo[o] = qd_clip(surf * (1.0 - C) + P.alpha_cloud * C, 0.0, 1.0);
+    const int landv = land[o];
+    const double cs = (P.snow && landv == 1) ? csnow[o] : 0.0;
+    const double gl = (P.eco && landv == 1) ? glacier[o] : 0.0;
+    albedo[o] = qd_albedo_cell(P, o, c, cloud_eff, hice, base, landv, cs, gl, eco_alpha, banded, water);
 }
 
 __global__ void k_precip_scalars_post(const double* raw, double wsum, double pq_min, double p_blend, int use_fb, double* out) {
@@ -243,14 +222,8 @@ k_precip_rawsums(const double* __restrict__ partial, int n, double* __restrict__
 }
 
 // ------------------------------------------------------------------ P019 lapse + snow, land bucket
-struct QdSnowP {
-    double dt, ga, rho_snow_safe, polar_lat, ice_max, elev_max, gamma, t_thresh, dT, ddf_s, tref, rate_s, swe_max, swe_ref_safe,
-           gl_frac, gl_swe;
-    int lapse, mode, swe;
-};
-
 // run_simulation.py:1946-2019 + hydrology.py:100-177: lapse-adjusted air temperature, sigmoid rain/snow
-// split, provisional snowpack (degree-day | constant melt), optical snow cover, glacier mask
+// split, provisional snowpack (degree-day | constant melt), optical snow cover, glacier mask; body: qd_pointwise.h
 __global__ void __launch_bounds__(QD_BLOCK)
 k_snow_provisional(QdGeom G, QdTabs T, QdSnowP P, const double* __restrict__ precip, const double* __restrict__ h,
                    const double* __restrict__ S_snow, const double* __restrict__ elev, const uint8_t* __restrict__ land,
@@ -261,37 +234,37 @@ k_snow_provisional(QdGeom G, QdTabs T, QdSnowP P, const double* __restrict__ pre
     if (j >= G.nlon) return;
     const int i = G.row0 + tl.row;
     const size_t o = (size_t)qd_lrow(G, i) * G.nlon + j;
-    const bool is_land = land[o] == 1;
-    const double T_a = 288.0 + P.ga * h[o];
-    const double S0 = S_snow[o];
-    const double h_snow = is_land ? qd_max(S0, 0.0) / P.rho_snow_safe : 0.0;
-    const bool polar = fabs(T.lat_deg[i]) >= P.polar_lat;
-    const double h_ice_eff = polar ? qd_min(h_snow, P.ice_max) : h_snow;
-    const double H_eff = qd_min(elev[o] + h_ice_eff, P.elev_max);
-    const double T_hat = P.lapse ? T_a - P.gamma * (H_eff / 1000.0) : T_a;
-    const double Pf = precip[o];
-    double f_snow = 1.0 / (1.0 + exp((T_hat - P.t_thresh) / P.dT));
-    f_snow = qd_clip(f_snow, 0.0, 1.0);
-    const double Ps = qd_nn(f_snow * Pf);
-    const double Pr = qd_nn((1.0 - f_snow) * Pf);
-    P_rain[o] = Pr;
-    if (!P.swe) { S_next[o] = S0; melt[o] = 0.0; C_snow[o] = 0.0; glacier[o] = 0.0; return; }
-    const double Ps_land = Ps * (is_land ? 1.0 : 0.0);
-    double melt_flux;
-    if (P.mode == 0) melt_flux = P.ddf_s * qd_max(T_hat - P.tref, 0.0);
-    else melt_flux = (T_hat >= P.t_thresh) ? P.rate_s : 0.0;
-    const double actual = qd_min(qd_max(S0, 0.0), melt_flux * P.dt);
-    double Sn = S0 + Ps_land * P.dt - actual;
-    if (P.swe_max > 0.0) Sn = qd_min(Sn, P.swe_max);
-    Sn = qd_max(0.0, Sn);
-    const double melt_out = (P.dt > 0) ? actual / P.dt : 0.0;
-    const double Cs = qd_clip(1.0 - exp(-qd_max(Sn, 0.0) / P.swe_ref_safe), 0.0, 1.0);
-    Sn = qd_nn(Sn);
-    const bool gl = is_land && ((Cs >= P.gl_frac) || (Sn >= P.gl_swe));
-    // rain on an ice cap is deposited into the snowpack (run_simulation.py:1996-2001)
-    const double Pr_gl = (Pr * (is_land ? 1.0 : 0.0)) * (gl ? 1.0 : 0.0);
-    if (Pr_gl != 0.0) Sn = Sn + Pr_gl * P.dt;
-    S_next[o] = Sn; melt[o] = qd_nn(melt_out); C_snow[o] = Cs; glacier[o] = gl ? 1.0 : 0.0;
+    const QdSnowOut r = qd_snow_cell(T, P, i, land[o] == 1, h[o], S_snow[o], elev[o], precip[o]);
+    P_rain[o] = r.Pr; S_next[o] = r.Sn; melt[o] = r.melt; C_snow[o] = r.Cs; glacier[o] = r.gl;
+}
+
+// The tail of the driver physics and the forcing of the same step in ONE launch (whole-globe handles inside qd_step_n): snowpack ->
+// cloud tracer blend + albedo -> two-star insolation + Teq are three pointwise kernels on the same cells (17 + 13 + 12 us as three
+// launches at 721 x 1440; each re-reads what its predecessor has just written: C_snow, the glacier mask, the albedo).  Same bodies,
+// same order, results handed on in registers.
+__global__ void __launch_bounds__(QD_BLOCK)
+k_snow_albedo_forcing(QdGeom G, QdTabs T, QdSnowP S, QdAlbP A, QdForcingP Fo,
+                      const double* __restrict__ precip, const double* __restrict__ h, const double* __restrict__ S_snow,
+                      const double* __restrict__ elev, const uint8_t* __restrict__ land, double* __restrict__ P_rain,
+                      double* __restrict__ S_next, double* __restrict__ melt, double* __restrict__ C_snow, double* __restrict__ glacier,
+                      const double* __restrict__ adv, double* __restrict__ cloud, const double* __restrict__ cloud_eff,
+                      const double* __restrict__ hice, const double* __restrict__ base, const double* __restrict__ eco_alpha,
+                      const double* __restrict__ banded, const double* __restrict__ water, double* __restrict__ albedo,
+                      double* __restrict__ isrA, double* __restrict__ isrB, double* __restrict__ isr, double* __restrict__ Teq,
+                      double* __restrict__ eday, double eday_dt) {
+    const QdTile tl = qd_tile();
+    const int j = tl.seg * QD_BLOCK + threadIdx.x;
+    if (j >= G.nlon) return;
+    const int i = G.row0 + tl.row;
+    const size_t o = (size_t)qd_lrow(G, i) * G.nlon + j;
+    const int landv = land[o];
+    const QdSnowOut r = qd_snow_cell(T, S, i, landv == 1, h[o], S_snow[o], elev[o], precip[o]);
+    P_rain[o] = r.Pr; S_next[o] = r.Sn; melt[o] = r.melt; C_snow[o] = r.Cs; glacier[o] = r.gl;
+    double c = cloud[o];
+    if (A.do_adv) { c = qd_clip((1.0 - A.alpha) * c + A.alpha * adv[o], 0.0, 1.0); cloud[o] = c; }
+    const double alb = qd_albedo_cell(A, o, c, cloud_eff, hice, base, landv, r.Cs, r.gl, eco_alpha, banded, water);
+    albedo[o] = alb;
+    qd_forcing_cell(T, Fo, i, j, o, alb, isrA, isrB, isr, Teq, eday, eday_dt);
 }
 
 struct QdBucketP { double dt, tau_s, cap; };
@@ -341,7 +314,7 @@ int qd_hydrology_commit_impl(qd_ctx* c, double dt) {
     return 0;
 }
 
-int qd_driver_physics_impl(qd_ctx* c, double dt) {
+int qd_driver_physics_impl(qd_ctx* c, double dt, const QdForcingCall* fc) {
     const qd_params& p = c->p;
     const QdGeom& G0 = c->geo;
     const dim3 blk(QD_BLOCK);
@@ -501,6 +474,22 @@ int qd_driver_physics_impl(qd_ctx* c, double dt) {
             S.ddf_s = p.snow_ddf_mm_per_k_day / 86400.0; S.tref = p.snow_melt_tref_K; S.rate_s = p.snow_melt_rate_mm_day / 86400.0;
             S.swe_max = (p.swe_max_mm == p.swe_max_mm && p.swe_max_mm > 0) ? p.swe_max_mm : -1.0;
             S.swe_ref_safe = std::max(1e-6, p.swe_ref_mm); S.gl_frac = p.glacier_frac; S.gl_swe = p.glacier_swe_mm; S.swe = p.swe_enable;
+            // the forcing of this step rides on the same launch when the caller (qd_step_n, whole-globe handle) hands it over
+            if (fc && G0.full) {
+                const QdForcingP Fo{QdStar{fc->sa[0], std::sin(fc->sa[1]), std::cos(fc->sa[1]), fc->sa[2]},
+                                    QdStar{fc->sb[0], std::sin(fc->sb[1]), std::cos(fc->sb[1]), fc->sb[2]}, fc->theta, 5.670374e-8, 1};
+                hipLaunchKernelGGL(k_snow_albedo_forcing, qd_grid2d(G0), blk, 0, c->stream, G0, c->tabs, S, A, Fo, F[QD_F_PRECIP], F[QD_F_H],
+                                   F[QD_F_S_SNOW], F[QD_F_ELEVATION], c->land, F[QD_F_P_RAIN], F[QD_F_S_SNOW_NEXT], F[QD_F_MELT],
+                                   F[QD_F_C_SNOW], F[QD_F_GLACIER], adv, F[QD_F_CLOUD],
+                                   c->cloud_eff_valid ? F[QD_F_CLOUD_EFF] : (const double*)nullptr, F[QD_F_HICE], F[QD_F_BASE_ALBEDO],
+                                   F[QD_F_ECO_ALPHA], F[QD_F_ECO_ALPHA_BANDED], F[QD_F_WATER_ALPHA], F[QD_F_ALBEDO], F[QD_F_ISR_A],
+                                   F[QD_F_ISR_B], F[QD_F_ISR], F[QD_F_TEQ], c->eco.eday_dt > 0 ? F[QD_F_ECO_EDAY] : (double*)nullptr,
+                                   c->eco.eday_dt);
+                c->eco.eday_dt = 0;
+                qd_mark(c, {F[QD_F_P_RAIN], F[QD_F_S_SNOW_NEXT], F[QD_F_MELT], F[QD_F_C_SNOW], F[QD_F_GLACIER]}, 0);
+                qd_mark(c, {F[QD_F_CLOUD], F[QD_F_ALBEDO], F[QD_F_ISR_A], F[QD_F_ISR_B], F[QD_F_ISR], F[QD_F_TEQ]}, 0);
+                return 0;
+            }
             QD_ROWS(c, msn, G, hipLaunchKernelGGL(k_snow_provisional, qd_grid2d(G), blk, 0, c->stream, G, c->tabs, S, F[QD_F_PRECIP],
                                                   F[QD_F_H], F[QD_F_S_SNOW], F[QD_F_ELEVATION], c->land, F[QD_F_P_RAIN],
                                                   F[QD_F_S_SNOW_NEXT], F[QD_F_MELT], F[QD_F_C_SNOW], F[QD_F_GLACIER]));
