@@ -318,6 +318,9 @@ void qd_launch_advect(qd_ctx* c, const double* u, const double* v, const double*
 void qd_launch_divvort(qd_ctx* c, const double* u, const double* v, double* out, int vort, int m);
 int  qd_gaussian(qd_ctx* c, const double* in, double* out, double* tmp, double sigma, int mode_wrap, int m_out, int clip01 = 0,
                  const double* scale_p = nullptr, double scale_k = 1.0);
+bool qd_gauss_pair_ok(const qd_ctx* c, double sigma);
+int  qd_gaussian_pair(qd_ctx* c, const double* inA, const double* inB, double sigma, int mode_wrap, const double* scA_p, double scA_k,
+                      double scB_k, const double* sc, int op, const double* blend5, double* outA, double* outB, double* out0);
 int  qd_gaussian_swap(qd_ctx* c, double*& field, double*& tmp, double sigma, int mode_wrap, int m_out, int clip01 = 0,
                       const double* scale_p = nullptr, double scale_k = 1.0);
 bool qd_gauss_can_fuse(const qd_ctx* c, double sigma);

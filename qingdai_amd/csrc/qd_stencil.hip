@@ -455,20 +455,10 @@ static void qd_launch_gauss_rows(qd_ctx* c, const double* in, double* out, const
                                             dim3(QD_BLOCK), 0, c->stream, G, in, out, W, mode_wrap, clip01, scale_p, scale_k));
 }
 
-// gaussian_filter(in, sigma, mode): axis 0 then axis 1.  out may alias in; tmp is a distinct slab.
-int qd_gaussian(qd_ctx* c, const double* in, double* out, double* tmp, double sigma, int mode_wrap, int m_out, int clip01,
-                const double* scale_p, double scale_k) {
-    const bool scaled = scale_p != nullptr || scale_k != 1.0;
-    if (scaled && !(c->use_fused && out != in && sigma > 1e-15 && c->geo.nlon > 2 * qd_gauss_radius(sigma)))
-        return qd_fail(c, "qd_gaussian: input scaling needs the fused blur");
-    if (!(sigma > 1e-15)) {
-        if (out != in) hipMemcpyAsync(out, in, c->geo.cells() * sizeof(double), hipMemcpyDeviceToDevice, c->stream);
-        qd_mark(c, {out}, m_out);
-        return 0;
-    }
-    QdGaussW W;
+// scipy _gaussian_kernel1d weights (radius int(4 sigma + 0.5)); false: radius beyond QD_GAUSS_MAXR
+static bool qd_gauss_weights(double sigma, QdGaussW& W) {
     const int r = (int)(4.0 * sigma + 0.5);
-    if (r > QD_GAUSS_MAXR) return qd_fail(c, "gaussian radius too large");
+    if (r > QD_GAUSS_MAXR) return false;
     W.r = r;
     // scipy _gaussian_kernel1d: exp(-0.5/sigma^2 * x^2) / sum, summed in array order -r..r
     std::vector<double> phi(2 * r + 1);
@@ -488,6 +478,130 @@ int qd_gaussian(qd_ctx* c, const double* in, double* out, double* tmp, double si
         for (; k < m; ++k) tot += phi[k];
     }
     for (int k = 0; k <= r; ++k) W.w[k] = phi[r + k] / tot;
+    return true;
+}
+
+// Two blurs of the same sigma and the pointwise blend of their results in ONE launch (whole-globe handles inside the driver
+// physics: precipitation = blend(blur(s P_raw), blur(k pos)); cloud = blend(cloud, clip(blur(C_from_P)), clip(blur(source)))).
+// A workgroup runs k_gauss_rows' two passes for field A, keeps its eight results per thread in registers, does the same for
+// field B through the same LDS rows, and blends -- same taps in the same order, two launches and three field round trips fewer.
+//   op 1 (precipitation, k_precip_blend): out0 = max((al != 0 ? (1 - al) a + al b : a), 0), al = sc[1]; field B is not even read
+//                                         when al == 0 (the fallback blend of physics.py:344-352 is off)
+//   op 2 (cloud, k_cloud_blend):          outA = a, outB = b (both clipped to [0, 1]), out0 = the blended cloud cover
+struct QdGaussPairP { int op; double w_mem, w_p, w_src, tend, c_floor; };
+template <int RR>
+__device__ __forceinline__ void qd_gauss_rows_pass(const QdGeom& G, const double* __restrict__ in, double sc, const double (&w)[RR + 1],
+                                                   int mode_wrap, int i0, int nvalid, int jbase, double (*sm)[QD_BLOCK], double (&acc)[QD_GB]) {
+    {
+        const int s = threadIdx.x;
+        const int jj = jbase - RR + s;
+        if (jj < G.nlon + RR) {
+            const int j = qd_ext(jj, G.nlon, mode_wrap);
+            double x[QD_GB + 2 * RR];
+#pragma unroll
+            for (int q = 0; q < QD_GB + 2 * RR; ++q) {
+                const int qq = q < nvalid + 2 * RR ? q : nvalid + 2 * RR - 1;
+                x[q] = in[(size_t)qd_lrow(G, qd_ext(i0 - RR + qq, G.nlat, mode_wrap)) * G.nlon + j] * sc;
+            }
+#pragma unroll
+            for (int k = 0; k < QD_GB; ++k) {
+                double tmp = x[k + RR] * w[0];
+#pragma unroll
+                for (int q = RR; q >= 1; --q) tmp += (x[k + RR - q] + x[k + RR + q]) * w[q];
+                sm[k][s] = tmp;
+            }
+        }
+    }
+    __syncthreads();
+    const int c0 = threadIdx.x;
+    if (c0 >= RR && c0 < QD_BLOCK - RR) {
+#pragma unroll
+        for (int k = 0; k < QD_GB; ++k) {
+            double a = sm[k][c0] * w[0];
+#pragma unroll
+            for (int q = RR; q >= 1; --q) a += (sm[k][c0 - q] + sm[k][c0 + q]) * w[q];
+            acc[k] = a;
+        }
+    }
+    __syncthreads();
+}
+
+template <int RR>
+__global__ void __launch_bounds__(QD_BLOCK)
+k_gauss_pair(QdGeom G, const double* __restrict__ inA, const double* __restrict__ inB, QdGaussW W, int mode_wrap,
+             const double* __restrict__ scA_p, double scA_k, double scB_k, const double* __restrict__ sc, QdGaussPairP P,
+             double* __restrict__ outA, double* __restrict__ outB, double* __restrict__ out0) {
+    constexpr int OWN = QD_BLOCK - 2 * RR;
+    __shared__ double sm[QD_GB][QD_BLOCK];
+    const int i0 = G.row0 + (int)blockIdx.y * QD_GB;
+    const int nvalid = min(QD_GB, G.row0 + G.nrows - i0);
+    const int jbase = (int)blockIdx.x * OWN;
+    double w[RR + 1];
+#pragma unroll
+    for (int k = 0; k <= RR; ++k) w[k] = W.w[k];
+    const double al = (P.op == 1) ? sc[1] : 0.0;
+    double a[QD_GB], b[QD_GB];
+#pragma unroll
+    for (int k = 0; k < QD_GB; ++k) { a[k] = 0.0; b[k] = 0.0; }
+    qd_gauss_rows_pass<RR>(G, inA, scA_p ? *scA_p : scA_k, w, mode_wrap, i0, nvalid, jbase, sm, a);
+    if (P.op != 1 || al != 0.0) qd_gauss_rows_pass<RR>(G, inB, scB_k, w, mode_wrap, i0, nvalid, jbase, sm, b);
+    const int c0 = threadIdx.x;
+    const int j = jbase + c0 - RR;
+    if (c0 < RR || c0 >= QD_BLOCK - RR || j >= G.nlon) return;
+#pragma unroll
+    for (int k = 0; k < QD_GB; ++k) {
+        if (k >= nvalid) break;
+        const size_t o = (size_t)qd_lrow(G, i0 + k) * G.nlon + j;
+        if (P.op == 1) {
+            double p = a[k];
+            if (al != 0.0) p = (1.0 - al) * p + al * b[k];
+            out0[o] = qd_max(p, 0.0);                                      // np.clip(P, 0, None)
+        } else {
+            const double cp = qd_clip(a[k], 0.0, 1.0), sr = qd_clip(b[k], 0.0, 1.0);    // np.clip(gaussian(...), 0, 1)
+            outA[o] = cp; outB[o] = sr;
+            const double c0v = out0[o];
+            const double tendency = sr * P.tend;
+            double c = (P.w_mem * c0v + P.w_p * cp + P.w_src * qd_clip(c0v + tendency, 0.0, 1.0));
+            if (P.c_floor > 0.0) c = qd_max(c, qd_clip(P.c_floor * cp, 0.0, 1.0));
+            out0[o] = qd_clip(c, 0.0, 1.0);
+        }
+    }
+}
+
+// whole-globe handles only (the caller checks qd_gauss_pair_ok): returns nonzero on failure
+bool qd_gauss_pair_ok(const qd_ctx* c, double sigma) {
+    const int r = qd_gauss_radius(sigma);
+    return c->geo.full && c->use_fused && c->merge_pointwise && sigma > 1e-15 && c->geo.nlon > 2 * r && (r == 1 || r == 2 || r == 4);
+}
+int qd_gaussian_pair(qd_ctx* c, const double* inA, const double* inB, double sigma, int mode_wrap, const double* scA_p, double scA_k,
+                     double scB_k, const double* sc, int op, const double* blend5, double* outA, double* outB, double* out0) {
+    QdGaussW W;
+    if (!qd_gauss_weights(sigma, W)) return qd_fail(c, "gaussian radius too large");
+    QdGaussPairP P{op, 0, 0, 0, 0, 0};
+    if (blend5) { P.w_mem = blend5[0]; P.w_p = blend5[1]; P.w_src = blend5[2]; P.tend = blend5[3]; P.c_floor = blend5[4]; }
+    const QdGeom& G = c->geo;
+    const int r = W.r;
+    const dim3 grid((G.nlon + (QD_BLOCK - 2 * r) - 1) / (QD_BLOCK - 2 * r), (G.nrows + QD_GB - 1) / QD_GB);
+    if (r == 1) hipLaunchKernelGGL(k_gauss_pair<1>, grid, dim3(QD_BLOCK), 0, c->stream, G, inA, inB, W, mode_wrap, scA_p, scA_k, scB_k, sc, P, outA, outB, out0);
+    else if (r == 2) hipLaunchKernelGGL(k_gauss_pair<2>, grid, dim3(QD_BLOCK), 0, c->stream, G, inA, inB, W, mode_wrap, scA_p, scA_k, scB_k, sc, P, outA, outB, out0);
+    else hipLaunchKernelGGL(k_gauss_pair<4>, grid, dim3(QD_BLOCK), 0, c->stream, G, inA, inB, W, mode_wrap, scA_p, scA_k, scB_k, sc, P, outA, outB, out0);
+    return 0;
+}
+
+// gaussian_filter(in, sigma, mode): axis 0 then axis 1.  out may alias in; tmp is a distinct slab.
+int qd_gaussian(qd_ctx* c, const double* in, double* out, double* tmp, double sigma, int mode_wrap, int m_out, int clip01,
+                const double* scale_p, double scale_k) {
+    const bool scaled = scale_p != nullptr || scale_k != 1.0;
+    if (scaled && !(c->use_fused && out != in && sigma > 1e-15 && c->geo.nlon > 2 * qd_gauss_radius(sigma)))
+        return qd_fail(c, "qd_gaussian: input scaling needs the fused blur");
+    if (!(sigma > 1e-15)) {
+        if (out != in) hipMemcpyAsync(out, in, c->geo.cells() * sizeof(double), hipMemcpyDeviceToDevice, c->stream);
+        qd_mark(c, {out}, m_out);
+        return 0;
+    }
+    QdGaussW W;
+    if (!qd_gauss_weights(sigma, W)) return qd_fail(c, "gaussian radius too large");
+    const int r = W.r;
     // axis 0 reaches r rows; axis 1 is row-local.  Both passes run on the output margin.
     if (c->use_fused && out != in && c->geo.nlon > 2 * r && (r == 1 || r == 2 || r == 4)) {
         if (r == 1) qd_launch_gauss_rows<1>(c, in, out, W, mode_wrap, clip01, scale_p, scale_k, m_out);
