@@ -312,7 +312,8 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
         hipMemsetAsync(c->med_err, 0, sizeof(unsigned int), c->stream);
     }
     if ((e = hipHostMalloc((void**)&c->hpin, 64 * sizeof(double))) != hipSuccess) return bail("hipHostMalloc", e);
-    if ((e = hipHostMalloc((void**)&c->hpin_rows, (size_t)2 * c->geo.lrows() * sizeof(double))) != hipSuccess) return bail("hipHostMalloc", e);
+    if ((e = hipHostMalloc((void**)&c->hpin_rows, (size_t)3 * c->geo.lrows() * sizeof(double))) != hipSuccess) return bail("hipHostMalloc", e);
+    std::memset(c->hpin_rows, 0, (size_t)3 * c->geo.lrows() * sizeof(double));      // [2 n .. 3 n): per-row arrival stamps of k_stress_max
     // reference initial state
     const double q0 = std::min(std::max(q_init_rh, 0.0), 1.0) * host_qsat(288.0, params->p0);
     hipLaunchKernelGGL(k_init_state, dim3((d->n_lon + QD_BLOCK - 1) / QD_BLOCK, c->geo.lrows()), dim3(QD_BLOCK), 0,

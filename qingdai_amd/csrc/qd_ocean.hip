@@ -133,7 +133,7 @@ __device__ __forceinline__ double qd_wave_max_d(double x) {
 __global__ void __launch_bounds__(QD_BLOCK)
 k_stress_max(QdGeom G, const double* __restrict__ ua, const double* __restrict__ va,
              const double* __restrict__ uo, const double* __restrict__ vo, double vcap, double rhoCD, double tau_scale,
-             double* __restrict__ taux, double* __restrict__ tauy, double* __restrict__ partial) {
+             double* __restrict__ taux, double* __restrict__ tauy, double* __restrict__ partial, double* seq_out, double seq) {
     __shared__ double sm[2][QD_BLOCK / 64];
     const int i = G.row0 + blockIdx.y;
     const size_t b = (size_t)qd_lrow(G, i) * G.nlon;
@@ -158,6 +158,9 @@ k_stress_max(QdGeom G, const double* __restrict__ ua, const double* __restrict__
         for (int k = 1; k < QD_BLOCK / 64; ++k) { mVa = sm[0][k] > mVa ? sm[0][k] : mVa; mUo = sm[1][k] > mUo ? sm[1][k] : mUo; }
         partial[blockIdx.y] = mVa;
         partial[gridDim.y + blockIdx.y] = mUo;
+        // whole-globe handles: `partial` is pinned host memory and the host is waiting for it -- every row stamps its own arrival
+        // (system-scope release behind its two maxima), so no k_host_flag launch has to follow (4.7 us per step)
+        if (seq_out) __hip_atomic_store(seq_out + blockIdx.y, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -484,13 +487,10 @@ __device__ __forceinline__ double qd_block_sum_ocn(double x, double* sm) {
     return r;
 }
 
-__global__ void __launch_bounds__(QD_BLOCK)
-k_polar_fill(QdGeom G, QdTabs T, const uint8_t* __restrict__ land, double* __restrict__ Ts, double* __restrict__ uo,
-             double* __restrict__ vo) {
-    __shared__ double sm[QD_BLOCK / 64];
-    const bool north = blockIdx.x == 1;
+// the polar fill of one pole row (ocean.py:197-262, 519-533) by ONE workgroup: ocean means of SST and of the current vector
+__device__ __forceinline__ void qd_polar_fill_row(const QdGeom& G, const QdTabs& T, const uint8_t* __restrict__ land, double* __restrict__ Ts,
+                                                  double* __restrict__ uo, double* __restrict__ vo, bool north, double* sm) {
     const int i = north ? G.nlat - 1 : 0;
-    if (i < G.row0 || i >= G.row0 + G.nrows) return;      // this band does not own the pole
     const size_t b = (size_t)qd_lrow(G, i) * G.nlon;
     double cnt = 0, sT = 0, s0 = 0, s1 = 0;
     for (int j = threadIdx.x; j < G.nlon; j += QD_BLOCK) {
@@ -521,6 +521,28 @@ k_polar_fill(QdGeom G, QdTabs T, const uint8_t* __restrict__ land, double* __res
 }
 
 __global__ void __launch_bounds__(QD_BLOCK)
+k_polar_fill(QdGeom G, QdTabs T, const uint8_t* __restrict__ land, double* __restrict__ Ts, double* __restrict__ uo,
+             double* __restrict__ vo) {
+    __shared__ double sm[QD_BLOCK / 64];
+    const bool north = blockIdx.x == 1;
+    const int i = north ? G.nlat - 1 : 0;
+    if (i < G.row0 || i >= G.row0 + G.nrows) return;      // this band does not own the pole
+    qd_polar_fill_row(G, T, land, Ts, uo, vo, north, sm);
+}
+
+__device__ __forceinline__ void qd_sst_clamp_cell(size_t o, double* __restrict__ sst, double tmin, double tmax, int inject,
+                                                  const uint8_t* __restrict__ land, const uint8_t* __restrict__ ice, int has_ice,
+                                                  double* __restrict__ Ts_atm, double* __restrict__ eta, const double* __restrict__ eta_mean,
+                                                  double eta_cap) {
+    // the deferred eta update of the LAST sub-step (nobody loads eta through the momentum kernel afterwards)
+    if (eta) eta[o] = qd_clip(qd_nn(eta[o] - *eta_mean), -eta_cap, eta_cap);
+    const double t = qd_clip(sst[o], tmin, tmax);
+    sst[o] = t;
+    // gcm.T_s = where(ocean & ~ice, ocean.Ts, gcm.T_s)    run_simulation.py:2252-2253
+    if (inject && land[o] == 0 && !(has_ice && ice[o] != 0)) Ts_atm[o] = t;
+}
+
+__global__ void __launch_bounds__(QD_BLOCK)
 k_sst_clamp_inject(QdGeom G, double* __restrict__ sst, double tmin, double tmax, int inject,
                    const uint8_t* __restrict__ land, const uint8_t* __restrict__ ice, int has_ice,
                    double* __restrict__ Ts_atm, double* __restrict__ eta, const double* __restrict__ eta_mean, double eta_cap) {
@@ -528,12 +550,31 @@ k_sst_clamp_inject(QdGeom G, double* __restrict__ sst, double tmin, double tmax,
     const int j = tl.seg * QD_BLOCK + threadIdx.x;
     if (j >= G.nlon) return;
     const size_t o = (size_t)qd_lrow(G, G.row0 + tl.row) * G.nlon + j;
-    // the deferred eta update of the LAST sub-step (nobody loads eta through the momentum kernel afterwards)
-    if (eta) eta[o] = qd_clip(qd_nn(eta[o] - *eta_mean), -eta_cap, eta_cap);
-    const double t = qd_clip(sst[o], tmin, tmax);
-    sst[o] = t;
-    // gcm.T_s = where(ocean & ~ice, ocean.Ts, gcm.T_s)    run_simulation.py:2252-2253
-    if (inject && land[o] == 0 && !(has_ice && ice[o] != 0)) Ts_atm[o] = t;
+    qd_sst_clamp_cell(o, sst, tmin, tmax, inject, land, ice, has_ice, Ts_atm, eta, eta_mean, eta_cap);
+}
+
+// whole-globe handles: the polar fill and the clamp + write-back in ONE launch.  The clamp of a cell reads nothing but the cell, so
+// only the two pole rows depend on the fill: the first workgroup of a pole row does the fill of its row and then the clamp of the
+// whole row, the other workgroups of that row leave at once, every other row is clamped as before.
+__global__ void __launch_bounds__(QD_BLOCK)
+k_polar_clamp_inject(QdGeom G, QdTabs T, double* __restrict__ sst, double* __restrict__ uo, double* __restrict__ vo, double tmin, double tmax,
+                     int inject, const uint8_t* __restrict__ land, const uint8_t* __restrict__ ice, int has_ice,
+                     double* __restrict__ Ts_atm, double* __restrict__ eta, const double* __restrict__ eta_mean, double eta_cap) {
+    __shared__ double sm[QD_BLOCK / 64];
+    const QdTile tl = qd_tile();
+    const int i = G.row0 + tl.row;
+    if (i == 0 || i == G.nlat - 1) {
+        if (tl.seg != 0) return;
+        qd_polar_fill_row(G, T, land, sst, uo, vo, i != 0, sm);
+        __syncthreads();                                     // (every thread re-reads only the columns it wrote itself: same stride)
+        const size_t b = (size_t)qd_lrow(G, i) * G.nlon;
+        for (int j = threadIdx.x; j < G.nlon; j += QD_BLOCK)
+            qd_sst_clamp_cell(b + j, sst, tmin, tmax, inject, land, ice, has_ice, Ts_atm, eta, eta_mean, eta_cap);
+        return;
+    }
+    const int j = tl.seg * QD_BLOCK + threadIdx.x;
+    if (j >= G.nlon) return;
+    qd_sst_clamp_cell((size_t)qd_lrow(G, i) * G.nlon + j, sst, tmin, tmax, inject, land, ice, has_ice, Ts_atm, eta, eta_mean, eta_cap);
 }
 
 // the mean of the tail kernel's strip / tile sums: one workgroup, fixed order (thread-strided partial sums, shuffle tree per
@@ -621,13 +662,14 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
             // whole globe: one launch; the 2 x n_lat row maxima are written straight into pinned host memory (device-visible,
             // coherent), so the wait the host needs anyway is the only cost -- no copy kernel (measured: 16 us per step)
             const QdGeom& G = S.g[0];
-            hipLaunchKernelGGL(k_stress_max, dim3(1, G.nrows), blk, 0, c->stream, G, F[QD_F_U], F[QD_F_V], F[QD_F_UO],
-                               F[QD_F_VO], p.vcap, p.rho_a_ocean * p.CD, p.tau_scale, taux, tauy, c->hpin_rows);
-            qd_mark(c, {taux, tauy}, m);
             c->eta_seq += 1.0;
-            hipLaunchKernelGGL(k_host_flag, dim3(1), dim3(64), 0, c->stream, c->hpin + 43, c->eta_seq);
+            hipLaunchKernelGGL(k_stress_max, dim3(1, G.nrows), blk, 0, c->stream, G, F[QD_F_U], F[QD_F_V], F[QD_F_UO],
+                               F[QD_F_VO], p.vcap, p.rho_a_ocean * p.CD, p.tau_scale, taux, tauy, c->hpin_rows,
+                               c->hpin_rows + (size_t)2 * G0.lrows(), c->eta_seq);
+            qd_mark(c, {taux, tauy}, m);
             if (compute_qnet && launch_qnet()) return -1;
-            if (qd_wait_host_flag(c, c->hpin + 43, c->eta_seq, "ocean step: the CFL maxima never arrived")) return -1;
+            for (int k = 0; k < G.nrows; ++k)
+                if (qd_wait_host_flag(c, c->hpin_rows + (size_t)2 * G0.lrows() + k, c->eta_seq, "ocean step: the CFL maxima never arrived")) return -1;
             for (int k = 0; k < G.nrows; ++k) { maxVa = std::max(maxVa, c->hpin_rows[k]); maxUo = std::max(maxUo, c->hpin_rows[G.nrows + k]); }
         } else {
         QD_HIP(c, hipMemsetAsync(c->dscal + QD_S_TMP0, 0, 6 * sizeof(double), c->stream));
@@ -636,7 +678,7 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
             // partial maxima of halo segments are harmless (a max over more valid rows of the globe)
             hipLaunchKernelGGL(k_stress_max, dim3(1, G.nrows), blk, 0, c->stream, G, F[QD_F_U], F[QD_F_V], F[QD_F_UO],
                                F[QD_F_VO], p.vcap, p.rho_a_ocean * p.CD, p.tau_scale, taux, tauy,
-                               c->red_partial + (size_t)k * 2 * G0.lrows());
+                               c->red_partial + (size_t)k * 2 * G0.lrows(), (double*)nullptr, 0.0);
             hipLaunchKernelGGL(k_max2_finish, dim3(1), blk, 0, c->stream, c->red_partial + (size_t)k * 2 * G0.lrows(), G.nrows,
                                c->dscal + QD_S_TMP0 + 2 * k);
         }
@@ -931,6 +973,12 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
     }
     {
         QdScope sc(c, "ocean_finish");
+        if (!band && p.ocean_polar_fix && c->merge_pointwise) {
+            hipLaunchKernelGGL(k_polar_clamp_inject, qd_grid2d(G0), blk, 0, c->stream, G0, c->tabs, F[QD_F_SST], F[QD_F_UO], F[QD_F_VO],
+                               p.ts_min, p.ts_max, inject_sst, c->land, c->icemask, use_ice_mask ? 1 : 0, F[QD_F_TS],
+                               (defer_eta && n_sub > 0) ? F[QD_F_ETA] : (double*)nullptr, mean_ptr, p.eta_cap);
+            return 0;
+        }
         if (p.ocean_polar_fix) {
             // the two pole rows are owned by the first / last band; their copies in the other polar
             // band's wrap halo go stale -> margins drop to 0 so the next stencil refreshes them

@@ -135,7 +135,19 @@ k_cloud_from_p(QdGeom G, const double* __restrict__ precip, const double* __rest
 }
 
 
-// physics.py:72-109 before the blur
+// np.clip(tanh(x), 0, 1) without the tanh where it cannot matter: tanh(x) <= 0 for x <= 0 (and the clip of a NaN is 0 as well), so
+// those lanes take 0 -- and a wavefront in which every lane does (cold rows, anticyclonic regions) skips the ~45 instructions of the
+// f64 tanh altogether.  Same result bit for bit: for x > 0 the same tanh is evaluated.
+__device__ __forceinline__ double qd_tanh01(double x) {
+    double t = 0.0;
+    if (x > 0.0) t = tanh(x);
+    return qd_clip(t, 0.0, 1.0);
+}
+
+// physics.py:72-109 before the blur (one cell)
+__device__ __forceinline__ double qd_cloud_source_cell(const QdGeom& G, const QdTabs& T, const double* __restrict__ u, const double* __restrict__ v,
+                                                       const double* __restrict__ Ts, double a, double dlat, double dlon, int i, int j);
+
 __global__ void __launch_bounds__(QD_BLOCK)
 k_cloud_source(QdGeom G, QdTabs T, const double* __restrict__ u, const double* __restrict__ v,
                const double* __restrict__ Ts, double a, double dlat, double dlon, double* __restrict__ out) {
@@ -143,22 +155,41 @@ k_cloud_source(QdGeom G, QdTabs T, const double* __restrict__ u, const double* _
     const int j = tl.seg * QD_BLOCK + threadIdx.x;
     if (j >= G.nlon) return;
     const int i = G.row0 + tl.row;
+    out[(size_t)qd_lrow(G, i) * G.nlon + j] = qd_cloud_source_cell(G, T, u, v, Ts, a, dlat, dlon, i, j);
+}
+
+// whole-globe handles: C_from_P (k_cloud_from_p) and the cloud source of the same cell in one launch
+__global__ void __launch_bounds__(QD_BLOCK)
+k_cloud_fromp_source(QdGeom G, QdTabs T, const double* __restrict__ precip, const double* __restrict__ pref, double cmax,
+                     const double* __restrict__ u, const double* __restrict__ v, const double* __restrict__ Ts, double a, double dlat,
+                     double dlon, double* __restrict__ cfp, double* __restrict__ src) {
+    const QdTile tl = qd_tile();
+    const int j = tl.seg * QD_BLOCK + threadIdx.x;
+    if (j >= G.nlon) return;
+    const int i = G.row0 + tl.row;
+    const size_t o = (size_t)qd_lrow(G, i) * G.nlon + j;
+    cfp[o] = cmax * tanh(precip[o] / (*pref + 1e-12));
+    src[o] = qd_cloud_source_cell(G, T, u, v, Ts, a, dlat, dlon, i, j);
+}
+
+__device__ __forceinline__ double qd_cloud_source_cell(const QdGeom& G, const QdTabs& T, const double* __restrict__ u, const double* __restrict__ v,
+                                                       const double* __restrict__ Ts, double a, double dlat, double dlon, int i, int j) {
     const size_t b = (size_t)qd_lrow(G, i) * G.nlon;
     const size_t o = b + j;
     const double T0 = Ts[o];
     double src = 0.0;
-    src = src + 0.5 * qd_clip(tanh((T0 - 285.0) / 12.0), 0.0, 1.0);
+    src = src + 0.5 * qd_tanh01((T0 - 285.0) / 12.0);
     const double vort = qd_divvort_point(G, T, v, u, i, j, a, dlat, dlon, 1);
     const double rel = vort / (T.fcor[i] + 1e-12);
-    src = src + 0.4 * qd_clip(tanh((rel - 0.5) / 2.0), 0.0, 1.0);
+    src = src + 0.4 * qd_tanh01((rel - 0.5) / 2.0);
     const double dx = dlon * a * T.cos6[i];
     const double dy = dlat * a;
     const int jp = qd_wrapc(j + 1, G.nlon), jm = qd_wrapc(j - 1, G.nlon);
     const double gx = (Ts[b + jp] - Ts[b + jm]) / (2 * dx);
     const double gy = (Ts[(size_t)qd_lrow(G, i + 1) * G.nlon + j] - Ts[(size_t)qd_lrow(G, i - 1) * G.nlon + j]) / (2 * dy);
     const double tadv = -(u[o] * gx + v[o] * gy);
-    src = src + 0.3 * qd_clip(tanh(fabs(tadv) / 2e-5), 0.0, 1.0);
-    out[o] = src;
+    src = src + 0.3 * qd_tanh01(fabs(tadv) / 2e-5);
+    return src;
 }
 
 struct QdBlendP { double w_mem, w_p, w_src, tend, c_floor; };
@@ -421,13 +452,18 @@ int qd_driver_physics_impl(qd_ctx* c, double dt, const QdForcingCall* fc) {
         double*& src = F[QD_F_CLOUD_SRC];
         int m = qd_plan(c, {QD_IN(F[QD_F_PRECIP], 0)});
         if (m < 0) return -1;
-        QD_ROWS(c, m, G, hipLaunchKernelGGL(k_cloud_from_p, qd_grid2d(G), blk, 0, c->stream, G, F[QD_F_PRECIP],
-                                            c->dscal + QD_S_MED_OUT, p.cmax, cfp));
-        qd_mark(c, {cfp}, m);
         int ms = qd_plan(c, {QD_IN(F[QD_F_U], 1), QD_IN(F[QD_F_V], 1), QD_IN(F[QD_F_TS], 1)});
         if (ms < 0) return -1;
+        if (G0.full && c->merge_pointwise) {
+            hipLaunchKernelGGL(k_cloud_fromp_source, qd_grid2d(G0), blk, 0, c->stream, G0, c->tabs, F[QD_F_PRECIP], c->dscal + QD_S_MED_OUT,
+                               p.cmax, F[QD_F_U], F[QD_F_V], F[QD_F_TS], p.a, c->dlat, c->dlon, cfp, src);
+        } else {
+        QD_ROWS(c, m, G, hipLaunchKernelGGL(k_cloud_from_p, qd_grid2d(G), blk, 0, c->stream, G, F[QD_F_PRECIP],
+                                            c->dscal + QD_S_MED_OUT, p.cmax, cfp));
         QD_ROWS(c, ms, G, hipLaunchKernelGGL(k_cloud_source, qd_grid2d(G), blk, 0, c->stream, G, c->tabs, F[QD_F_U], F[QD_F_V],
                                              F[QD_F_TS], p.a, c->dlat, c->dlon, src));
+        }
+        qd_mark(c, {cfp}, m);
         qd_mark(c, {src}, ms);
         const int mg = qd_plan(c, {QD_IN(cfp, R1), QD_IN(src, R1), QD_IN(F[QD_F_CLOUD], 0)});
         if (mg < 0) return -1;
