@@ -191,6 +191,7 @@ struct qd_ctx {
     double* med_pred = nullptr;      // [4 sites][16]: last median, valid flag, statistics, published bracket (see qd_reduce.hip): predicted median brackets (qd_reduce.hip)
     int med_predict = 1;             // QD_MEDIAN_PREDICT=0: always the two-histogram-pass select
     int med_seen[4] = {0, 0, 0, 0};  // call sites that have a window centre on the device
+    int band_tail = 1;               // QD_BAND_TAIL=0: latitude bands keep the round-2 sub-step (k_cont_sstadv + k_eta_mean + k_sst_outlier_fused)
     int merge_pointwise = 1;         // QD_MERGE_POINTWISE=0: every pointwise stage of qd_step_n as a launch of its own
     int med_one = 0;                 // QD_MEDIAN_ONE=1: the windowed median as ONE launch (k_med_one) instead of three -- measured equal
                                      // (39.6 us against 17 + 13 + 11: the chain of flush / ticket / fence round trips is the cost, not the launches)

@@ -723,7 +723,11 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
     // latitude bands with a host ring defer the same way; their mean is reduced on the HOST between the ranks (event wait on the
     // continuity kernel while the SST kernel is already queued) and handed to the next momentum kernel in pinned host memory
     const bool band_defer = band && can_defer && qd_has_host_ring(c);
-    const bool defer_eta = (!band && can_defer) || band_defer;
+    // latitude bands WITHOUT a host ring run the same two kernels per sub-step as the whole globe (round 3): the streaming tail kernel
+    // on the band's segments, its in-launch sum finished as the band's SHARE of the mean (sum_b / (W + 1e-15), W the global ocean
+    // weight), one all-reduce of that scalar, applied by the next momentum kernel on load.  QD_BAND_TAIL=0: the round-2 band path.
+    const bool band_tail = band && can_defer && !band_defer && c->ocn_tail == 1 && c->tail_acc && c->band_tail && G0.nlon >= 64;
+    const bool defer_eta = (!band && can_defer) || band_defer || band_tail;
     double* const mean_ptr = band_defer ? c->hpin + 42 : c->dscal + QD_S_ETA_MEAN;
     // latitude bands: whenever a sub-step has to exchange halos, every slab of the sub-step loop is refreshed in the same group
     struct CoRefresh { qd_ctx* c; ~CoRefresh() { c->corefresh.clear(); } } corefresh_guard{c};
@@ -733,7 +737,7 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
     // its per-tile eta sums into the mean.  Measured alternatives, both slower: the tail kernel's last workgroup doing it behind
     // two-level tickets (+12 us per sub-step: ticket round trips, acquire fence and read-back form a serial chain at the very end
     // of the launch); every wave of the next momentum kernel adding the ~1100 sums itself (+3.7 us per launch).
-    const bool use_tail = c->use_fused && !band && defer_eta && G0.nlon >= 64 && c->ocn_tail;
+    const bool use_tail = c->use_fused && (!band || band_tail) && defer_eta && G0.nlon >= 64 && c->ocn_tail;
     // QD_TAIL_ACC (default): the streaming tail kernel reduces its own strip sums (fixed-point atomics + spread tickets, qd_wave.h)
     // and its last workgroup writes the mean -- no k_eta_mean_tail launch (4.5 us of launch floor per sub-step)
     const bool tail_acc = use_tail && (c->ocn_tail == 1 || c->ocn_tail >= 3) && c->tail_acc;
@@ -832,10 +836,30 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
             A.r_a = 1.0 / p.a; A.r_dlon = 1.0 / c->dlon; A.r_dlat = 1.0 / c->dlat; A.r_2dlon = 1.0 / (2 * c->dlon); A.r_2dlat = 1.0 / (2 * c->dlat);
             A.r_rcH = 1.0 / HP.rcH;
             A.acc = tail_acc ? c->eta_acc : nullptr; A.mean_out = c->dscal + QD_S_ETA_MEAN; A.wsum = c->wsum_ocean;
+            if (band) {
+                // T1 = the blended, gathered SST is needed two rows beyond the rows a launch stores (K_h lap), uo / vo with it
+                const int m = qd_plan(c, {QD_IN(F[QD_F_UO], 2), QD_IN(F[QD_F_VO], 2), QD_IN(F[QD_F_ETA], 0), QD_IN(F[QD_F_SST], Ro + 2),
+                                          QD_IN(F[QD_F_QNET], 0), QD_IN8(c->icemask, 0)});
+                if (m < 0) return -1;
+                A.own0 = c->own_row0; A.own1 = c->own_row0 + c->own_nrows;
+                QdSegs S = qd_segments(c, m);
+                size_t off = 0;
+                for (int k = 0; k < S.n; ++k) {
+                    const QdGeom& Gs = S.g[k];
+                    const bool owned = Gs.row0 <= c->own_row0 && c->own_row0 < Gs.row0 + Gs.nrows;      // the segment that holds the band's own rows
+                    A.acc = owned ? c->eta_acc : nullptr;
+                    A.partial = c->red_partial + off;
+                    if (qd_launch_ocn_tail(c, Gs, A)) return -1;
+                    off += (size_t)qd_ocn_tail_tiles(c, Gs);
+                }
+                if (qd_allreduce_f64(c, c->dscal + QD_S_ETA_MEAN, 1, 0)) return -1;
+                qd_mark(c, {F[QD_F_ETA], A.Ts_out, A.uo_out, A.vo_out}, m);
+            } else {
             if (qd_launch_ocn_tail(c, Gown, A)) return -1;
             if (!tail_acc)
                 hipLaunchKernelGGL(k_eta_mean_tail, dim3(1), dim3(256), 0, c->stream, c->red_partial, qd_ocn_tail_tiles(c, Gown), c->wsum_ocean,
                                    c->dscal + QD_S_ETA_MEAN);
+            }
             qd_swap(c, QD_F_SST, 1); qd_swap(c, QD_F_UO, 2); qd_swap(c, QD_F_VO, 3);
         } else if (c->use_fused) {
             QdScope sc(c, "ocean_cont_sst");

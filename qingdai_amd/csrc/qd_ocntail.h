@@ -12,6 +12,7 @@ struct QdTailArgs {
     double a, dlat, dlon, sub_dt, msdtH, alpha, K_h, rcH, ice_qfac, cap;
     double r_a, r_dlon, r_dlat, r_2dlon, r_2dlat, r_rcH;     // correctly rounded reciprocals of a, dlon, dlat, 2 dlon, 2 dlat, rcH (host)
     int use_q, has_ice, mean4, ntc, R, pad_;                 // R: strip height of the streaming form
+    int own0, own1;                                          // rows whose eta enters the area-weighted sum (a band's owned rows; set by the launcher for whole-globe handles)
 };
 
 int qd_ocn_tail_tiles(const qd_ctx* c, const QdGeom& G);

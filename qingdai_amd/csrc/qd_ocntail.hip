@@ -227,10 +227,16 @@ __device__ __forceinline__ double qt_ld(qt_rsrc r, unsigned row_elems, unsigned 
 __device__ __forceinline__ void qt_st(qt_rsrc r, unsigned row_elems, unsigned vo, double v) { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(qt_u32x2, v), r, vo, row_elems * 8u, 0); }
 __device__ __forceinline__ int qt_ld8(qt_rsrc r, unsigned row_elems, unsigned vo8) { return (int)__builtin_amdgcn_raw_buffer_load_b8(r, vo8, row_elems, 0); }
 
-struct QtW { int n, m, lane, j, o0, o1; unsigned vo, vs, vo8, slab; bool own; };
+struct QtW { int n, m, lane, j, o0, o1; unsigned vo, vs, vo8, slab; bool own; int lbase, lrows, own0, own1; };      // lbase / lrows: the slab (band handles); own0 / own1: rows whose eta enters the sum
 
-// element offset of global row g (whole-globe handles: local row = global row), clamped into the domain
-__device__ __forceinline__ unsigned qt_row(const QtW& W, int g) { return (unsigned)qd_clampi(g, 0, W.n - 1) * (unsigned)W.m; }
+// element offset of global row g, clamped into the domain and into the slab (whole-globe handles: local row = global row; band
+// handles: local row = g - lbase with the period-n wrap of their ring halo)
+__device__ __forceinline__ unsigned qt_row(const QtW& W, int g) {
+    int l = qd_clampi(g, 0, W.n - 1) - W.lbase;
+    if (l < 0) l += W.n; else if (l >= W.n) l -= W.n;
+    l = l < W.lrows ? l : W.lrows - 1;
+    return (unsigned)l * (unsigned)W.m;
+}
 __device__ __forceinline__ unsigned qt_row_roll(const QtW& W, int g) { if (g < 0) g += W.n; else if (g >= W.n) g -= W.n; return qt_row(W, g); }
 
 // ---- wave 0: continuity (ocean.py:365-374) + outlier filter and caps (ocean.py:409-434)
@@ -262,7 +268,7 @@ __device__ __forceinline__ double qt_currents_wave(const QdTabs& T, const QdTail
         if (island) e = 0.0;
         const unsigned r0 = qt_row(W, g);
         qt_st(E, r0, W.vs, e);
-        acc += W.own ? e * (island ? 0.0 : qd_sload(T.warea, g)) : 0.0;
+        acc += (W.own && g >= W.own0 && g < W.own1) ? e * (island ? 0.0 : qd_sload(T.warea, g)) : 0.0;      // a band's halo rows: not its sum
         // outliers + caps
         double u = qd_nn(uc), v = qd_nn(vc);
         const double cap = P.cap, s2 = u * u + v * v;
@@ -412,6 +418,7 @@ k_ocn_tail_stream(QdGeom G, QdTabs T, QdTailArgs P) {
     W.own = W.lane >= 1 && W.lane <= QS_TC2 && jraw < W.m;
     W.vo = (unsigned)W.j * 8u; W.vo8 = (unsigned)W.j; W.vs = W.own ? (unsigned)jraw * 8u : 0x80000000u;
     W.slab = (unsigned)(G.lrows_ + QD_PAD_ROWS) * (unsigned)G.nlon * 8u;
+    W.lbase = G.lbase; W.lrows = G.lrows_; W.own0 = P.own0; W.own1 = P.own1;
     W.o0 = G.row0 + rs * P.R;
     W.o1 = min(W.o0 + P.R, G.row0 + G.nrows);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -479,6 +486,7 @@ k_ocn_tail_tile(QdGeom G, QdTabs T, QdTailArgs P) {
     W.own = W.lane >= 1 && W.lane <= QT_TC && jraw < W.m;
     W.vo = (unsigned)W.j * 8u; W.vo8 = (unsigned)W.j; W.vs = W.own ? (unsigned)jraw * 8u : 0x80000000u;
     W.slab = (unsigned)(G.lrows_ + QD_PAD_ROWS) * (unsigned)G.nlon * 8u;
+    W.lbase = G.lbase; W.lrows = G.lrows_; W.own0 = 0; W.own1 = G.nlat;
     const int n = W.n;
     const int i0 = G.row0 + rs * QT_TR, i1 = min(i0 + QT_TR, G.row0 + G.nrows), ib = i0 - 2;
     W.o0 = i0; W.o1 = i1;
@@ -690,6 +698,7 @@ k_ocn_step(QsOcnArgs A, QdTabs T, QdTailArgs P, QfArgs F) {
     QtW W;
     W.n = n; W.m = m; W.lane = lane; W.j = j; W.own = own; W.o0 = 0; W.o1 = 0;
     W.vo = (unsigned)j * 8u; W.vo8 = (unsigned)j; W.vs = own ? (unsigned)jraw * 8u : 0x80000000u; W.slab = slab;
+    W.lbase = G.lbase; W.lrows = G.lrows_; W.own0 = 0; W.own1 = n;
     const unsigned sb = slab;
     // ---- phase B1: T1 rows of slots 5 wv .. 5 wv + 4 (slot = plane row)
     {
@@ -882,7 +891,8 @@ int qd_ocn_tail_tiles(const qd_ctx* c, const QdGeom& G) {
 }
 
 int qd_launch_ocn_tail(qd_ctx* c, const QdGeom& G, QdTailArgs& P) {
-    if (G.nlon < 64 || !G.full) return qd_fail(c, "k_ocn_tail: whole-globe handles of >= 64 columns only");
+    if (G.nlon < 64 || (!G.full && c->ocn_tail != 1)) return qd_fail(c, "k_ocn_tail: >= 64 columns; band handles take the streaming form only");
+    if (G.full) { P.own0 = 0; P.own1 = G.nlat; }
     QdScope sc(c, "ocean_tail", true);
     if (c->ocn_tail >= 2) {                                  // LDS-tiled forms
         P.ntc = (G.nlon + QT_TC - 1) / QT_TC;

@@ -83,7 +83,7 @@ __device__ __forceinline__ unsigned qs_off_roll(const QdGeom& G, int g) {
 #define QS_PD_DYN 4               // atmosphere kernel
 #endif
 #ifndef QS_PD_OCN
-#define QS_PD_OCN 4               // ocean kernel (its momentum waves hold five inputs per row)
+#define QS_PD_OCN 2               // ocean kernel: its momentum waves hold five inputs per row -- two rows in flight measured 19.0 us against 20.2 with four (register pressure: 91 against 110 VGPRs, fewer SGPR spills in the row loop)
 #endif
 
 struct QsW {                      // what a wave knows about its strip (everything but lane / v* is wave-uniform)

@@ -91,7 +91,8 @@ __device__ __forceinline__ bool qd_acc_arrive(unsigned long long* acc, unsigned 
     if (__hip_atomic_fetch_add(a + 2, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != in_slot - 1u) return false;
     return __hip_atomic_fetch_add(acc + QD_ACC_SLOTS * QD_ACC_STRIDE, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == slots - 1u;
 }
-// the finishing wave (all 64 lanes): total / (wsum + 1e-15), and everything cleared for the next launch
+// the finishing wave (all 64 lanes): total / (wsum + 1e-15) -- wsum < 0: the raw total (latitude bands all-reduce it first) -- and
+// everything cleared for the next launch
 __device__ __forceinline__ double qd_acc_finish(unsigned long long* acc, const double* partial, int n, double wsum) {
     const int lane = threadIdx.x & 63;
     unsigned long long* s = acc + QD_ACC_STRIDE * lane;
@@ -109,8 +110,10 @@ __device__ __forceinline__ double qd_acc_finish(unsigned long long* acc, const d
         for (int k = lane; k < n; k += 64) a += __hip_atomic_load(partial + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
-        return __shfl(a, 0, 64) / (wsum + 1e-15);
+        const double tot = __shfl(a, 0, 64);
+        return wsum < 0.0 ? tot : tot / (wsum + 1e-15);
     }
-    return ((double)hi + (double)lo * 0x1p-50) / (wsum + 1e-15);
+    const double tot = (double)hi + (double)lo * 0x1p-50;
+    return wsum < 0.0 ? tot : tot / (wsum + 1e-15);
 }
 
