@@ -333,6 +333,11 @@ def main():
         dev.lib.qd_comm_host_allreduce_count(dev.h, _ct.byref(nh))
         comm = {"band_rows": band[1], "halo_rows": band[2], "halo_exchanges_per_step": (ne.value - comm0[0]) / K,
                 "rccl_allreduces_per_step": (na.value - comm0[1]) / K, "host_ring_allreduces_per_step": (nh.value - comm0[2]) / K}
+        ng = _ct.c_int(0)
+        dev.lib.qd_comm_grouped_sum_count(dev.h, _ct.byref(ng))
+        # of the all-reduces, those that went out inside a halo exchange's ncclGroup (counted over the whole run incl. warm-up)
+        comm["allreduces_grouped_into_an_exchange_per_step"] = ng.value / max(1, K + W)
+        comm["collective_launches_per_step"] = comm["halo_exchanges_per_step"] + comm["rccl_allreduces_per_step"] - ng.value / max(1, K + W)
     kern_ms, kern_n = dev.timing_get(args.profile_kernel)
     also_ms, also_n = dev.timing_get(also) if also else (0.0, 0)
     dev.timing(on=False)

@@ -260,6 +260,10 @@ int qd_comm_init(qd_handle h, const void* id128, size_t bytes);   /* all ranks: 
 int qd_comm_init_local(qd_handle* handles, int n);
 int qd_comm_stats(qd_handle h, int* halo_exchanges);
 int qd_comm_allreduce_count(qd_handle h, int* allreduces);        /* all-reduce collectives issued so far (statistics) */
+/* of those, the eta sums of ocean sub-steps that went out INSIDE the ncclGroup of the following halo exchange instead of as a
+ * collective launch of their own (round 3; WindDrivenSlabOcean.step removes the global mean of eta once per sub-step,
+ * pygcm/ocean.py:369-377 -- the reference has no counterpart for the transport) */
+int qd_comm_grouped_sum_count(qd_handle h, int* grouped);
 /* host ring: the ranks of ONE node all-reduce the few host-visible scalars of a step (eta sum per ocean sub-step, CFL maxima)
  * through a POSIX shared-memory segment instead of an RCCL launch each; every rank passes the same `name` (unique per launch).
  * Optional: without it those scalars go through RCCL like everything else. */

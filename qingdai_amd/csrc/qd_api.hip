@@ -257,6 +257,7 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
     { const char* ef = std::getenv("QD_SHAPIRO_STREAM"); if (ef) c->shapiro_stream = std::atoi(ef); }
     { const char* ef = std::getenv("QD_OCN_TAIL"); if (ef) c->ocn_tail = std::atoi(ef); }   // 0: two launches (k_cont_sstadv, k_sst_outlier_fused); 1: k_ocn_tail_stream (default); 2: LDS-tiled k_ocn_tail; 3: k_ocn_tail_tile; 4: k_ocn_step (the whole sub-step in one launch)
     { const char* ef = std::getenv("QD_BAND_TAIL"); if (ef) c->band_tail = ef[0] == '0' ? 0 : 1; }
+    { const char* ef = std::getenv("QD_GROUP_SUMS"); if (ef) c->group_sums = ef[0] == '0' ? 0 : 1; }
     c->geo = QdGeom{d->n_lat, d->n_lon, d->row0, d->n_rows, d->halo, full ? 1 : 0, d->row0 - d->halo, d->n_rows + 2 * d->halo};
     c->own_row0 = d->row0; c->own_nrows = d->n_rows;
     auto bail = [&](const char* w, hipError_t e) { qd_fail(nullptr, w, e); qd_destroy(c); return -1; };

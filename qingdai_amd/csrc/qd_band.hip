@@ -215,6 +215,10 @@ int qd_exchange(qd_ctx* c, const QdUse* slots, int n) {
     if (c->comm) {
         ncclComm_t comm = (ncclComm_t)c->comm;
         ncclGroupStart();
+        if (c->pending_sum) {                                 // a scalar sum nobody has needed yet rides in this group (qd_allreduce_sum_deferred)
+            ncclAllReduce(c->pending_sum, c->pending_sum, 1, ncclDouble, ncclSum, comm, c->stream);
+            c->pending_sum = nullptr; c->grouped_sums++;
+        }
         for (int k = 0; k < n; ++k) {
             const size_t esz = slots[k].u8 ? 1 : sizeof(double);
             const size_t cnt = (size_t)H * G.nlon;
@@ -257,6 +261,26 @@ int qd_exchange(qd_ctx* c, const QdUse* slots, int n) {
         return qd_fail(c, "band handle without a communicator (qd_comm_init / qd_comm_init_local)");
     }
     for (int k = 0; k < n; ++k) c->vm[*slots[k].slot] = H;
+    return 0;
+}
+
+// A one-double sum whose result is first read by a LATER kernel (the eta mean of an ocean sub-step: the next momentum kernel
+// applies it on load): over RCCL it is not issued here but remembered, and goes out inside the ncclGroup of the next halo exchange
+// if one comes before qd_allreduce_flush -- one group launch instead of two.  Other transports reduce at once.
+int qd_allreduce_sum_deferred(qd_ctx* c, double* dptr) {
+    if (c->geo.full) return 0;
+    if (!c->comm || !c->group_sums) return qd_allreduce_f64(c, dptr, 1, 0);
+    if (c->pending_sum && qd_allreduce_flush(c)) return -1;
+    c->allreduces++;
+    c->pending_sum = dptr;
+    return 0;
+}
+int qd_allreduce_flush(qd_ctx* c) {
+    if (!c->pending_sum) return 0;
+    double* p = c->pending_sum;
+    c->pending_sum = nullptr;
+    ncclResult_t r = ncclAllReduce(p, p, 1, ncclDouble, ncclSum, (ncclComm_t)c->comm, c->stream);
+    if (r != ncclSuccess) { c->err = std::string("allreduce: ") + ncclGetErrorString(r); return -1; }
     return 0;
 }
 
@@ -410,6 +434,7 @@ extern "C" int qd_comm_barrier(qd_handle c) {
 
 extern "C" int qd_comm_stats(qd_handle c, int* exchanges) { if (!c || !exchanges) return -1; *exchanges = c->exchanges; return 0; }
 extern "C" int qd_comm_allreduce_count(qd_handle c, int* allreduces) { if (!c || !allreduces) return -1; *allreduces = c->allreduces; return 0; }
+extern "C" int qd_comm_grouped_sum_count(qd_handle c, int* grouped) { if (!c || !grouped) return -1; *grouped = (int)c->grouped_sums; return 0; }
 
 // ---- planner simulation (host only; tests) --------------------------------------------------
 extern "C" int qd_plansim_create(const qd_grid_desc* d, qd_handle* out) {

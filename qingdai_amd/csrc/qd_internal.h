@@ -191,6 +191,9 @@ struct qd_ctx {
     double* med_pred = nullptr;      // [4 sites][16]: last median, valid flag, statistics, published bracket (see qd_reduce.hip): predicted median brackets (qd_reduce.hip)
     int med_predict = 1;             // QD_MEDIAN_PREDICT=0: always the two-histogram-pass select
     int med_seen[4] = {0, 0, 0, 0};  // call sites that have a window centre on the device
+    double* pending_sum = nullptr;   // a deferred one-double all-reduce (qd_allreduce_sum_deferred)
+    int group_sums = 1;              // QD_GROUP_SUMS=0: issue every eta sum as its own collective
+    long grouped_sums = 0;           // deferred sums that went out inside a halo exchange's group
     int band_tail = 1;               // QD_BAND_TAIL=0: latitude bands keep the round-2 sub-step (k_cont_sstadv + k_eta_mean + k_sst_outlier_fused)
     int merge_pointwise = 1;         // QD_MERGE_POINTWISE=0: every pointwise stage of qd_step_n as a launch of its own
     int med_one = 0;                 // QD_MEDIAN_ONE=1: the windowed median as ONE launch (k_med_one) instead of three -- measured equal
@@ -276,6 +279,8 @@ struct QdScope {               // optional per-kernel-group timing with hipEvent
 #define QD_IN8(ptr, r) QdUse{(void**)&(ptr), (r), 1}
 // makes sure every input slab is valid `radius` rows beyond what the launch will compute; exchanges
 // halos when one is not; returns the margin (rows beyond the owned band) the outputs can be computed on
+int qd_allreduce_sum_deferred(qd_ctx* c, double* dptr);
+int qd_allreduce_flush(qd_ctx* c);
 int qd_plan(qd_ctx* c, const QdUse* in, int n, int want = INT_MAX);
 inline int qd_plan(qd_ctx* c, std::initializer_list<QdUse> in, int want = INT_MAX) { return qd_plan(c, in.begin(), (int)in.size(), want); }
 void qd_mark(qd_ctx* c, std::initializer_list<const void*> out, int margin);

@@ -779,6 +779,7 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
             const int m = qd_plan(c, {QD_IN(F[QD_F_ETA], 5), QD_IN(F[QD_F_UO], 4), QD_IN(F[QD_F_VO], 4), QD_IN(taux, 4),
                                       QD_IN(tauy, 4)});
             if (m < 0) return -1;
+            if (qd_allreduce_flush(c)) return -1;             // the previous sub-step's eta sum, unless the exchange above took it along
             QdOcnArgs O;
             O.uo = F[QD_F_UO]; O.vo = F[QD_F_VO]; O.eta = F[QD_F_ETA]; O.taux = taux; O.tauy = tauy; O.land = c->land;
             O.uo_out = qd_scratch(c, 0); O.vo_out = qd_scratch(c, 1); O.eta_out = qd_scratch(c, 2);
@@ -852,7 +853,8 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
                     if (qd_launch_ocn_tail(c, Gs, A)) return -1;
                     off += (size_t)qd_ocn_tail_tiles(c, Gs);
                 }
-                if (qd_allreduce_f64(c, c->dscal + QD_S_ETA_MEAN, 1, 0)) return -1;
+                // first read by the NEXT momentum kernel: if that kernel's inputs need a halo exchange, the sum rides in its group
+                if (qd_allreduce_sum_deferred(c, c->dscal + QD_S_ETA_MEAN)) return -1;
                 qd_mark(c, {F[QD_F_ETA], A.Ts_out, A.uo_out, A.vo_out}, m);
             } else {
             if (qd_launch_ocn_tail(c, Gown, A)) return -1;
@@ -995,6 +997,7 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
             qd_swap(c, QD_F_UO, 2); qd_swap(c, QD_F_VO, 3);
         }
     }
+    if (qd_allreduce_flush(c)) return -1;
     {
         QdScope sc(c, "ocean_finish");
         if (!band && p.ocean_polar_fix && c->merge_pointwise) {
