@@ -776,8 +776,14 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
             continue;
         }
         if (do_diff && c->use_fused && p.ocean_k4_nsub == 1) {
-            const int m = qd_plan(c, {QD_IN(F[QD_F_ETA], 5), QD_IN(F[QD_F_UO], 4), QD_IN(F[QD_F_VO], 4), QD_IN(taux, 4),
-                                      QD_IN(tauy, 4)});
+            // band_tail: every exchange of the sub-step happens HERE, so that the previous sub-step's eta sum (still pending) can ride
+            // in its group: the momentum kernel is planned two rows wider than it needs (its outputs then carry the margin the tail's
+            // T1 rows want) and the tail's other inputs are checked now instead of between the two launches
+            if (band_tail && qd_plan(c, {QD_IN(F[QD_F_ETA], 7), QD_IN(F[QD_F_UO], 6), QD_IN(F[QD_F_VO], 6), QD_IN(taux, 6), QD_IN(tauy, 6),
+                                         QD_IN(F[QD_F_SST], Ro + 2), QD_IN(F[QD_F_QNET], 0), QD_IN8(c->icemask, 0)}) < 0) return -1;
+            // (after the wide plan this one never exchanges: it only tells how far the momentum kernel can go -- at least two rows
+            //  beyond what the tail will store)
+            const int m = qd_plan(c, {QD_IN(F[QD_F_ETA], 5), QD_IN(F[QD_F_UO], 4), QD_IN(F[QD_F_VO], 4), QD_IN(taux, 4), QD_IN(tauy, 4)});
             if (m < 0) return -1;
             if (qd_allreduce_flush(c)) return -1;             // the previous sub-step's eta sum, unless the exchange above took it along
             QdOcnArgs O;
