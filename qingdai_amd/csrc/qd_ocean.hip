@@ -160,7 +160,12 @@ k_stress_max(QdGeom G, const double* __restrict__ ua, const double* __restrict__
         partial[gridDim.y + blockIdx.y] = mUo;
         // whole-globe handles: `partial` is pinned host memory and the host is waiting for it -- every row stamps its own arrival
         // (system-scope release behind its two maxima), so no k_host_flag launch has to follow (4.7 us per step)
-        if (seq_out) __hip_atomic_store(seq_out + blockIdx.y, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // (a RELEASE here writes the whole L2 back once per row: 21.6 us for the launch instead of 11.6; the two maxima and the stamp
+        //  are uncached stores of ONE thread to pinned host memory -- they leave in order once the maxima have been acknowledged)
+        if (seq_out) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(seq_out + blockIdx.y, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -555,21 +560,73 @@ k_sst_clamp_inject(QdGeom G, double* __restrict__ sst, double tmin, double tmax,
 
 // whole-globe handles: the polar fill and the clamp + write-back in ONE launch.  The clamp of a cell reads nothing but the cell, so
 // only the two pole rows depend on the fill: the first workgroup of a pole row does the fill of its row and then the clamp of the
-// whole row, the other workgroups of that row leave at once, every other row is clamped as before.
+// whole row, the other workgroups of that row leave at once, every other row is clamped as before.  The pole workgroup is the long
+// one (a chain of row passes around four block sums: 21 us when written as fill-then-clamp over memory), so for rows of up to
+// QD_PF_CH x 256 columns it loads its row ONCE (all chunks in flight together), reduces the four sums in one exchange and writes the
+// filled, clamped row from registers -- same sums in the same order (thread-strided, shuffle tree, waves in order).
+#define QD_PF_CH 6
 __global__ void __launch_bounds__(QD_BLOCK)
 k_polar_clamp_inject(QdGeom G, QdTabs T, double* __restrict__ sst, double* __restrict__ uo, double* __restrict__ vo, double tmin, double tmax,
                      int inject, const uint8_t* __restrict__ land, const uint8_t* __restrict__ ice, int has_ice,
                      double* __restrict__ Ts_atm, double* __restrict__ eta, const double* __restrict__ eta_mean, double eta_cap) {
-    __shared__ double sm[QD_BLOCK / 64];
+    __shared__ double sm[4][QD_BLOCK / 64];
     const QdTile tl = qd_tile();
     const int i = G.row0 + tl.row;
     if (i == 0 || i == G.nlat - 1) {
         if (tl.seg != 0) return;
-        qd_polar_fill_row(G, T, land, sst, uo, vo, i != 0, sm);
-        __syncthreads();                                     // (every thread re-reads only the columns it wrote itself: same stride)
+        const bool north = i != 0;
         const size_t b = (size_t)qd_lrow(G, i) * G.nlon;
-        for (int j = threadIdx.x; j < G.nlon; j += QD_BLOCK)
-            qd_sst_clamp_cell(b + j, sst, tmin, tmax, inject, land, ice, has_ice, Ts_atm, eta, eta_mean, eta_cap);
+        if (G.nlon > QD_PF_CH * QD_BLOCK) {                  // wide rows: the two-pass form
+            qd_polar_fill_row(G, T, land, sst, uo, vo, north, &sm[0][0]);
+            __syncthreads();                                 // (every thread re-reads only the columns it wrote itself: same stride)
+            for (int j = threadIdx.x; j < G.nlon; j += QD_BLOCK)
+                qd_sst_clamp_cell(b + j, sst, tmin, tmax, inject, land, ice, has_ice, Ts_atm, eta, eta_mean, eta_cap);
+            return;
+        }
+        double t_[QD_PF_CH], u_[QD_PF_CH], v_[QD_PF_CH], sl_[QD_PF_CH], cl_[QD_PF_CH]; int ld_[QD_PF_CH];
+#pragma unroll
+        for (int k = 0; k < QD_PF_CH; ++k) {
+            const int j = threadIdx.x + k * QD_BLOCK;
+            const int jj = j < G.nlon ? j : G.nlon - 1;
+            ld_[k] = j < G.nlon ? (int)land[b + jj] : 1;     // columns beyond the row count as land: they contribute nothing
+            t_[k] = sst[b + jj]; u_[k] = uo[b + jj]; v_[k] = vo[b + jj]; sl_[k] = T.sin_lon[jj]; cl_[k] = T.cos_lon[jj];
+        }
+        double cnt = 0, sT = 0, s0 = 0, s1 = 0;
+#pragma unroll
+        for (int k = 0; k < QD_PF_CH; ++k) {
+            if (ld_[k] != 0) continue;
+            cnt += 1.0;
+            sT += t_[k];
+            const double nx = north ? -cl_[k] : cl_[k], ny = north ? -sl_[k] : sl_[k];
+            s0 += (-sl_[k]) * u_[k] + nx * v_[k];
+            s1 += cl_[k] * u_[k] + ny * v_[k];
+        }
+        cnt = qd_wave_sum_d(cnt); sT = qd_wave_sum_d(sT); s0 = qd_wave_sum_d(s0); s1 = qd_wave_sum_d(s1);
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        if (lane == 0) { sm[0][wv] = cnt; sm[1][wv] = sT; sm[2][wv] = s0; sm[3][wv] = s1; }
+        __syncthreads();
+        cnt = sm[0][0]; sT = sm[1][0]; s0 = sm[2][0]; s1 = sm[3][0];
+        for (int k = 1; k < QD_BLOCK / 64; ++k) { cnt += sm[0][k]; sT += sm[1][k]; s0 += sm[2][k]; s1 += sm[3][k]; }
+        const bool any = cnt > 0.0;
+        const double mT = sT / cnt, m0 = s0 / cnt, m1 = s1 / cnt;
+#pragma unroll
+        for (int k = 0; k < QD_PF_CH; ++k) {
+            const int j = threadIdx.x + k * QD_BLOCK;
+            if (j >= G.nlon) continue;
+            const size_t o = b + j;
+            double tv = t_[k];
+            if (any && ld_[k] == 0) {
+                const double nx = north ? -cl_[k] : cl_[k], ny = north ? -sl_[k] : sl_[k];
+                tv = mT;
+                uo[o] = (-sl_[k]) * m0 + cl_[k] * m1;       // ee_all @ v3_mean (third component is zero)
+                vo[o] = nx * m0 + ny * m1;
+            }
+            // qd_sst_clamp_cell on the filled value
+            if (eta) eta[o] = qd_clip(qd_nn(eta[o] - *eta_mean), -eta_cap, eta_cap);
+            const double t = qd_clip(tv, tmin, tmax);
+            sst[o] = t;
+            if (inject && ld_[k] == 0 && !(has_ice && ice[o] != 0)) Ts_atm[o] = t;
+        }
         return;
     }
     const int j = tl.seg * QD_BLOCK + threadIdx.x;

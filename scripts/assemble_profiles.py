@@ -32,13 +32,16 @@ def main():
         tr[name] = (n0 + n, (m0 * n0 + mean * n) / (n0 + n))
     nlat, nlon = int(os.environ.get("QD_PROF_NLAT", "721")), int(os.environ.get("QD_PROF_NLON", "1440"))
     cells = nlat * nlon
-    cal = "k_precip_blend"
+    # calibration kernel with a known byte count: k_qnet reads nine f64 fields + the land mask and writes one f64 field + the ice mask
+    # (round 2 used k_precip_blend, which round 3 merged into k_gauss_pair)
+    cal = "k_qnet" if "k_qnet" in f else "k_precip_blend"
+    cal_rd, cal_wr = ((9 * 8 + 1) * cells, 9 * cells) if cal == "k_qnet" else (2 * cells * 8, cells * 8)
     traffic = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, no stats/sys-trace; scripts/profile_round.sh) "
                        "of `bench.py --no-cpu-baseline --no-ecology-leg --steps 12 --warmup 4`; mean per dispatch, counters in KiB.  Correction per "
                        "MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half the bytes of a coalesced streaming read -> x2, re-calibrated on "
-                       "k_precip_blend (reads two fields, writes one).  Memory-side (fabric) requests: Infinity-Cache hits are counted.",
-               "calibration": {"kernel": cal, "known_read_KiB": 2 * cells * 8 / 1024.0, "FETCH_SIZE_KiB": f[cal]["FETCH_SIZE"],
-                               "known_write_KiB": cells * 8 / 1024.0, "WRITE_SIZE_KiB": w[cal]["WRITE_SIZE"]}, "kernels": {}}
+                       "a pointwise kernel of known byte count (see `calibration`).  Memory-side (fabric) requests: Infinity-Cache hits are counted.",
+               "calibration": {"kernel": cal, "known_read_KiB": cal_rd / 1024.0, "FETCH_SIZE_KiB": f[cal]["FETCH_SIZE"],
+                               "known_write_KiB": cal_wr / 1024.0, "WRITE_SIZE_KiB": w[cal]["WRITE_SIZE"]}, "kernels": {}}
     for k in f:
         if k.startswith("__amd"):
             continue
