@@ -407,7 +407,10 @@ __device__ __forceinline__ void qt_stamp(int slot) {
 #define QT_STAMP(k) ((void)0)
 #endif
 
-__global__ void __launch_bounds__(128)
+// NS: SST waves per strip.  The SST wave is the long one of a strip (per-wave timelines, round 3: 22 us for its 12 rows against 12 us
+// for the currents wave's 8); with NS = 2 each SST wave takes half of the strip's rows (+ its own four halo rows of T1).
+template <int NS>
+__global__ void __launch_bounds__(64 + 64 * NS)
 k_ocn_tail_stream(QdGeom G, QdTabs T, QdTailArgs P) {
     const unsigned w = qd_xcd_chunk(blockIdx.x, gridDim.x);
     const int rs = (int)(w / (unsigned)P.ntc), cs = (int)(w % (unsigned)P.ntc);
@@ -423,7 +426,17 @@ k_ocn_tail_stream(QdGeom G, QdTabs T, QdTailArgs P) {
     W.o1 = min(W.o0 + P.R, G.row0 + G.nrows);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     QT_STAMP(0);
-    if (wv == 1) { __builtin_amdgcn_s_setprio(2); qt_sst_wave(G, T, P, W); QT_STAMP(2); return; }      // the SST wave is the long one
+    if (wv >= 1) {                                           // the SST waves are the long ones
+        __builtin_amdgcn_s_setprio(2);
+        if (NS == 2) {
+            const int mid = W.o0 + (W.o1 - W.o0 + 1) / 2;
+            if (wv == 1) W.o1 = mid; else W.o0 = mid;
+            if (W.o0 >= W.o1) return;
+        }
+        qt_sst_wave(G, T, P, W);
+        QT_STAMP(2);
+        return;
+    }
     double acc = qt_currents_wave(T, P, W);
     QT_STAMP(2);
     acc = qt_wave_sum(acc);
@@ -873,6 +886,12 @@ int qd_launch_ocn_step(qd_ctx* c, const QdOcnArgs& O, QdTailArgs& P) {
     return 0;
 }
 
+// SST waves per strip (QD_TAIL_NS: tuning override, read per launch)
+static int qt_sst_waves(const qd_ctx* c) {
+    if (const char* e = std::getenv("QD_TAIL_NS")) { const int r = std::atoi(e); if (r == 1 || r == 2) return r; }
+    return 2;
+}
+
 // Strip height of the streaming form.  Measured (rocprofv3 kernel trace, 721 x 1440), with the eta mean finished inside the launch:
 // R = 6 / 7 / 8 / 9 / 10 / 12 -> 29.2 / 24.6 / 26.3 / 26.3 / 26.9 / 28.5 us (without it R = 4 / 6 / 8 / 10 / 12 / 16 / 24 -> 27.0 / 26.2 / 23.9 /
 // 25.4 / 27.4 / 32.7 / 41.3): a wave is a serial chain of rows, shorter strips mean more of them in parallel; below 7 the SST wave's
@@ -880,7 +899,10 @@ int qd_launch_ocn_step(qd_ctx* c, const QdOcnArgs& O, QdTailArgs& P) {
 // QD_TAIL_R: tuning override, read per launch.
 static int qt_rows(const qd_ctx* c) {
     if (const char* e = std::getenv("QD_TAIL_R")) { const int r = std::atoi(e); if (r > 0) return r; }
-    return 8;                                               // (7 is 1.5 us faster in the trace, 0.3 % of the step: not worth a second summation order in the tests)
+    // round 3, two SST waves per strip (HIP events, tail + the k_ocn_stream launch that follows it, 721 x 1440): R = 12 / 13 / 14 / 16 / 18 / 20
+    // -> 25.7 + 16.8 / 26.8 + 16.9 / 24.8 + 16.8 / 26.9 + 16.9 / 26.4 + 16.8 / 28.1 + 16.8 us; one SST wave: R = 7 / 8 / 9 / 10 / 12 -> 24.0 + 17.8 / 26.1 + 17.0 /
+    // 26.5 + 17.0 / 27.6 + 17.1 / 29.2 + 17.0.  (The momentum kernel's time depends on what the tail leaves in the caches: judge the pair.)
+    return qt_sst_waves(c) == 2 ? 14 : 8;
 }
 
 // number of eta partial sums the launch leaves in P.partial
@@ -912,7 +934,8 @@ int qd_launch_ocn_tail(qd_ctx* c, const QdGeom& G, QdTailArgs& P) {
     if (!stamps) { hipMalloc(&stamps, stamp_words * 8); hipMemcpyToSymbol(HIP_SYMBOL(qt_stamp_buf), &stamps, sizeof(stamps)); }
     hipMemsetAsync(stamps, 0, stamp_words * 8, c->stream);
 #endif
-    QD_LAUNCH_TIMED(sc, k_ocn_tail_stream, dim3(nrs * P.ntc), dim3(128), c->stream, G, c->tabs, P);
+    if (qt_sst_waves(c) == 2) QD_LAUNCH_TIMED(sc, k_ocn_tail_stream<2>, dim3(nrs * P.ntc), dim3(192), c->stream, G, c->tabs, P);
+    else QD_LAUNCH_TIMED(sc, k_ocn_tail_stream<1>, dim3(nrs * P.ntc), dim3(128), c->stream, G, c->tabs, P);
 #ifdef QT_STAMPS
     if (const char* f = std::getenv("QD_STAMPS_FILE")) {
         std::vector<unsigned long long> h(stamp_words);
