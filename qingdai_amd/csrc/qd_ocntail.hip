@@ -889,7 +889,7 @@ int qd_launch_ocn_step(qd_ctx* c, const QdOcnArgs& O, QdTailArgs& P) {
 // SST waves per strip (QD_TAIL_NS: tuning override, read per launch)
 static int qt_sst_waves(const qd_ctx* c) {
     if (const char* e = std::getenv("QD_TAIL_NS")) { const int r = std::atoi(e); if (r == 1 || r == 2) return r; }
-    return 2;
+    return 1;
 }
 
 // Strip height of the streaming form.  Measured (rocprofv3 kernel trace, 721 x 1440), with the eta mean finished inside the launch:
@@ -902,7 +902,9 @@ static int qt_rows(const qd_ctx* c) {
     // round 3, two SST waves per strip (HIP events, tail + the k_ocn_stream launch that follows it, 721 x 1440): R = 12 / 13 / 14 / 16 / 18 / 20
     // -> 25.7 + 16.8 / 26.8 + 16.9 / 24.8 + 16.8 / 26.9 + 16.9 / 26.4 + 16.8 / 28.1 + 16.8 us; one SST wave: R = 7 / 8 / 9 / 10 / 12 -> 24.0 + 17.8 / 26.1 + 17.0 /
     // 26.5 + 17.0 / 27.6 + 17.1 / 29.2 + 17.0.  (The momentum kernel's time depends on what the tail leaves in the caches: judge the pair.)
-    return qt_sst_waves(c) == 2 ? 14 : 8;
+    // What decides is the 240-step bench, not the event times of a 12-step probe: (NS, R) = (2, 14) / (1, 8) / (1, 7) -> 0.991 / 0.988 /
+    // 0.968-0.971 ms per step (same box, twice each), and under rocprofv3 the two-SST-wave form runs 30.7 us per launch against 25.1.
+    return qt_sst_waves(c) == 2 ? 14 : 7;
 }
 
 // number of eta partial sums the launch leaves in P.partial
