@@ -173,6 +173,10 @@ int qd_op_divergence(qd_handle h, const double* u, const double* v, double* out)
 int qd_op_vorticity(qd_handle h, const double* u, const double* v, double* out);    /* grid.py:70-88 */
 int qd_op_gaussian(qd_handle h, const double* F, double sigma, int mode_wrap, double* out); /* physics.py:44 */
 int qd_op_median_positive(qd_handle h, const double* x, double dflt, double* out);  /* dynamics.py:344-348 */
+/* (new, diagnostics) the per-call-site state of the three in-step medians (dynamics.py:344-348, run_simulation.py:1740-1747,
+ * 1866-1874): 4 sites x 16 doubles {last median, -, -, valid, hits, misses, candidates of the last call, positives of the last
+ * call, bracket lo, hi, -, ok, calls, last miss: call, centre, result}; site 1 = P_cond, 2 = convergence, 3 = precipitation */
+int qd_median_state(qd_handle h, double* out64);
 
 /* ---- ecology spectral sub-step, first stage (pygcm/ecology/spectral.py:304-426) --------------------
  * dual_star_insolation_to_bands on the resident ISR_A / ISR_B: specA/specB/tray are the NB host-computed band weights of the

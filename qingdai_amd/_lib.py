@@ -32,7 +32,7 @@ SYMBOLS = [
     "qd_get_step_counter", "qd_set_step_counter", "qd_forcing", "qd_simple_albedo", "qd_atmos_step",
     "qd_ocean_step", "qd_driver_physics", "qd_hydrology_commit", "qd_step_n", "qd_last_ocean_nsub", "qd_sync",
     "qd_op_laplacian", "qd_op_hyperdiffuse", "qd_op_advect", "qd_op_shapiro", "qd_op_zonal_filter", "qd_op_divergence",
-    "qd_op_vorticity", "qd_op_gaussian", "qd_op_median_positive", "qd_reduce", "qd_energy_diagnostics", "qd_energy_diagnostics_last", "qd_band_insolation",
+    "qd_op_vorticity", "qd_op_gaussian", "qd_op_median_positive", "qd_median_state", "qd_reduce", "qd_energy_diagnostics", "qd_energy_diagnostics_last", "qd_band_insolation",
     "qd_comm_unique_id", "qd_comm_init", "qd_comm_init_local", "qd_comm_stats", "qd_comm_allreduce_count", "qd_comm_grouped_sum_count", "qd_comm_init_shm", "qd_comm_host_allreduce_count", "qd_hostring_open", "qd_hostring_allreduce",
     "qd_hostring_close", "qd_comm_barrier", "qd_comm_allreduce_max",
     "qd_plansim_create", "qd_plansim_destroy", "qd_plansim_plan", "qd_plansim_mark", "qd_plansim_margin", "qd_plansim_segments",
@@ -126,6 +126,7 @@ def load():
     lib.qd_comm_init.argtypes = [vp, vp, sz]
     lib.qd_comm_barrier.argtypes = [vp]
     lib.qd_comm_init_local.argtypes = [ctypes.POINTER(vp), i32]
+    lib.qd_median_state.argtypes = [vp, dp]
     lib.qd_comm_stats.argtypes = [vp, ctypes.POINTER(i32)]
     lib.qd_comm_allreduce_count.argtypes = [vp, ctypes.POINTER(i32)]
     lib.qd_comm_grouped_sum_count.argtypes = [vp, ctypes.POINTER(i32)]

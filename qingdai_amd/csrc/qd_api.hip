@@ -308,10 +308,7 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
         if ((e = hipMalloc(&c->med_pred, 64 * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
         hipMemsetAsync(c->med_pred, 0, 64 * sizeof(double), c->stream);
         { const char* ef = std::getenv("QD_MEDIAN_PREDICT"); if (ef && ef[0] == '0') c->med_predict = 0; }
-        { const char* ef = std::getenv("QD_MEDIAN_ONE"); if (ef) c->med_one = ef[0] == '1' ? 1 : 0; }
         { const char* ef = std::getenv("QD_MERGE_POINTWISE"); if (ef) c->merge_pointwise = ef[0] == '0' ? 0 : 1; }
-        if ((e = hipMalloc(&c->med_err, sizeof(unsigned int))) != hipSuccess) return bail("hipMalloc", e);
-        hipMemsetAsync(c->med_err, 0, sizeof(unsigned int), c->stream);
     }
     if ((e = hipHostMalloc((void**)&c->hpin, 64 * sizeof(double))) != hipSuccess) return bail("hipHostMalloc", e);
     if ((e = hipHostMalloc((void**)&c->hpin_rows, (size_t)3 * c->geo.lrows() * sizeof(double))) != hipSuccess) return bail("hipHostMalloc", e);
@@ -356,7 +353,6 @@ extern "C" int qd_destroy(qd_handle c) {
     qd_eco_free(c);
     if (c->sel_cand) hipFree(c->sel_cand); if (c->sel_ccount) hipFree(c->sel_ccount);
     if (c->med_pred) hipFree(c->med_pred);
-    if (c->med_err) hipFree(c->med_err);
     if (c->med_gather) hipFree(c->med_gather);
     qd_comm_release(c);
     if (c->hpin) hipHostFree(c->hpin);
@@ -474,12 +470,6 @@ extern "C" int qd_sync(qd_handle c) {
     if (!c) return -1;
     hipSetDevice(c->desc.device);
     QD_HIP(c, hipStreamSynchronize(c->stream));
-    if (c->med_err && c->med_gen) {                          // a workgroup of k_med_one that gave up waiting for the bracket flag
-        unsigned int flag = 0;
-        QD_HIP(c, hipMemcpy(&flag, c->med_err, sizeof(flag), hipMemcpyDeviceToHost));
-        if (flag) return qd_fail(c, "k_med_one: a workgroup timed out waiting for the bracket (workgroups not co-resident?); "
-                                    "set QD_MEDIAN_ONE=0");
-    }
     return 0;
 }
 extern "C" int qd_last_ocean_nsub(qd_handle c, int* n) { if (!c || !n) return -1; *n = c->last_nsub; return 0; }
@@ -676,6 +666,16 @@ extern "C" int qd_op_median_positive(qd_handle c, const double* x, double dflt, 
     QD_HIP(c, hipMemcpyAsync(c->hpin, c->dscal + QD_S_MED_OUT, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     QD_HIP(c, hipStreamSynchronize(c->stream));
     *out = c->hpin[0];
+    return 0;
+}
+
+extern "C" int qd_median_state(qd_handle c, double* out64) {
+    if (!c || !out64) return -1;
+    hipSetDevice(c->desc.device);
+    for (int k = 0; k < 16 * 4; ++k) out64[k] = 0.0;
+    if (!c->med_pred) return 0;
+    QD_HIP(c, hipStreamSynchronize(c->stream));
+    QD_HIP(c, hipMemcpy(out64, c->med_pred, sizeof(double) * 16 * 4, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -196,10 +196,6 @@ struct qd_ctx {
     long grouped_sums = 0;           // deferred sums that went out inside a halo exchange's group
     int band_tail = 1;               // QD_BAND_TAIL=0: latitude bands keep the round-2 sub-step (k_cont_sstadv + k_eta_mean + k_sst_outlier_fused)
     int merge_pointwise = 1;         // QD_MERGE_POINTWISE=0: every pointwise stage of qd_step_n as a launch of its own
-    int med_one = 0;                 // QD_MEDIAN_ONE=1: the windowed median as ONE launch (k_med_one) instead of three -- measured equal
-                                     // (39.6 us against 17 + 13 + 11: the chain of flush / ticket / fence round trips is the cost, not the launches)
-    unsigned long long med_gen = 0;  // generation of k_med_one's bracket flag
-    unsigned int* med_err = nullptr; // raised by a k_med_one workgroup that gave up waiting (checked by qd_sync)
     double* med_gather = nullptr;    // band handles: [world][4 + 4092] gathered candidate segments of the windowed median
     double* hpin = nullptr;        // pinned host scalars
     double* hpin_rows = nullptr;   // pinned, 2 x slab rows: per-row partial maxima read back in one copy

@@ -363,86 +363,39 @@ k_sel_final(unsigned long long* st, const double* __restrict__ cand, unsigned in
 // ------------------------------------------------------------------ windowed-histogram median (whole-globe handles)
 // The medians of a step are medians of fields whose scale does not jump between steps.  Each call site keeps its last
 // median on the device.  Pass 1 (k_med_hist) histograms the positives over a WINDOW of bit patterns centred on it -- a factor
-// 16 either way, 2048 bins of 2^44 ulps (0.2 % wide) -- and counts the positives and those below the window; the last
-// workgroup locates the bins of the two middle ranks and publishes their value range [lo, hi].  Pass 2 (k_med_bracket) copies
-// the positives inside [lo, hi] to a list (a few thousand values) and recounts; one workgroup (k_med_final) selects the ranks
-// from the list.  That is three launches and two passes over the field where the digit-by-digit select needs four and three.
+// 16 either way, 2048 bins of 2^44 ulps (0.2 % wide) -- and counts the positives and those below the window.  Pass 2
+// (k_med_scan_bracket; bands: k_med_bracket behind an all-reduce and a one-workgroup scan) locates the bins of the two middle
+// ranks, i.e. their value range [lo, hi], copies the positives inside it to a list (a few hundred values) and recounts; one
+// workgroup (k_med_final) selects the ranks from the list, held in LDS.  That is three launches and two passes over the field
+// where the digit-by-digit select needs four and three.  The window has to be that wide: in the benchmark's first hundred steps
+// the three medians move by 5-60 % from one step to the next (scripts/median_drift.py), so a bracket guessed from the last
+// median alone would miss most of the time.
 // Exact whatever the window was: if a rank falls outside it (first use after an upload, a field that became all-zero) the
 // finishing workgroup runs the radix select over the whole field itself -- slow, rare, and it re-centres the window.
 // pred[site]: {last median, -, -, valid, hits, misses, last list length, last count | lo, hi, -, bracket ok}
 #define QD_MED_SITES 4
 #define QD_MED_BAND_CAP 4092u      // candidates per band in the gathered segments (4096 doubles each)
 #define QD_MED_WSHIFT 44
-// returns true in the workgroup that ran the scan and published the bracket (mode 0: the last one to finish; mode 2: the only one)
-__device__ __forceinline__ bool qd_med_hist_body(const QdGeom& G, const double* __restrict__ x, int transform, double tparam, double* pred,
-                                                 unsigned long long* st, unsigned int* hist, int mode, int nblk_x, int nblk_y, int bx, int by) {
-    // mode 0: histogram + scan by the last workgroup (whole-globe handles)
-    // mode 1: histogram only   mode 2: scan only (one workgroup) -- latitude bands all-reduce the histogram in between
-    __shared__ unsigned int sh[QD_HIST_BINS + 2];             // + count of positives, + count below the window
-    __shared__ unsigned long long s_st[2];
-    __shared__ int s_last;
-    const int t = threadIdx.x, lane = t & 63;
-    const bool valid = pred[3] != 0.0;
-    // window of bit patterns [base, base + 2048 << 44): centre / 16 .. centre * 16 (8 binades)
-    const unsigned long long cbits = (unsigned long long)__double_as_longlong(valid ? pred[0] : 1.0);
+#define QD_MED_LDS_LIST 4096       // candidates the finishing workgroup keeps in LDS (32 KB)
+// window of bit patterns [base, base + 2048 << 44) around a site's last median: centre / 16 .. centre * 16 (8 binades)
+__device__ __forceinline__ unsigned long long qd_med_window_base(bool valid, double centre) {
+    const unsigned long long cbits = (unsigned long long)__double_as_longlong(valid ? centre : 1.0);
     const unsigned long long four = 4ull << 52;
-    const unsigned long long base = cbits > four ? cbits - four : 0ull;
-    if (mode != 2) {
-    for (int k = t; k < QD_HIST_BINS + 2; k += QD_BLOCK) sh[k] = 0u;
-    __syncthreads();
-    const int jstep = nblk_x * QD_BLOCK;
-    unsigned int n_pos = 0, n_below = 0;
-    for (int i = G.row0 + by; i < G.row0 + G.nrows; i += nblk_y) {
-        const size_t b = (size_t)qd_lrow(G, i) * G.nlon;
-        for (int jb = bx * QD_BLOCK; jb < G.nlon; jb += 8 * jstep) {
-            double vbuf[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int j = jb + q * jstep + t;
-                vbuf[q] = x[b + (j < G.nlon ? j : G.nlon - 1)];
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int j0 = jb + q * jstep;
-                if (j0 >= G.nlon) break;
-                const int j = j0 + t;
-                const double v = (j < G.nlon) ? qd_med_value(vbuf[q], transform, tparam) : 0.0;
-                const bool pos = v > 0.0;
-                const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
-                n_pos += pos ? 1u : 0u;
-                const bool below = pos && bits < base;
-                n_below += below ? 1u : 0u;
-                const unsigned long long idx = (bits - base) >> QD_MED_WSHIFT;
-                if (pos && !below && idx < (unsigned long long)QD_HIST_BINS) atomicAdd(&sh[(unsigned int)idx], 1u);
-            }
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { n_pos += __shfl_down(n_pos, o, 64); n_below += __shfl_down(n_below, o, 64); }
-    if (lane == 0) {                                          // one global atomic per workgroup and counter, like any other bin
-        if (n_pos) atomicAdd(&sh[QD_HIST_BINS], n_pos);
-        if (n_below) atomicAdd(&sh[QD_HIST_BINS + 1], n_below);
-    }
-    __syncthreads();
-    for (int k = t; k < QD_HIST_BINS + 2; k += QD_BLOCK) if (sh[k]) atomicAdd(&hist[k], sh[k]);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (mode == 1) return false;
-    __syncthreads();
-    if (t == 0) {
-        const unsigned long long ticket = atomicAdd(&st[6], 1ull);
-        s_last = (ticket == (unsigned long long)(nblk_x * nblk_y) - 1ull) ? 1 : 0;
-    }
-    __syncthreads();
-    if (!s_last) return false;
-    }   // mode != 2
-    // ---- last workgroup: bins of the two middle ranks
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    for (int k = t; k < QD_HIST_BINS; k += QD_BLOCK) sh[k] = __hip_atomic_load(&hist[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (t < 2) s_st[t] = (unsigned long long)__hip_atomic_load(&hist[QD_HIST_BINS + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const int per = QD_HIST_BINS / QD_BLOCK;
+    return cbits > four ? cbits - four : 0ull;
+}
+
+struct QdMedBracket { unsigned long long lo_b, hi_b; bool ok, none; };
+
+// One workgroup of QD_BLOCK threads, the summed histogram in sh[0 .. QD_HIST_BINS) and {positives, positives below the window} in
+// cnt[0..1] (LDS, already visible to every thread): the bit patterns [lo_b, hi_b] that hold both middle ranks.  Every thread gets
+// the same answer.  No usable window (first call, a regime change of the field): the side the ranks went to, or every positive
+// value -- the finisher then selects from the field itself.
+__device__ __forceinline__ QdMedBracket qd_med_scan(const unsigned int* sh, const unsigned long long* cnt, bool valid,
+                                                    unsigned long long base) {
     __shared__ unsigned int wtot[QD_BLOCK / 64];
     __shared__ int s_bin[2];
+    const int t = threadIdx.x, lane = t & 63;
+    const int per = QD_HIST_BINS / QD_BLOCK;
     unsigned int sacc = 0;
     for (int k = 0; k < per; ++k) sacc += sh[t * per + k];
     unsigned int inc = sacc;
@@ -455,7 +408,7 @@ __device__ __forceinline__ bool qd_med_hist_body(const QdGeom& G, const double* 
     for (int k = 0; k < (t >> 6); ++k) wbase += wtot[k];
     for (int k = 0; k < QD_BLOCK / 64; ++k) total += wtot[k];
     const unsigned long long excl = (unsigned long long)wbase + inc - sacc;
-    const unsigned long long m = s_st[0], below = s_st[1];
+    const unsigned long long m = cnt[0], below = cnt[1];
     const unsigned long long k1 = m ? (m - 1ull) / 2ull : 0ull, k2 = m / 2ull;
     const bool inside = valid && m > 0ull && k1 >= below && k2 < below + (unsigned long long)total;
     if (inside && sacc > 0) {
@@ -470,41 +423,117 @@ __device__ __forceinline__ bool qd_med_hist_body(const QdGeom& G, const double* 
         }
     }
     __syncthreads();
-    if (t == 0) {
-        const bool ok = inside && s_bin[0] >= 0 && s_bin[1] >= s_bin[0];
-        const unsigned long long top = base + ((unsigned long long)QD_HIST_BINS << QD_MED_WSHIFT);   // first pattern above the window
-        const unsigned long long maxb = 0x7FEFFFFFFFFFFFFFull;                                        // DBL_MAX
-        unsigned long long lo_b = 1ull, hi_b = maxb;           // no usable window: every positive value is a candidate
-        if (ok) {
-            lo_b = base + ((unsigned long long)s_bin[0] << QD_MED_WSHIFT);
-            hi_b = base + ((unsigned long long)(s_bin[1] + 1) << QD_MED_WSHIFT) - 1ull;
-        } else if (valid && m > 0ull) {
-            // the ranks left the window (a regime change of the field): hand the finisher the side they went to
-            if (k2 < below) hi_b = base - 1ull;
-            else if (k1 >= below + (unsigned long long)total) lo_b = top;
-        }
-        if (lo_b < 1ull) lo_b = 1ull;
-        if (hi_b > maxb) hi_b = maxb;
-        pred[8] = __longlong_as_double((long long)lo_b);
-        pred[9] = __longlong_as_double((long long)hi_b);
-        pred[11] = 1.0;
-        // no positive entry at all (whole-globe handles): the bracket pass has nothing to collect or recount -- its workgroups return
-        // at once, and the finisher, which finds the count it left at zero, writes the default
-        pred[10] = (mode == 0 && m == 0ull) ? 1.0 : 0.0;
-        __hip_atomic_store(&st[6], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    QdMedBracket B;
+    B.ok = inside && s_bin[0] >= 0 && s_bin[1] >= s_bin[0];
+    B.none = m == 0ull;
+    const unsigned long long top = base + ((unsigned long long)QD_HIST_BINS << QD_MED_WSHIFT);   // first pattern above the window
+    const unsigned long long maxb = 0x7FEFFFFFFFFFFFFFull;                                        // DBL_MAX
+    B.lo_b = 1ull; B.hi_b = maxb;                             // no usable window: every positive value is a candidate
+    if (B.ok) {
+        B.lo_b = base + ((unsigned long long)s_bin[0] << QD_MED_WSHIFT);
+        B.hi_b = base + ((unsigned long long)(s_bin[1] + 1) << QD_MED_WSHIFT) - 1ull;
+    } else if (valid && m > 0ull) {
+        // the ranks left the window (a regime change of the field): hand the finisher the side they went to
+        if (k2 < below) B.hi_b = base - 1ull;
+        else if (k1 >= below + (unsigned long long)total) B.lo_b = top;
     }
-    for (int k = t; k < QD_HIST_BINS + 2; k += QD_BLOCK) __hip_atomic_store(&hist[k], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return true;
+    if (B.lo_b < 1ull) B.lo_b = 1ull;
+    if (B.hi_b > maxb) B.hi_b = maxb;
+    __syncthreads();                                          // s_bin / wtot may be reused by a second call
+    return B;
+}
+
+// mode 1: histogram only (every workgroup adds its LDS histogram to hist[]; nothing is scanned or reset here)
+// mode 2: scan only, one workgroup -- latitude bands all-reduce the histogram in between; publishes pred[8..11], resets hist[]
+// (whole-globe handles: mode 1, then every workgroup of k_med_scan_bracket scans for itself)
+__device__ __forceinline__ void qd_med_hist_body(const QdGeom& G, const double* __restrict__ x, int transform, double tparam, double* pred,
+                                                 unsigned int* hist, int mode, int nblk_x, int nblk_y, int bx, int by) {
+    __shared__ unsigned int sh[QD_HIST_BINS + 2];             // + count of positives, + count below the window
+    __shared__ unsigned long long s_st[2];
+    const int t = threadIdx.x, lane = t & 63;
+    const bool valid = pred[3] != 0.0;
+    const unsigned long long base = qd_med_window_base(valid, pred[0]);
+    if (mode != 2) {
+        for (int k = t; k < QD_HIST_BINS + 2; k += QD_BLOCK) sh[k] = 0u;
+        __syncthreads();
+        const int jstep = nblk_x * QD_BLOCK;
+        unsigned int n_pos = 0, n_below = 0;
+        for (int i = G.row0 + by; i < G.row0 + G.nrows; i += nblk_y) {
+            const size_t b = (size_t)qd_lrow(G, i) * G.nlon;
+            for (int jb = bx * QD_BLOCK; jb < G.nlon; jb += 8 * jstep) {
+                double vbuf[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int j = jb + q * jstep + t;
+                    vbuf[q] = x[b + (j < G.nlon ? j : G.nlon - 1)];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int j0 = jb + q * jstep;
+                    if (j0 >= G.nlon) break;
+                    const int j = j0 + t;
+                    const double v = (j < G.nlon) ? qd_med_value(vbuf[q], transform, tparam) : 0.0;
+                    const bool pos = v > 0.0;
+                    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+                    n_pos += pos ? 1u : 0u;
+                    const bool below = pos && bits < base;
+                    n_below += below ? 1u : 0u;
+                    const unsigned long long idx = (bits - base) >> QD_MED_WSHIFT;
+                    if (pos && !below && idx < (unsigned long long)QD_HIST_BINS) atomicAdd(&sh[(unsigned int)idx], 1u);
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { n_pos += __shfl_down(n_pos, o, 64); n_below += __shfl_down(n_below, o, 64); }
+        if (lane == 0) {                                      // one global atomic per workgroup and counter, like any other bin
+            if (n_pos) atomicAdd(&sh[QD_HIST_BINS], n_pos);
+            if (n_below) atomicAdd(&sh[QD_HIST_BINS + 1], n_below);
+        }
+        __syncthreads();
+        for (int k = t; k < QD_HIST_BINS + 2; k += QD_BLOCK) if (sh[k]) atomicAdd(&hist[k], sh[k]);
+        return;
+    }
+    // ---- mode 2 (bands): the all-reduced histogram -> bracket
+    for (int k = t; k < QD_HIST_BINS; k += QD_BLOCK) sh[k] = hist[k];
+    if (t < 2) s_st[t] = (unsigned long long)hist[QD_HIST_BINS + t];
+    __syncthreads();
+    const QdMedBracket B = qd_med_scan(sh, s_st, valid, base);
+    if (t == 0) {
+        pred[8] = __longlong_as_double((long long)B.lo_b);
+        pred[9] = __longlong_as_double((long long)B.hi_b);
+        pred[10] = 0.0;
+        pred[11] = 1.0;
+    }
+    for (int k = t; k < QD_HIST_BINS + 2; k += QD_BLOCK) hist[k] = 0u;
 }
 
 __global__ void __launch_bounds__(QD_BLOCK)
-k_med_hist(QdGeom G, const double* __restrict__ x, int transform, double tparam, double* pred, unsigned long long* st,
-           unsigned int* hist, int mode) {
-    qd_med_hist_body(G, x, transform, tparam, pred, st, hist, mode, (int)gridDim.x, (int)gridDim.y, (int)blockIdx.x, (int)blockIdx.y);
+k_med_hist(QdGeom G, const double* __restrict__ x, int transform, double tparam, double* pred, unsigned int* hist, int mode) {
+    qd_med_hist_body(G, x, transform, tparam, pred, hist, mode, (int)gridDim.x, (int)gridDim.y, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 __global__ void k_med_seed(double* pred, const double* out, const unsigned long long* count) {
     if (threadIdx.x == 0 && blockIdx.x == 0) { pred[0] = *out; pred[3] = (*count > 0ull) ? 1.0 : 0.0; }
+}
+
+// one value of the collecting pass: counts, and a slot in the candidate list when it lies inside [lo, hi] (one returning atomic per
+// wavefront that holds any)
+__device__ __forceinline__ void qd_med_collect(double v, double lo, double hi, int lane, unsigned long long lt, unsigned int& n_pos,
+                                               unsigned int& n_below, double* __restrict__ cand, unsigned int* __restrict__ ccount,
+                                               unsigned int cap) {
+    const bool pos = v > 0.0;
+    n_pos += pos ? 1u : 0u;
+    n_below += (pos && v < lo) ? 1u : 0u;
+    const bool in = pos && v >= lo && v <= hi;
+    const unsigned long long m = __ballot(in);
+    if (m) {
+        unsigned int base = 0;
+        const int leader = __ffsll((long long)m) - 1;
+        if (lane == leader) base = atomicAdd(&ccount[0], (unsigned int)__popcll(m));
+        base = (unsigned int)__shfl((int)base, leader, 64);
+        const unsigned int idx = base + (unsigned int)__popcll(m & lt);
+        if (in && idx < cap) cand[idx] = v;                  // the count keeps running past the capacity: overflow is visible
+    }
 }
 
 // lo > hi: empty bracket (the finisher falls back to the field itself)
@@ -530,19 +559,7 @@ __device__ __forceinline__ void qd_med_bracket_body(const QdGeom& G, const doubl
                 if (j0 >= G.nlon) break;                                  // wave-uniform
                 const int j = j0 + t;
                 const double v = (j < G.nlon) ? qd_med_value(vbuf[q], transform, tparam) : 0.0;
-                const bool pos = v > 0.0;
-                n_pos += pos ? 1u : 0u;
-                n_below += (pos && v < lo) ? 1u : 0u;
-                const bool in = pos && v >= lo && v <= hi;
-                const unsigned long long m = __ballot(in);
-                if (m) {
-                    unsigned int base = 0;
-                    const int leader = __ffsll((long long)m) - 1;
-                    if (lane == leader) base = atomicAdd(&ccount[0], (unsigned int)__popcll(m));
-                    base = (unsigned int)__shfl((int)base, leader, 64);
-                    const unsigned int idx = base + (unsigned int)__popcll(m & lt);
-                    if (in && idx < cap) cand[idx] = v;          // the count keeps running past the capacity: overflow is visible
-                }
+                qd_med_collect(v, lo, hi, lane, lt, n_pos, n_below, cand, ccount, cap);
             }
         }
     }
@@ -565,6 +582,88 @@ k_med_bracket(QdGeom G, const double* __restrict__ x, int transform, double tpar
     const bool valid = pred[3] != 0.0;
     const double lo = valid ? pred[0] : 0.0, hi = valid ? pred[1] : -1.0;     // invalid: empty bracket, the finisher falls back
     qd_med_bracket_body(G, x, transform, tparam, lo, hi, st, cand, ccount, cap, (int)gridDim.x, (int)gridDim.y, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// Whole-globe handles: pass 2 with the scan in front of it.  EVERY workgroup reads the summed histogram (8 KB, written by the
+// previous launch's atomics) and finds the bracket for itself -- 256 redundant scans of a microsecond each instead of one scan
+// behind a ticket, a fence and a launch boundary (round 3: k_med_hist was 17 us of which the ticket -> acquire -> 2050 loads -> scan
+// -> publish -> reset tail of its last workgroup was 6) -- while the first row of the field is already on its way.  Workgroup
+// (0, 0) also publishes the bracket for the finisher (pred[8..11]).  k_med_final resets the histogram.
+__global__ void __launch_bounds__(QD_BLOCK)
+k_med_scan_bracket(QdGeom G, const double* __restrict__ x, int transform, double tparam, double* pred, const unsigned int* __restrict__ hist,
+                   unsigned long long* st, double* __restrict__ cand, unsigned int* __restrict__ ccount, unsigned int cap) {
+    __shared__ unsigned int sh[QD_HIST_BINS];
+    __shared__ unsigned long long s_cnt[2];
+    __shared__ unsigned int s_c[2][QD_BLOCK / 64];
+    const int t = threadIdx.x, lane = t & 63;
+    const int nby = (int)gridDim.y, by = (int)blockIdx.y;
+    const bool valid = pred[3] != 0.0;
+    const unsigned long long base = qd_med_window_base(valid, pred[0]);
+    constexpr int PER = QD_HIST_BINS / QD_BLOCK;
+    unsigned int hreg[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) hreg[k] = hist[t + k * QD_BLOCK];
+    unsigned int creg = 0;
+    if (t < 2) creg = hist[QD_HIST_BINS + t];
+    // the first row of this workgroup: in flight during the scan
+    const int i_end = G.row0 + G.nrows;
+    int i = G.row0 + by;
+    double vbuf[8];
+    {
+        const size_t b = (size_t)qd_lrow(G, i < i_end ? i : i_end - 1) * G.nlon;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const int j = q * QD_BLOCK + t; vbuf[q] = x[b + (j < G.nlon ? j : G.nlon - 1)]; }
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) sh[t + k * QD_BLOCK] = hreg[k];
+    if (t < 2) s_cnt[t] = (unsigned long long)creg;
+    __syncthreads();
+    const QdMedBracket B = qd_med_scan(sh, s_cnt, valid, base);
+    if (t == 0 && by == 0 && blockIdx.x == 0) {
+        pred[8] = __longlong_as_double((long long)B.lo_b);
+        pred[9] = __longlong_as_double((long long)B.hi_b);
+        pred[10] = B.none ? 1.0 : 0.0;
+        pred[11] = 1.0;
+    }
+    if (B.none) return;                                       // no positive entry: the finisher finds its counts at zero and writes the default
+    const double lo = __longlong_as_double((long long)B.lo_b), hi = __longlong_as_double((long long)B.hi_b);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    unsigned int n_pos = 0, n_below = 0;
+    for (; i < i_end; i += nby) {
+        for (int jb = 0; jb < G.nlon; jb += 8 * QD_BLOCK) {
+            double cur[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) cur[q] = vbuf[q];
+            // the next batch (the next column block of this row, or the next row) while this one is filtered
+            {
+                const bool more_cols = jb + 8 * QD_BLOCK < G.nlon;
+                const int in = more_cols ? i : i + nby;
+                const int jn = more_cols ? jb + 8 * QD_BLOCK : 0;
+                if (in < i_end) {
+                    const size_t b = (size_t)qd_lrow(G, in) * G.nlon;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { const int j = jn + q * QD_BLOCK + t; vbuf[q] = x[b + (j < G.nlon ? j : G.nlon - 1)]; }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int j0 = jb + q * QD_BLOCK;
+                if (j0 >= G.nlon) break;                                  // wave-uniform
+                const int j = j0 + t;
+                const double v = (j < G.nlon) ? qd_med_value(cur[q], transform, tparam) : 0.0;
+                qd_med_collect(v, lo, hi, lane, lt, n_pos, n_below, cand, ccount, cap);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { n_pos += __shfl_down(n_pos, o, 64); n_below += __shfl_down(n_below, o, 64); }
+    if (lane == 0) { s_c[0][t >> 6] = n_pos; s_c[1][t >> 6] = n_below; }
+    __syncthreads();
+    if (t < 2) {                                              // one global atomic per workgroup and counter
+        unsigned int a = 0;
+        for (int k = 0; k < QD_BLOCK / 64; ++k) a += s_c[t][k];
+        if (a) atomicAdd(&st[t], (unsigned long long)a);
+    }
 }
 
 // value of element k of the select source: the candidate list, or (fallback) the transformed field; non-positive = skip
@@ -590,7 +689,7 @@ template <int NT>
 __device__ __forceinline__ void qd_med_final_body(unsigned long long* st, const double* __restrict__ cand, unsigned int* ccount, double* pred,
                                                   const double* __restrict__ field, unsigned long long n_field, int transform, double tparam,
                                                   double dflt, double* out, unsigned long long* count_out, int world, unsigned int cap,
-                                                  double* miss_flag) {
+                                                  double* miss_flag, unsigned int* hist_reset) {
     // world > 0: latitude bands -- `cand` holds the all-gathered segments; counts are the sums of their headers; when the
     // ranks are not inside the gathered lists (a band overflowed its capacity, or the window missed) nothing is written but
     // *miss_flag = 1 and the host falls back to the digit-by-digit select on every band
@@ -599,7 +698,9 @@ __device__ __forceinline__ void qd_med_final_body(unsigned long long* st, const 
     __shared__ unsigned long long s_prefix, s_rank;
     __shared__ double s_min[NT / 64];
     __shared__ unsigned int s_cnt[NT / 64];
+    __shared__ double s_list[QD_MED_LDS_LIST];                          // the candidate list, when it fits: six passes from LDS, not from L2
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (hist_reset) for (int k = t; k < QD_HIST_BINS + 2; k += NT) hist_reset[k] = 0u;      // whole globe: k_med_scan_bracket has read it
     unsigned long long m, c_lo;
     unsigned int M;
     bool overflow = false;
@@ -640,6 +741,10 @@ __device__ __forceinline__ void qd_med_final_body(unsigned long long* st, const 
         pre0 = bl;
     }
     if (t == 0) { s_prefix = 0ull; s_rank = hit ? (k1 - c_lo) : k1; }
+    if (src == 0 && N <= (size_t)QD_MED_LDS_LIST) {
+        for (size_t k = t; k < N; k += NT) s_list[k] = cand[k];
+        cand = s_list;
+    }
     __syncthreads();
     const int shifts[6] = {53, 42, 31, 20, 10, 0};
     const int widths[6] = {11, 11, 11, 11, 10, 10};
@@ -721,79 +826,9 @@ __device__ __forceinline__ void qd_med_final_body(unsigned long long* st, const 
 __global__ void __launch_bounds__(QD_FIN_BLOCK)
 k_med_final(unsigned long long* st, const double* __restrict__ cand, unsigned int* ccount, double* pred,
             const double* __restrict__ field, unsigned long long n_field, int transform, double tparam, double dflt, double* out,
-            unsigned long long* count_out, int world, unsigned int cap, double* miss_flag) {
-    qd_med_final_body<QD_FIN_BLOCK>(st, cand, ccount, pred, field, n_field, transform, tparam, dflt, out, count_out, world, cap, miss_flag);
-}
-
-// ------------------------------------------------------------------ the windowed median in ONE launch (whole-globe handles)
-// k_med_hist -> k_med_bracket -> k_med_final are three launches of ~17 + 13 + 11 us, each mostly a chain of dependent round trips
-// (flush, ticket, fence, scan) plus its own ramp and boundary; three medians per step were 12 % of the step.  Here the same three
-// bodies run inside one launch of QD_MED_ONE_BLOCKS co-resident workgroups: everybody histograms, the last one scans and publishes
-// the bracket and then RELEASES a generation flag; everybody else waits on that flag (one lane polls, relaxed load + s_sleep,
-// then an agent acquire), collects its candidates, and the last one to finish that selects the ranks from the list.
-// Co-residency: 256 workgroups of 256 threads and 9 KB of LDS fit any gfx950 several times over, and the launch is alone on the device
-// (whole-globe handles run one stream; the in-process band groups never take this path).  The wait is bounded all the same: a
-// workgroup that does not see the flag after QD_MED_SPIN polls writes NaN to the result, raises *err and leaves.
-// MEASURED (rocprofv3 kernel trace, 721 x 1440): 39.6 us per median -- the same as the three launches.  What a median costs is the
-// chain of dependent round trips (LDS histogram -> flush atomics -> ticket -> acquire -> 2050 atomic loads -> scan -> release ->
-// flag -> acquire -> collect -> release -> ticket -> acquire -> six select passes), ~2 us each, not the launch boundaries.  Kept
-// behind QD_MEDIAN_ONE=1 (tests/test_gpu_parity.py runs both forms); the three-launch form stays the default.
-#define QD_MED_ONE_BLOCKS 256
-#define QD_MED_SPIN 400000
-__global__ void __launch_bounds__(QD_BLOCK)
-k_med_one(QdGeom G, const double* __restrict__ x, int transform, double tparam, double* pred, unsigned long long* st, unsigned int* hist,
-          double* __restrict__ cand, unsigned int* ccount, unsigned int cap, unsigned long long gen, unsigned long long n_field,
-          double dflt, double* out, unsigned long long* count_out, unsigned int* err) {
-    __shared__ int s_flag;
-    const int t = threadIdx.x;
-    const int nby = (int)gridDim.y, by = (int)blockIdx.y;
-    // ---- phase 1: windowed histogram; the last workgroup publishes pred[8..11]
-    const bool scanned = qd_med_hist_body(G, x, transform, tparam, pred, st, hist, 0, 1, nby, 0, by);
-    if (scanned) {                                           // (uniform per workgroup)
-        __syncthreads();                                     // thread 0's bracket stores and everybody's histogram resets are issued
-        if (t == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(&st[7], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    // ---- wait for the bracket
-    if (t == 0) {
-        int ok = 0;
-        for (int it = 0; it < QD_MED_SPIN; ++it) {
-            if (__hip_atomic_load(&st[7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) { ok = 1; break; }
-            __builtin_amdgcn_s_sleep(4);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        s_flag = ok;
-    }
-    __syncthreads();
-    if (!s_flag) {                                           // never seen on a healthy device: say so loudly instead of hanging
-        if (t == 0) { atomicExch(err, 1u); *out = __longlong_as_double(0x7FF8000000000000ll); }
-        return;
-    }
-    const double lo = __hip_atomic_load(&pred[8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const double hi = __hip_atomic_load(&pred[9], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool none = __hip_atomic_load(&pred[10], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0;     // no positive entry at all
-    const bool okb = __hip_atomic_load(&pred[11], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0;
-    // ---- phase 2: candidates of the bracket + recount
-    if (!none) qd_med_bracket_body(G, x, transform, tparam, okb ? lo : 0.0, okb ? hi : -1.0, st, cand, ccount, cap, 1, nby, 0, by);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this workgroup's counter adds and list stores are complete
-    __syncthreads();
-    if (t == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the candidate list is plain stores: publish them before the ticket
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long ticket = atomicAdd(&st[5], 1ull);
-        s_flag = (ticket == (unsigned long long)nby - 1ull) ? 1 : 0;
-    }
-    __syncthreads();
-    if (!s_flag) return;
-    // ---- the last workgroup: select the ranks from the list
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (t == 0) __hip_atomic_store(&st[5], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    qd_med_final_body<QD_BLOCK>(st, cand, ccount, pred, x, n_field, transform, tparam, dflt, out, count_out, 0, 0u, (double*)nullptr);
+            unsigned long long* count_out, int world, unsigned int cap, double* miss_flag, unsigned int* hist_reset) {
+    qd_med_final_body<QD_FIN_BLOCK>(st, cand, ccount, pred, field, n_field, transform, tparam, dflt, out, count_out, world, cap, miss_flag,
+                                    hist_reset);
 }
 
 // result + reset of the select state for the next call; `count_out` (optional) keeps the count
@@ -822,20 +857,13 @@ int qd_median_positive_dev(qd_ctx* c, const double* x, double dflt, int slot, in
     if (c->geo.full && c->sel_cand && c->med_pred && c->med_predict && site >= 0 && site < QD_MED_SITES) {
         // windowed histogram around the site's last median, one collecting pass, one finishing workgroup
         double* pred = c->med_pred + 16 * site;
-        if (c->med_seen[site] && c->med_one) {
-            const dim3 g1(1, std::min(G.nrows, QD_MED_ONE_BLOCKS));
-            hipLaunchKernelGGL(k_med_one, g1, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, pred, c->sel_state, c->hist, c->sel_cand,
-                               c->sel_ccount, (unsigned int)c->geo.cells(), ++c->med_gen, (unsigned long long)c->geo.cells(), dflt,
-                               c->dscal + slot, c->dcount, c->med_err);
-            return 0;
-        }
         if (c->med_seen[site]) {
-            hipLaunchKernelGGL(k_med_hist, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, pred, c->sel_state, c->hist, 0);
-            hipLaunchKernelGGL(k_med_bracket, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, pred + 8, c->sel_state,
+            hipLaunchKernelGGL(k_med_hist, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, pred, c->hist, 1);
+            hipLaunchKernelGGL(k_med_scan_bracket, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, pred, c->hist, c->sel_state,
                                c->sel_cand, c->sel_ccount, (unsigned int)c->geo.cells());
             hipLaunchKernelGGL(k_med_final, dim3(1), dim3(QD_FIN_BLOCK), 0, c->stream, c->sel_state, c->sel_cand, c->sel_ccount, pred, x,
                                (unsigned long long)c->geo.cells(), transform, tparam, dflt, c->dscal + slot, c->dcount, 0, 0u,
-                               (double*)nullptr);
+                               (double*)nullptr, c->hist);
             return 0;
         }
         c->med_seen[site] = 1;                                // first use: the digit-by-digit select below, then seed the window
@@ -870,9 +898,9 @@ int qd_median_positive_dev(qd_ctx* c, const double* x, double dflt, int slot, in
         const int world = c->desc.world, rank = c->desc.rank;
         const unsigned int cap = QD_MED_BAND_CAP;
         const size_t segd = (size_t)cap + 4u;
-        hipLaunchKernelGGL(k_med_hist, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, bpred, c->sel_state, c->hist, 1);
+        hipLaunchKernelGGL(k_med_hist, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, bpred, c->hist, 1);
         if (qd_allreduce_u32(c, c->hist, QD_HIST_BINS + 2)) return -1;
-        hipLaunchKernelGGL(k_med_hist, dim3(1, 1), dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, bpred, c->sel_state, c->hist, 2);
+        hipLaunchKernelGGL(k_med_hist, dim3(1, 1), dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, bpred, c->hist, 2);
         QD_HIP(c, hipMemsetAsync(c->med_gather, 0, (size_t)world * segd * sizeof(double), c->stream));
         double* seg = c->med_gather + (size_t)rank * segd;
         hipLaunchKernelGGL(k_med_bracket, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, bpred + 8, c->sel_state,
@@ -880,7 +908,7 @@ int qd_median_positive_dev(qd_ctx* c, const double* x, double dflt, int slot, in
         hipLaunchKernelGGL(k_med_pack, dim3(1), dim3(64), 0, c->stream, c->sel_state, c->sel_ccount, seg);
         if (qd_allreduce_u32(c, (unsigned int*)c->med_gather, (int)(2 * world * segd))) return -1;     // x + 0 + ... + 0: exact
         hipLaunchKernelGGL(k_med_final, dim3(1), dim3(QD_FIN_BLOCK), 0, c->stream, c->sel_state, c->med_gather, c->sel_ccount, bpred, x,
-                           0ull, transform, tparam, dflt, c->dscal + slot, c->dcount, world, cap, c->dscal + QD_S_TMP1);
+                           0ull, transform, tparam, dflt, c->dscal + slot, c->dcount, world, cap, c->dscal + QD_S_TMP1, (unsigned int*)nullptr);
         QD_HIP(c, hipMemcpyAsync(c->hpin + 32, c->dscal + QD_S_TMP1, sizeof(double), hipMemcpyDeviceToHost, c->stream));
         QD_HIP(c, hipStreamSynchronize(c->stream));
         if (c->hpin[32] == 0.0) return 0;

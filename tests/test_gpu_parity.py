@@ -205,9 +205,10 @@ def test_median_exact(gpu):
 
 
 def test_median_predicted_bracket(gpu, monkeypatch):
-    """The predicted-bracket select (qd_reduce.hip: k_med_bracket + k_med_final): a slowly drifting field keeps the median inside
-    the bracket kept from the previous call (fast path), jumps / empty fields / ties force the in-kernel fallback; every result
-    is numpy's median bit for bit, and equals the histogram-pass select (QD_MEDIAN_PREDICT=0)."""
+    """The windowed-histogram select (qd_reduce.hip: k_med_hist + k_med_scan_bracket + k_med_final): a drifting field keeps the
+    median inside the window centred on the previous call's result (fast path; candidate lists of a few hundred values selected from
+    LDS, the all-equal field's 38 000 from the global list), jumps / empty fields / ties force the in-kernel fallback; every result is
+    numpy's median bit for bit, and equals the histogram-pass select (QD_MEDIAN_PREDICT=0)."""
     import qingdai_amd as qa
     from qingdai_amd.device import Device
     r = np.random.default_rng(17)
@@ -236,12 +237,10 @@ def test_median_predicted_bracket(gpu, monkeypatch):
     for k, (g, x) in enumerate(zip(got, seq)):
         assert g == want(x), (k, g, want(x))
     p = qa.QdParams(); p.has_csmap = 0
-    monkeypatch.setenv("QD_MEDIAN_ONE", "1")                         # the same three bodies inside one launch (k_med_one)
-    dev1 = Device(qa.SphericalGrid(181, 300), p)
-    assert [dev1.op_median_positive(x, 1e-6) for x in seq] == got
-    dev1.sync()                                                      # (qd_sync reports a workgroup that gave up waiting)
-    dev1.close()
-    monkeypatch.delenv("QD_MEDIAN_ONE")
+    import ctypes
+    st = (ctypes.c_double * 64)()
+    assert dev.lib.qd_median_state(dev.h, st) == 0                   # site 0 = the operator seam
+    assert st[4] >= 14, (st[4], st[5])        # served from the candidate list (a jump out of the window lists the side it went to)
     monkeypatch.setenv("QD_MEDIAN_PREDICT", "0")
     dev0 = Device(qa.SphericalGrid(181, 300), p)
     assert [dev0.op_median_positive(x, 1e-6) for x in seq] == got
