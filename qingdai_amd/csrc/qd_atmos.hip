@@ -84,7 +84,7 @@ k_column(QdGeom G, QdColP P, QdColPtrs A) {
             const double RH = qd_clip(q / qd_max(1e-12, qsat_air), 0.0, 1.5);
             const double rh_excess = qd_max(0.0, RH - P.rh0);
             const double P_ref = *A.pref;
-            const double p_term = tanh(P_ref > 0 ? Pc / P_ref : 0.0);
+            const double p_term = qd_tanh(P_ref > 0 ? Pc / P_ref : 0.0);
             cloud_eff = qd_clip(cloud + P.k_q * rh_excess + P.k_p * p_term, 0.0, 1.0);
         } else cloud_eff = cloud;
         A.cloud_eff[o] = cloud_eff;

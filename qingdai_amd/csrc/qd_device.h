@@ -2,6 +2,7 @@
 // Expression order follows the reference line by line (citations in qd_stencil.hip).
 #pragma once
 #include "qd_internal.h"
+#include "qd_math.h"
 
 // ------------------------------------------------------------------ Laplacian (O1)
 template <bool SCRUB>

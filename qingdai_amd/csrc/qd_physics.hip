@@ -131,7 +131,7 @@ k_cloud_from_p(QdGeom G, const double* __restrict__ precip, const double* __rest
     const int j = tl.seg * QD_BLOCK + threadIdx.x;
     if (j >= G.nlon) return;
     const size_t o = (size_t)qd_lrow(G, G.row0 + tl.row) * G.nlon + j;
-    out[o] = cmax * tanh(precip[o] / (*pref + 1e-12));
+    out[o] = cmax * qd_tanh(precip[o] / (*pref + 1e-12));
 }
 
 
@@ -140,7 +140,7 @@ k_cloud_from_p(QdGeom G, const double* __restrict__ precip, const double* __rest
 // f64 tanh altogether.  Same result bit for bit: for x > 0 the same tanh is evaluated.
 __device__ __forceinline__ double qd_tanh01(double x) {
     double t = 0.0;
-    if (x > 0.0) t = tanh(x);
+    if (x > 0.0) t = qd_tanh_nonneg(x);
     return qd_clip(t, 0.0, 1.0);
 }
 
@@ -168,7 +168,7 @@ k_cloud_fromp_source(QdGeom G, QdTabs T, const double* __restrict__ precip, cons
     if (j >= G.nlon) return;
     const int i = G.row0 + tl.row;
     const size_t o = (size_t)qd_lrow(G, i) * G.nlon + j;
-    cfp[o] = cmax * tanh(precip[o] / (*pref + 1e-12));
+    cfp[o] = cmax * qd_tanh(precip[o] / (*pref + 1e-12));
     src[o] = qd_cloud_source_cell(G, T, u, v, Ts, a, dlat, dlon, i, j);
 }
 
