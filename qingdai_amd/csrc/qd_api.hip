@@ -309,6 +309,7 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
         hipMemsetAsync(c->med_pred, 0, 64 * sizeof(double), c->stream);
         { const char* ef = std::getenv("QD_MEDIAN_PREDICT"); if (ef && ef[0] == '0') c->med_predict = 0; }
         { const char* ef = std::getenv("QD_MERGE_POINTWISE"); if (ef) c->merge_pointwise = ef[0] == '0' ? 0 : 1; }
+        { const char* ef = std::getenv("QD_HOIST_PRECIP"); if (ef) c->hoist_precip = ef[0] == '0' ? 0 : 1; }
     }
     if ((e = hipHostMalloc((void**)&c->hpin, 64 * sizeof(double))) != hipSuccess) return bail("hipHostMalloc", e);
     if ((e = hipHostMalloc((void**)&c->hpin_rows, (size_t)3 * c->geo.lrows() * sizeof(double))) != hipSuccess) return bail("hipHostMalloc", e);
@@ -541,14 +542,23 @@ extern "C" int qd_step_n(qd_handle c, int n, double dt, int flags, const double*
         // whole-globe handles: the forcing rides on the last launch of the driver physics (k_snow_albedo_forcing)
         const bool merged = with_phys && c->geo.full && c->merge_pointwise;
         const QdForcingCall fc{st, st + 3, st[6]};
-        if (with_phys) { if ((rc = qd_driver_physics_impl(c, dt, merged ? &fc : nullptr))) return rc; }
+        if (with_phys) {
+            const int part = c->precip_done ? 2 : 0;         // the precipitation block may have run inside the previous ocean step
+            c->precip_done = 0;
+            if ((rc = qd_driver_physics_impl(c, dt, merged ? &fc : nullptr, part))) return rc;
+        }
         else if ((rc = qd_simple_albedo_impl(c, 0.08))) return rc;
         if (!merged && (rc = qd_forcing_impl(c, st, st + 3, st[6], 1))) return rc;
         if ((rc = qd_atmos_step_impl(c, dt, pass_alb ? 1 : 0))) return rc;
         // bit4: energy-budget means of the FIRST step, taken where the reference driver takes them -- after time_step, on the
         // fluxes of the coupling block (run_simulation.py:2199-2246) -- and kept for qd_energy_diagnostics_last
         if (with_ocean && want_diag && s == 0 && (rc = qd_energy_diag_impl(c, c->last_diag))) return rc;
-        if (with_ocean && (rc = qd_ocean_step_impl(c, dt, 1, 1, 1))) return rc;
+        // The precipitation block of step s + 1 (run_simulation.py:1740-1790) reads u, v and P_cond as time_step left them and
+        // nothing the ocean step, the tracers, the individuals or the bucket touch, and writes only what the rest of step s + 1's
+        // driver physics reads: it is queued inside the ocean step, between the stress kernel and the host's wait for the CFL maxima.
+        if (with_ocean && with_phys && c->geo.full && c->hoist_precip && s + 1 < n)
+            c->before_cfl_wait = [c, dt]() { const int r = qd_driver_physics_impl(c, dt, nullptr, 1); if (!r) c->precip_done = 1; return r; };
+        if (with_ocean) { rc = qd_ocean_step_impl(c, dt, 1, 1, 1); c->before_cfl_wait = nullptr; if (rc) return rc; }
         if (with_phyto && (rc = qd_phyto_step_impl(c, dt))) return rc;      // run_simulation.py:2254-2258
         // IndividualPool.try_substep reads this step's isr_A / isr_B and W_land before the bucket update (run_simulation.py:2021-2046)
         if (with_eco && c->eco.n_indiv > 0 && (rc = qd_indiv_substep_impl(c, dt, nullptr))) return rc;

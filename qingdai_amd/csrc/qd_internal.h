@@ -12,6 +12,7 @@
 #include <stdint.h>
 #include <string>
 #include <vector>
+#include <functional>
 #include <map>
 #include <unordered_map>
 #include <initializer_list>
@@ -195,6 +196,9 @@ struct qd_ctx {
     int group_sums = 1;              // QD_GROUP_SUMS=0: issue every eta sum as its own collective
     long grouped_sums = 0;           // deferred sums that went out inside a halo exchange's group
     int band_tail = 1;               // QD_BAND_TAIL=0: latitude bands keep the round-2 sub-step (k_cont_sstadv + k_eta_mean + k_sst_outlier_fused)
+    int hoist_precip = 1;            // QD_HOIST_PRECIP=0: qd_step_n keeps the next step's precipitation block behind the ocean step
+    int precip_done = 0;             // the precipitation block of the next driver-physics call has already run (qd_step_n)
+    std::function<int()> before_cfl_wait;   // whole-globe ocean step: queued after the stress kernel, before the host waits for the CFL maxima
     int merge_pointwise = 1;         // QD_MERGE_POINTWISE=0: every pointwise stage of qd_step_n as a launch of its own
     double* med_gather = nullptr;    // band handles: [world][4 + 4092] gathered candidate segments of the windowed median
     double* hpin = nullptr;        // pinned host scalars
@@ -359,7 +363,8 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
 // qd_physics.hip
 // fc != nullptr (whole-globe handles): the forcing of the same step (stars, rotation angle) rides on the last launch of the physics
 struct QdForcingCall { const double* sa; const double* sb; double theta; };
-int qd_driver_physics_impl(qd_ctx* c, double dt, const QdForcingCall* fc = nullptr);
+// part 0: everything; 1: only the precipitation block (divergence median, P_raw, the two blurs, the blend); 2: everything after it
+int qd_driver_physics_impl(qd_ctx* c, double dt, const QdForcingCall* fc = nullptr, int part = 0);
 int qd_hydrology_commit_impl(qd_ctx* c, double dt);
 
 // qd_api.hip

@@ -725,6 +725,13 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
                                c->hpin_rows + (size_t)2 * G0.lrows(), c->eta_seq);
             qd_mark(c, {taux, tauy}, m);
             if (compute_qnet && launch_qnet()) return -1;
+            // qd_step_n: work of the NEXT step that depends on neither the ocean nor the sub-step count (the precipitation block:
+            // ~65 us of launches) goes in here, so the device has something to do while the host waits (the gap was 24 us a step)
+            if (c->before_cfl_wait) {
+                std::function<int()> fn = std::move(c->before_cfl_wait);
+                c->before_cfl_wait = nullptr;
+                if (fn()) return -1;
+            }
             for (int k = 0; k < G.nrows; ++k)
                 if (qd_wait_host_flag(c, c->hpin_rows + (size_t)2 * G0.lrows() + k, c->eta_seq, "ocean step: the CFL maxima never arrived")) return -1;
             for (int k = 0; k < G.nrows; ++k) { maxVa = std::max(maxVa, c->hpin_rows[k]); maxUo = std::max(maxUo, c->hpin_rows[G.nrows + k]); }

@@ -345,7 +345,7 @@ int qd_hydrology_commit_impl(qd_ctx* c, double dt) {
     return 0;
 }
 
-int qd_driver_physics_impl(qd_ctx* c, double dt, const QdForcingCall* fc) {
+int qd_driver_physics_impl(qd_ctx* c, double dt, const QdForcingCall* fc, int part) {
     const qd_params& p = c->p;
     const QdGeom& G0 = c->geo;
     const dim3 blk(QD_BLOCK);
@@ -359,7 +359,7 @@ int qd_driver_physics_impl(qd_ctx* c, double dt, const QdForcingCall* fc) {
     double*& pdyn = c->scratch[7];
     const int R1 = qd_gauss_radius(1.0);
     const int Rc = qd_adv_reach(c, dt, 250.0);
-    {
+    if (part != 2) {
         QdScope sc(c, "phys_precip");
         // median of pos = max(0, -(div - D_crit)) over pos > 0, straight from the divergence field
         int m = qd_plan(c, {QD_IN(F[QD_F_U], 1), QD_IN(F[QD_F_V], 1), QD_IN(F[QD_F_PCOND], 0)});
@@ -441,6 +441,7 @@ int qd_driver_physics_impl(qd_ctx* c, double dt, const QdForcingCall* fc) {
         qd_mark(c, {F[QD_F_PRECIP]}, mg);
         }
     }
+    if (part == 1) return 0;
     {
         QdScope sc(c, "phys_cloud");
         if (isset(p.pref) && p.pref != 0.0) {

@@ -518,3 +518,29 @@ def test_driver_loop_vs_oracle(gpu, use_ocean):
     # steps at 1e-7; everything else at the usual bound.
     for k, e in errs.items():
         assert e < (1e-7 if k in ("uo", "eta") else STEP_TOL), (k, e)
+
+
+def test_step_n_precipitation_block_inside_the_ocean_step_changes_nothing(gpu, monkeypatch):
+    """qd_step_n queues the NEXT step's precipitation block (divergence median, P_raw, blurs, blend) inside the ocean step, between
+    the stress kernel and the host's wait for the CFL maxima (the device idled there).  Same kernels on the same inputs in another
+    place of the stream: every field must come out bit for bit as with QD_HOIST_PRECIP=0, over spans of several steps (the block
+    is only moved when a next step exists) and with the hydrology and tracer hooks in between."""
+    from qingdai_amd.driver import Simulation
+    import qingdai_amd as qa
+
+    def run(hoist):
+        monkeypatch.setenv("QD_HOIST_PRECIP", hoist)
+        sim = Simulation(91, 180, params=qa.QdParams(), use_ocean=True, quiet=True, ecology=False)
+        lat = np.deg2rad(sim.grid.lat_mesh)
+        sim.gcm.h = 8000.0 - 9000.0 * np.sin(lat) ** 2
+        sim.gcm.T_s = 262.0 + 36.0 * np.cos(lat) ** 2
+        sim.run_steps(5)
+        sim.run_steps(1)
+        sim.run_steps(3)
+        out = {k: np.array(sim.dev.get(k)) for k in ("U", "V", "H", "TS", "Q", "CLOUD", "PRECIP", "ALBEDO", "S_SNOW", "W_LAND", "RUNOFF",
+                                                     "UO", "VO", "ETA", "SST", "HICE")}
+        sim.dev.close()
+        return out
+    a, b = run("1"), run("0")
+    for k in a:
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
