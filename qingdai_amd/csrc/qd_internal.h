@@ -196,6 +196,8 @@ struct qd_ctx {
     int group_sums = 1;              // QD_GROUP_SUMS=0: issue every eta sum as its own collective
     long grouped_sums = 0;           // deferred sums that went out inside a halo exchange's group
     int band_tail = 1;               // QD_BAND_TAIL=0: latitude bands keep the round-2 sub-step (k_cont_sstadv + k_eta_mean + k_sst_outlier_fused)
+    double* qt_tab = nullptr;        // packed row table of k_ocn_tail_fast (built at its first launch for qt_tab_a = params.a)
+    double qt_tab_a = 0.0;
     int hoist_precip = 1;            // QD_HOIST_PRECIP=0: qd_step_n keeps the next step's precipitation block behind the ocean step
     int precip_done = 0;             // the precipitation block of the next driver-physics call has already run (qd_step_n)
     std::function<int()> before_cfl_wait;   // whole-globe ocean step: queued after the stress kernel, before the host waits for the CFL maxima

@@ -831,7 +831,7 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
             A.r_a = 1.0 / p.a; A.r_dlon = 1.0 / c->dlon; A.r_dlat = 1.0 / c->dlat; A.r_2dlon = 1.0 / (2 * c->dlon); A.r_2dlat = 1.0 / (2 * c->dlat);
             A.r_rcH = 1.0 / HP.rcH;
             A.acc = tail_acc ? c->eta_acc : nullptr; A.mean_out = c->dscal + QD_S_ETA_MEAN; A.wsum = c->wsum_ocean;
-            A.ntc = 0; A.R = 0; A.pad_ = 0;
+            A.ntc = 0; A.R = 0; A.Rp = 0; A.nmid = 0; A.flags = 0;
             if (qd_launch_ocn_step(c, O, A)) return -1;
             if (!tail_acc)
                 hipLaunchKernelGGL(k_eta_mean_tail, dim3(1), dim3(256), 0, c->stream, c->red_partial, qd_ocn_step_tiles(c), c->wsum_ocean,

@@ -6,12 +6,14 @@ struct QdTailArgs {
     const double *uo, *vo, *Ts, *qnet;
     const uint8_t *land, *ice;
     double *eta, *Ts_out, *uo_out, *vo_out, *partial;
+    const double* tab;                                       // k_ocn_tail_fast: packed per-row coefficients [n_lat][16] (qd_ocntail.hip, k_tail_tab)
     unsigned long long* acc;                                 // fixed-point accumulator + tickets of the strip sums (qd_wave.h), or nullptr
     double* mean_out;                                        // acc != nullptr: the last workgroup writes sum / (wsum + 1e-15) here
     double wsum;
     double a, dlat, dlon, sub_dt, msdtH, alpha, K_h, rcH, ice_qfac, cap;
     double r_a, r_dlon, r_dlat, r_2dlon, r_2dlat, r_rcH;     // correctly rounded reciprocals of a, dlon, dlat, 2 dlon, 2 dlat, rcH (host)
-    int use_q, has_ice, mean4, ntc, R, pad_;                 // R: strip height of the streaming form
+    int use_q, has_ice, mean4, ntc, R, Rp;                   // R: strip height of the streaming forms; Rp: height of a pole strip (k_ocn_tail_fast)
+    int nmid, flags;                                         // k_ocn_tail_fast: strips between the pole strips; bit0 = every wave takes the general form
     int own0, own1;                                          // rows whose eta enters the area-weighted sum (a band's owned rows; set by the launcher for whole-globe handles)
 };
 

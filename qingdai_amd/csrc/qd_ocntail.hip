@@ -37,6 +37,14 @@ __device__ __forceinline__ double qt_div(double x, double c, double rc) {
     return (q0 - q0 == 0.0) ? q1 : q0;                      // non-finite quotient: the correction would turn inf into NaN
 }
 
+// qt_div without the guard: a non-finite quotient comes out as NaN instead of +-inf.  For the fast SST wave's departure point, where
+// either sends the lane to the general form (|dx| < 1 fails for both).
+__device__ __forceinline__ double qt_div_fin(double x, double c, double rc) {
+    const double q0 = x * rc;
+    const double e = __builtin_fma(-c, q0, x);
+    return __builtin_fma(e, rc, q0);
+}
+
 // qd_departure (qd_device.h) with the four divisions by row / grid constants taken through qt_div
 __device__ __forceinline__ QdBilin qt_departure(const QdGeom& G, int gi, int j, double u, double v, double dt,
                                                 double acos, double r_acos, const QdTailArgs& P) {
@@ -219,6 +227,7 @@ k_ocn_tail(QdGeom G, QdTabs T, QdTailArgs P) {
 // Same device expressions as k_ocn_tail above (qt_div, qt_departure's arithmetic, the row-table Laplacian): the two forms agree to
 // the rounding of the eta sum.
 #define QS_TC2 62
+#define QS_TCF 60                 // k_ocn_tail_fast: lanes 2 .. 61 own a column (1 and 62: T1 for the Laplacian; 0 and 63: SST for their gather)
 
 typedef unsigned int qt_u32x2 __attribute__((ext_vector_type(2)));
 typedef __amdgpu_buffer_rsrc_t qt_rsrc;
@@ -227,7 +236,7 @@ __device__ __forceinline__ double qt_ld(qt_rsrc r, unsigned row_elems, unsigned 
 __device__ __forceinline__ void qt_st(qt_rsrc r, unsigned row_elems, unsigned vo, double v) { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(qt_u32x2, v), r, vo, row_elems * 8u, 0); }
 __device__ __forceinline__ int qt_ld8(qt_rsrc r, unsigned row_elems, unsigned vo8) { return (int)__builtin_amdgcn_raw_buffer_load_b8(r, vo8, row_elems, 0); }
 
-struct QtW { int n, m, lane, j, o0, o1; unsigned vo, vs, vo8, slab; bool own; int lbase, lrows, own0, own1; };      // lbase / lrows: the slab (band handles); own0 / own1: rows whose eta enters the sum
+struct QtW { int n, m, lane, j, o0, o1; unsigned vo, vs, vo8, slab; bool own; int lbase, lrows, own0, own1, jbase; };      // lbase / lrows: the slab (band handles); own0 / own1: rows whose eta enters the sum
 
 // element offset of global row g, clamped into the domain and into the slab (whole-globe handles: local row = global row; band
 // handles: local row = g - lbase with the period-n wrap of their ring halo)
@@ -446,6 +455,308 @@ k_ocn_tail_stream(QdGeom G, QdTabs T, QdTailArgs P) {
         if (__builtin_amdgcn_ballot_w64(last) != 0ull) {
             const double m = qd_acc_finish(P.acc, P.partial, (int)gridDim.x, P.wsum);
             if (W.lane == 0) *P.mean_out = m;
+        }
+    }
+}
+
+// ---- the streaming form again, slimmed for the rows where nothing special happens (round 3b) -------------------------------------
+// What the counters said about k_ocn_tail_stream (profiles/README.md, round 3b): its waves keep the SIMDs issuing ~70 % of the
+// time (176 VALU + 141 SALU instructions per SST row: row clamps, pole branches, 64-bit gather addresses, spilled SGPRs coming back
+// through v_readlane) AND every row of either wave waits a full memory round trip -- the currents wave loads row g+1 while it
+// works on row g, the SST wave cannot issue a gather before the currents it departs with have arrived.  k_ocn_tail_fast:
+//   * the rows are cut into a short strip at each pole (Rp rows: the forms above, with their clamps, folds and pole stencils) and
+//     even strips in between, whose waves never see a pole: plain row offsets, the interior Laplacian, no np.roll rows;
+//   * every load is issued TWO row steps before its use into one of two fixed register slots, refilled at the end of the step
+//     that consumed it (qd_stream.h has the reasons for the slots, the scheduling barrier and qs_own);
+//   * the SST wave's gather does not go to memory: a sub-step moves water by ~0.003 of a cell (3 m/s x 23 s against 28 km), so the
+//     four corners of the bilinear gather are among the nine cells around (g, j) -- rows g-1, g, g+1, which the stream holds in
+//     registers, columns by DPP lane shifts.  Same arithmetic on the same operands in the same order (the corner values are
+//     selected, the weights computed as qt_departure computes them; of scipy's fold only "+- (n_lon - 1)" can happen, the clamps
+//     are identities), so the result is the memory gather's bit for bit.  Waves that hold column 0 or n_lon - 1 (period
+//     n_lon - 1: the fold lands two lanes away, the clamp c1 = c0 on the lane itself) pick the corners by ds_bpermute.
+//   * a lane whose departure point is a cell or more away, or NaN, raises a flag; the wave finishes its strip (garbage in, garbage
+//     out) and then runs the general form over the same strip, which overwrites everything it stored.
+struct QtPart { int ps, pn, nmid, mid0, mid1; };
+__host__ __device__ inline QtPart qt_partition(int lo, int hi, int n, int R, int Rp) {
+    QtPart q;
+    const int rows = hi - lo;
+    q.ps = lo == 0 ? (Rp < rows ? Rp : rows) : 0;
+    q.pn = hi == n ? (Rp < rows - q.ps ? Rp : rows - q.ps) : 0;
+    q.mid0 = lo + q.ps; q.mid1 = hi - q.pn;
+    q.nmid = (q.mid1 - q.mid0 + R - 1) / R;
+    return q;
+}
+__host__ __device__ inline int qt_part_strips(const QtPart& q) { return (q.ps > 0) + q.nmid + (q.pn > 0); }
+
+// Per-row coefficients of the two fast waves, packed so that a row step needs ONE row of ONE table, fetched by vector loads with a
+// wave-uniform address (every lane gets the same 16 bytes) in the same two-steps-ahead slots as the fields.  As scalar loads from
+// eight tables they were five or six exposed s_waitcnt lgkmcnt(0) a step (SMEM returns out of order: any use waits for all) and
+// ten SGPRs of table pointers in kernels that spill SGPRs by the hundred.
+//   [0] a cos05[g]   [1] 1/(a cos05[g])   [2] lapA[g-1]   [3] lapA[g-3]   [4] lapP[g-2]   [5] lapQ[g-2]      (SST wave, T1 row g / output row g-2)
+//   [8] cos[g+1]     [9] cos[g-1]         [10] 1/(a cos6[g])   [11] max(cos[g], 0)                            (currents wave, row g)
+__global__ void k_tail_tab(QdTabs T, int n, double a, double* __restrict__ tab) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    auto cl = [n](int r) { return r < 0 ? 0 : (r > n - 1 ? n - 1 : r); };
+    double* o = tab + (size_t)g * 16;
+    o[0] = a * T.cos05[g]; o[1] = T.ocn_igx[g]; o[2] = T.lapA[1][cl(g - 1)]; o[3] = T.lapA[1][cl(g - 3)];
+    o[4] = T.lapP[1][cl(g - 2)]; o[5] = T.lapQ[1][cl(g - 2)]; o[6] = 0.0; o[7] = 0.0;
+    o[8] = T.cos_raw[cl(g + 1)]; o[9] = T.cos_raw[cl(g - 1)]; o[10] = T.inv_acos6[g]; o[11] = T.warea[g];
+    o[12] = 0.0; o[13] = 0.0; o[14] = 0.0; o[15] = 0.0;
+}
+typedef unsigned int qt_u32x4 __attribute__((ext_vector_type(4)));
+typedef double qt_f64x2 __attribute__((ext_vector_type(2)));
+// two doubles of table row `row16` (element offset of the row = 16 g), the same for every lane
+__device__ __forceinline__ qt_f64x2 qt_ldk(qt_rsrc K, unsigned row16, unsigned pair) {
+    return __builtin_bit_cast(qt_f64x2, __builtin_amdgcn_raw_buffer_load_b128(K, 0u, row16 * 8u + pair * 16u, 0));
+}
+
+// a wave-uniform constant parked in VGPRs: left to itself the compiler keeps such values as kernarg state and, out of SGPRs,
+// re-loads the argument block inside the row loop (56 dwords of s_load per step, each an exposed lgkmcnt(0)) or spills them to
+// lanes of a VGPR (v_readlane per use); VGPRs are not scarce in these kernels
+__device__ __forceinline__ double qt_vreg(double x) {
+    double y;
+    asm("v_mov_b64 %0, %1" : "=v"(y) : "s"(x));
+    return y;
+}
+
+struct QtCurSlot { double u, v, e; int l; qt_f64x2 k0, k1; };
+struct QtCurK { double dlon2, r_2dlon, dlat2, r_2dlat, msdtH, cap, cap81; int mean4; };
+
+// one row of the continuity + caps wave away from the poles; `ro`: element offset of row g in the slab
+__device__ __forceinline__ void qt_cur_fast_step(const QtCurK& P, const QtW& W, qt_rsrc U, qt_rsrc V, qt_rsrc E, qt_rsrc L,
+                                                 qt_rsrc UO, qt_rsrc VO, qt_rsrc KT, double& us, double& uc, double& vs, double& vc, double& acc,
+                                                 QtCurSlot& sl, int g, unsigned ro) {
+    const double un = qs_own(sl.u), vn = qs_own(sl.v), e0 = sl.e;
+    const bool island = sl.l == 1;
+    const double ue = qd_east(uc), uw = qd_west(uc), ve = qd_east(vc), vw = qd_west(vc);
+    const double dp = qt_div(ue - uw, P.dlon2, P.r_2dlon);
+    const double qn = vn * sl.k0.x;
+    const double qs = vs * sl.k0.y;
+    const double dq = qt_div(qn - qs, P.dlat2, P.r_2dlat);
+    const double div = sl.k1.x * (dp + dq);
+    double e = e0 + P.msdtH * div;
+    if (island) e = 0.0;
+    qt_st(E, ro, W.vs, e);
+    acc += (W.own && g >= W.own0 && g < W.own1) ? e * (island ? 0.0 : sl.k1.y) : 0.0;
+    double u = qd_nn(uc), v = qd_nn(vc);
+    const double cap = P.cap, s2 = u * u + v * v;
+    if (!(s2 < P.cap81)) {
+        const double speed = sqrt(s2);
+        if (P.mean4) {
+            if (speed > cap) {
+                u = 0.25 * (qd_nn(un) + qd_nn(us) + qd_nn(ue) + qd_nn(uw));
+                v = 0.25 * (qd_nn(vn) + qd_nn(vs) + qd_nn(ve) + qd_nn(vw));
+            }
+            const double sp2 = sqrt(u * u + v * v);
+            const double sc2 = (sp2 > cap) ? cap / (sp2 + 1e-12) : 1.0;
+            u = u * sc2; v = v * sc2;
+        } else {
+            const double sc = (speed > cap) ? cap / (speed + 1e-12) : 1.0;
+            u = u * sc; v = v * sc;
+        }
+    }
+    qt_st(UO, ro, W.vs, u); qt_st(VO, ro, W.vs, v);
+    us = uc; uc = un; vs = vc; vc = vn;
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned r2 = ro + 2u * (unsigned)W.m;              // what step g + 2 consumes: u, v of row g + 3, eta and land of row g + 2
+    sl.u = qt_ld(U, r2 + (unsigned)W.m, W.vo); sl.v = qt_ld(V, r2 + (unsigned)W.m, W.vo); sl.e = qt_ld(E, r2, W.vo); sl.l = qt_ld8(L, r2, W.vo8);
+    sl.k0 = qt_ldk(KT, 16u * (unsigned)(g + 2), 4u); sl.k1 = qt_ldk(KT, 16u * (unsigned)(g + 2), 5u);
+    __builtin_amdgcn_sched_barrier(0);                       // (else the next step's arithmetic is scheduled in front of these loads)
+}
+
+__device__ __forceinline__ double qt_currents_fast(const QdTailArgs& P, const QtW& W) {
+    const unsigned sb = W.slab, m = (unsigned)W.m;
+    const qt_rsrc U = qt_make_rsrc(P.uo, sb), V = qt_make_rsrc(P.vo, sb), E = qt_make_rsrc(P.eta, sb), L = qt_make_rsrc(P.land, sb / 8u);
+    const qt_rsrc UO = qt_make_rsrc(P.uo_out, sb), VO = qt_make_rsrc(P.vo_out, sb), KT = qt_make_rsrc(P.tab, (unsigned)W.n * 128u);
+    unsigned ro = (unsigned)(W.o0 - W.lbase) * m;
+    double us = qt_ld(U, ro - m, W.vo), vs = qt_ld(V, ro - m, W.vo);
+    double uc = qt_ld(U, ro, W.vo), vc = qt_ld(V, ro, W.vo);
+    double acc = 0.0;
+    QtCurK K;
+    K.dlon2 = qt_vreg(2 * P.dlon); K.r_2dlon = qt_vreg(P.r_2dlon); K.dlat2 = qt_vreg(2 * P.dlat); K.r_2dlat = qt_vreg(P.r_2dlat);
+    K.msdtH = qt_vreg(P.msdtH); K.cap = qt_vreg(P.cap); K.cap81 = qt_vreg(0.81 * (P.cap * P.cap)); K.mean4 = P.mean4;
+    QtCurSlot a, b;
+    a.u = qt_ld(U, ro + m, W.vo); a.v = qt_ld(V, ro + m, W.vo); a.e = qt_ld(E, ro, W.vo); a.l = qt_ld8(L, ro, W.vo8);
+    a.k0 = qt_ldk(KT, 16u * (unsigned)W.o0, 4u); a.k1 = qt_ldk(KT, 16u * (unsigned)W.o0, 5u);
+    b.u = qt_ld(U, ro + 2u * m, W.vo); b.v = qt_ld(V, ro + 2u * m, W.vo); b.e = qt_ld(E, ro + m, W.vo); b.l = qt_ld8(L, ro + m, W.vo8);
+    b.k0 = qt_ldk(KT, 16u * (unsigned)(W.o0 + 1), 4u); b.k1 = qt_ldk(KT, 16u * (unsigned)(W.o0 + 1), 5u);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // the loop is entered with nothing in flight (exact counts inside: qd_stream.h)
+    int g = W.o0;
+    for (; g + 1 < W.o1; g += 2) {
+        qt_cur_fast_step(K, W, U, V, E, L, UO, VO, KT, us, uc, vs, vc, acc, a, g, ro);
+        qt_cur_fast_step(K, W, U, V, E, L, UO, VO, KT, us, uc, vs, vc, acc, b, g + 1, ro + m);
+        ro += 2u * m;
+    }
+    if (g < W.o1) qt_cur_fast_step(K, W, U, V, E, L, UO, VO, KT, us, uc, vs, vc, acc, a, g, ro);
+    return acc;
+}
+
+struct QtSstSlot { double u, v, s, q; int l, ic; qt_f64x2 k0, k1, k2; };
+struct QtSstK { double a, r_a, dt, dlon, r_dlon, dlat, r_dlat, alpha, om_alpha, dtK, rcH, r_rcH, dtq; int has_ice, qfac_on; };
+
+__device__ __forceinline__ double qt_shfl(double x, int src_lane) {
+    const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(x));
+    const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
+
+// One row step of the SST wave away from the poles.  g: the row whose T1 is computed; ro: element offset of row g.  OUT: row g - 2 is
+// finished (K_h lap of the window + heating) and stored.  Returns through `bad` whether a lane needed the general gather.
+template <bool EDGE, bool OUT>
+__device__ __forceinline__ void qt_sst_fast_step(const QtSstK& K, const QtW& W, qt_rsrc U, qt_rsrc V, qt_rsrc S, qt_rsrc Q,
+                                                 qt_rsrc L, qt_rsrc I, qt_rsrc SO, qt_rsrc KT, double& Tm, double& T0, double& Wm, double& W0, double& Em,
+                                                 double& E0, double& w0, double& w1, double& w2, double& w3, double& w4, bool& bad,
+                                                 QtSstSlot& sl, int g, unsigned ro) {
+    const double Tp = qs_own(sl.s);                           // SST row g + 1: lives on as row g of the next step
+    double Wp = 0.0, Ep = 0.0;
+    if (!EDGE) { Wp = qd_west(Tp); Ep = qd_east(Tp); }
+    const double u = sl.u, v = sl.v;
+    // qt_departure's arithmetic, piece by piece
+    const double acos = sl.k0.x, r_acos = sl.k0.y;
+    const double dl = qt_div_fin(u * K.dt, acos, r_acos);
+    const double dph = qt_div_fin(v * K.dt, K.a, K.r_a);
+    const double dx = qt_div_fin(dl, K.dlon, K.r_dlon);
+    const double dy = qt_div_fin(dph, K.dlat, K.r_dlat);
+    const bool near = fabs(dx) < 1.0 && fabs(dy) < 1.0;       // (false for NaN: a non-finite u or v, or an overflow on the way)
+    bad = bad || (W.lane >= 1 && W.lane <= 62 && !near);      // lanes 0 and 63 only lend their SST: what they compute is never read
+    const double r = (double)g - dy;                          // 1 <= g <= n - 2 and |dy| < 1: inside [0, n - 1], no fold, no clamp
+    double cc = (double)W.j - dx;
+    if (EDGE) {                                               // qd_fold with |dx| < 1: trunc(.) is 0 below the range and 1 above it
+        const double sz = (double)(W.m - 1);
+        cc = cc < 0.0 ? cc + sz * 1.0 : (cc > sz ? cc - sz * 1.0 : cc);
+    }
+    const double r0f = floor(r), c0f = floor(cc);
+    const double tr = r - r0f, tc = cc - c0f;
+    const bool pr = r0f < (double)g;                          // r0 = g - 1 (else g)
+    double X_m, X_0, X_p, Y_m, Y_0, Y_p;
+    if (EDGE) {
+        const int c0 = (int)c0f;
+        const int c1 = c0 + 1 < W.m ? c0 + 1 : W.m - 1;
+        int l0 = c0 - W.jbase, l1 = c1 - W.jbase;
+        l0 = l0 < 0 ? l0 + W.m : (l0 >= W.m ? l0 - W.m : l0);
+        l1 = l1 < 0 ? l1 + W.m : (l1 >= W.m ? l1 - W.m : l1);
+        l0 &= 63; l1 &= 63;                                   // lanes 1 .. 62 stay inside the wave when |dx| < 1
+        X_m = qt_shfl(Tm, l0); X_0 = qt_shfl(T0, l0); X_p = qt_shfl(Tp, l0);
+        Y_m = qt_shfl(Tm, l1); Y_0 = qt_shfl(T0, l1); Y_p = qt_shfl(Tp, l1);
+    } else {
+        const bool pc = c0f < (double)W.j;                    // c0 = j - 1 (else j); c1 = c0 + 1: no clamp away from the two edge columns
+        X_m = pc ? Wm : Tm; X_0 = pc ? W0 : T0; X_p = pc ? Wp : Tp;
+        Y_m = pc ? Tm : Em; Y_0 = pc ? T0 : E0; Y_p = pc ? Tp : Ep;
+    }
+    QtGather q;
+    q.f00 = pr ? X_m : X_0; q.f10 = pr ? X_0 : X_p; q.f01 = pr ? Y_m : Y_0; q.f11 = pr ? Y_0 : Y_p;
+    q.wr0 = 1.0 - tr; q.wr1 = tr; q.wc0 = 1.0 - tc; q.wc1 = tc; q.nan_coord = false;
+    const double t1v = qd_nn(K.om_alpha * T0 + K.alpha * qt_gather_use(q));
+    Tm = T0; T0 = Tp;
+    if (!EDGE) { Wm = W0; W0 = Wp; Em = E0; E0 = Ep; }
+    w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = t1v;
+    if (OUT) {
+        // window centre i = g - 2: 2 <= i <= n - 3, the interior form of qt_lap_win
+        const double e = qd_east(w2), wst = qd_west(w2);
+        const double Gb = sl.k1.x * (w4 - w2);                // lapA[i + 1]
+        const double Ga = sl.k1.y * (w2 - w0);                // lapA[i - 1]
+        const double d2 = (e - 2.0 * w2) + wst;
+        const double lap = sl.k2.x * (Gb - Ga) + sl.k2.y * d2;   // lapP[i], lapQ[i]
+        double Tv = w2 + K.dtK * lap;
+        const double heat = qt_div(sl.q, K.rcH, K.r_rcH);
+        const bool ocean = sl.l == 0;
+        const bool ic = K.has_ice && sl.ic != 0;
+        if (ocean && !ic) Tv = Tv + K.dt * heat;
+        if (K.qfac_on && ocean && ic) Tv = Tv + K.dtq * heat;
+        qt_st(SO, ro - 2u * (unsigned)W.m, W.vs, qd_nn(Tv));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned r2 = ro + 2u * (unsigned)W.m;              // what step g + 2 consumes
+    sl.u = qt_ld(U, r2, W.vo); sl.v = qt_ld(V, r2, W.vo); sl.s = qt_ld(S, r2 + (unsigned)W.m, W.vo);
+    sl.q = qt_ld(Q, ro, W.vo); sl.l = qt_ld8(L, ro, W.vo8); sl.ic = qt_ld8(I, ro, W.vo8);
+    sl.k0 = qt_ldk(KT, 16u * (unsigned)(g + 2), 0u); sl.k1 = qt_ldk(KT, 16u * (unsigned)(g + 2), 1u); sl.k2 = qt_ldk(KT, 16u * (unsigned)(g + 2), 2u);
+    __builtin_amdgcn_sched_barrier(0);                       // (else the next step's arithmetic is scheduled in front of these loads)
+}
+
+// true: a lane needed the general gather (the caller runs the general wave over the strip)
+template <bool EDGE>
+__device__ __forceinline__ bool qt_sst_fast(const QdTailArgs& P, const QtW& W) {
+    const unsigned sb = W.slab, m = (unsigned)W.m;
+    const qt_rsrc U = qt_make_rsrc(P.uo, sb), V = qt_make_rsrc(P.vo, sb), S = qt_make_rsrc(P.Ts, sb), Q = qt_make_rsrc(P.qnet, sb);
+    const qt_rsrc L = qt_make_rsrc(P.land, sb / 8u), I = qt_make_rsrc(P.ice, sb / 8u), SO = qt_make_rsrc(P.Ts_out, sb);
+    const qt_rsrc KT = qt_make_rsrc(P.tab, (unsigned)W.n * 128u);
+    QtSstK K;
+    K.a = qt_vreg(P.a); K.r_a = qt_vreg(P.r_a); K.dt = qt_vreg(P.sub_dt); K.dlon = qt_vreg(P.dlon); K.r_dlon = qt_vreg(P.r_dlon);
+    K.dlat = qt_vreg(P.dlat); K.r_dlat = qt_vreg(P.r_dlat); K.alpha = qt_vreg(P.alpha); K.om_alpha = qt_vreg(1.0 - P.alpha);
+    K.dtK = qt_vreg(P.sub_dt * P.K_h); K.rcH = qt_vreg(P.rcH); K.r_rcH = qt_vreg(P.r_rcH); K.dtq = qt_vreg(P.sub_dt * P.ice_qfac);
+    K.has_ice = P.has_ice; K.qfac_on = P.ice_qfac > 0.0 ? 1 : 0;
+    const int t0 = W.o0 - 2;                                 // first row of T1 this strip needs (last: o1 + 1)
+    unsigned ro = (unsigned)(t0 - W.lbase) * m;
+    double Tm = qt_ld(S, ro - m, W.vo), T0 = qt_ld(S, ro, W.vo);
+    QtSstSlot a, b;
+    a.u = qt_ld(U, ro, W.vo); a.v = qt_ld(V, ro, W.vo); a.s = qt_ld(S, ro + m, W.vo);
+    a.k0 = qt_ldk(KT, 16u * (unsigned)t0, 0u); a.k1 = qt_ldk(KT, 16u * (unsigned)t0, 1u); a.k2 = qt_ldk(KT, 16u * (unsigned)t0, 2u);
+    b.u = qt_ld(U, ro + m, W.vo); b.v = qt_ld(V, ro + m, W.vo); b.s = qt_ld(S, ro + 2u * m, W.vo);
+    b.k0 = qt_ldk(KT, 16u * (unsigned)(t0 + 1), 0u); b.k1 = qt_ldk(KT, 16u * (unsigned)(t0 + 1), 1u); b.k2 = qt_ldk(KT, 16u * (unsigned)(t0 + 1), 2u);
+    a.q = b.q = 0.0; a.l = b.l = 0; a.ic = b.ic = 0;         // (the first four steps store nothing)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // the loop is entered with nothing in flight (exact counts inside: qd_stream.h)
+    double Wm = 0.0, W0 = 0.0, Em = 0.0, E0 = 0.0;
+    if (!EDGE) { Wm = qd_west(Tm); W0 = qd_west(T0); Em = qd_east(Tm); E0 = qd_east(T0); }
+    double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0, w4 = 0.0;
+    bool bad = false;
+#define QT_FS(OUTF, SL, GG, RO) qt_sst_fast_step<EDGE, OUTF>(K, W, U, V, S, Q, L, I, SO, KT, Tm, T0, Wm, W0, Em, E0, w0, w1, w2, w3, w4, bad, SL, GG, RO)
+    int g = t0;
+    QT_FS(false, a, g, ro); QT_FS(false, b, g + 1, ro + m); QT_FS(false, a, g + 2, ro + 2u * m); QT_FS(false, b, g + 3, ro + 3u * m);
+    g += 4; ro += 4u * m;
+    const int gend = W.o1 + 2;
+    for (; g + 1 < gend; g += 2) { QT_FS(true, a, g, ro); QT_FS(true, b, g + 1, ro + m); ro += 2u * m; }
+    if (g < gend) QT_FS(true, a, g, ro);
+#undef QT_FS
+    return __builtin_amdgcn_ballot_w64(bad) != 0ull;
+}
+
+__global__ void __launch_bounds__(128)
+k_ocn_tail_fast(QdGeom G, QdTabs T, QdTailArgs P) {
+    const unsigned w = qd_xcd_chunk(blockIdx.x, gridDim.x);
+    const int rs = (int)(w / (unsigned)P.ntc), cs = (int)(w % (unsigned)P.ntc);
+    QtW W;
+    W.n = G.nlat; W.m = G.nlon; W.lane = threadIdx.x & 63;
+    W.jbase = cs * QS_TCF - 2;
+    const int jraw = W.jbase + W.lane;
+    W.j = jraw < 0 ? jraw + W.m : (jraw >= W.m ? jraw - W.m : jraw);
+    W.own = W.lane >= 2 && W.lane <= QS_TCF + 1 && jraw < W.m;
+    W.vo = (unsigned)W.j * 8u; W.vo8 = (unsigned)W.j; W.vs = W.own ? (unsigned)jraw * 8u : 0x80000000u;
+    W.slab = (unsigned)(G.lrows_ + QD_PAD_ROWS) * (unsigned)G.nlon * 8u;
+    W.lbase = G.lbase; W.lrows = G.lrows_; W.own0 = P.own0; W.own1 = P.own1;
+    const int lo = G.row0, hi = G.row0 + G.nrows;
+    const QtPart q = qt_partition(lo, hi, G.nlat, P.R, P.Rp);
+    const int k = rs - (q.ps > 0 ? 1 : 0);                   // index among the middle strips
+    if (q.ps > 0 && rs == 0) { W.o0 = lo; W.o1 = lo + q.ps; }
+    else if (k < q.nmid) {                                   // even cut of the middle rows
+        const int M = q.mid1 - q.mid0;
+        W.o0 = q.mid0 + (int)(((long long)k * M) / q.nmid);
+        W.o1 = q.mid0 + (int)(((long long)(k + 1) * M) / q.nmid);
+    } else { W.o0 = q.mid1; W.o1 = hi; }
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // rows a fast wave touches lie inside the slab without a wrap, and away from the poles
+    const bool plain = (P.flags & 1) == 0 && W.o0 - 3 - W.lbase >= 0 && W.o1 + 2 - W.lbase <= W.lrows - 1;
+    QT_STAMP(0);
+    if (wv >= 1) {
+        __builtin_amdgcn_s_setprio(2);
+        bool general = !(plain && W.o0 >= 3 && W.o1 <= W.n - 3 && P.use_q && P.K_h > 0.0);
+        if (!general) {
+            const bool edge_lane = W.lane >= 1 && W.lane <= 62 && (W.j == 0 || W.j == W.m - 1);
+            general = __builtin_amdgcn_ballot_w64(edge_lane) != 0ull ? qt_sst_fast<true>(P, W) : qt_sst_fast<false>(P, W);
+        }
+        if (general) qt_sst_wave(G, T, P, W);
+        QT_STAMP(2);
+        return;
+    }
+    double acc = (plain && W.o0 >= 1 && W.o1 <= W.n - 1) ? qt_currents_fast(P, W) : qt_currents_wave(T, P, W);
+    QT_STAMP(2);
+    acc = qt_wave_sum(acc);
+    if (W.lane == 0) __hip_atomic_store(P.partial + w, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // coherent: the finisher may read it
+    if (P.acc) {                                             // eta mean inside this launch: the last workgroup to arrive finishes it
+        const bool last = W.lane == 0 && qd_acc_arrive(P.acc, w, gridDim.x, acc);
+        if (__builtin_amdgcn_ballot_w64(last) != 0ull) {
+            const double mm = qd_acc_finish(P.acc, P.partial, (int)gridDim.x, P.wsum);
+            if (W.lane == 0) *P.mean_out = mm;
         }
     }
 }
@@ -907,9 +1218,27 @@ static int qt_rows(const qd_ctx* c) {
     return qt_sst_waves(c) == 2 ? 14 : 7;
 }
 
+// the slim streaming form (k_ocn_tail_fast) unless QD_TAIL_V=1 asks for the round-3 kernel; its strip heights
+static bool qt_use_fast(const qd_ctx* c) {
+    if (const char* e = std::getenv("QD_TAIL_V")) { if (e[0] == '1') return false; }
+    return c->ocn_tail == 1;
+}
+// 240-step bench, 721 x 1440, ms per step (same box): R = 8 / 9 / 10 / 11 / 12 -> 0.926 / 0.895 / 0.894 / 0.907 / 0.896; pole strips of 3 / 4 / 5
+// rows: 0.894 / 0.893 / 0.893; the round-3 kernel on that box: 0.940
+static int qt_fast_rows(const qd_ctx*) {
+    if (const char* e = std::getenv("QD_TAIL_R")) { const int r = std::atoi(e); if (r > 0) return r; }
+    return 10;
+}
+static int qt_fast_pole_rows(const qd_ctx*) {
+    if (const char* e = std::getenv("QD_TAIL_RP")) { const int r = std::atoi(e); if (r >= 3) return r; }
+    return 3;                                                // >= 3: a middle strip's T1 rows start at o0 - 2 >= 1
+}
+
 // number of eta partial sums the launch leaves in P.partial
 int qd_ocn_tail_tiles(const qd_ctx* c, const QdGeom& G) {
     if (c->ocn_tail >= 2) return ((G.nrows + QT_TR - 1) / QT_TR) * ((G.nlon + QT_TC - 1) / QT_TC);
+    if (qt_use_fast(c))
+        return qt_part_strips(qt_partition(G.row0, G.row0 + G.nrows, G.nlat, qt_fast_rows(c), qt_fast_pole_rows(c))) * ((G.nlon + QS_TCF - 1) / QS_TCF);
     const int R = qt_rows(c);
     return ((G.nrows + R - 1) / R) * ((G.nlon + QS_TC2 - 1) / QS_TC2);
 }
@@ -926,9 +1255,24 @@ int qd_launch_ocn_tail(qd_ctx* c, const QdGeom& G, QdTailArgs& P) {
         else QD_LAUNCH_TIMED(sc, k_ocn_tail, dim3(ntr * P.ntc), dim3(256), c->stream, G, c->tabs, P);
         return 0;
     }
-    P.R = qt_rows(c);
-    P.ntc = (G.nlon + QS_TC2 - 1) / QS_TC2;
-    const int nrs = (G.nrows + P.R - 1) / P.R;
+    const bool fast = qt_use_fast(c);
+    if (fast && (!c->qt_tab || c->qt_tab_a != P.a)) {        // packed row table of the fast waves (once per handle)
+        if (!c->qt_tab) {
+            if (hipMalloc(&c->qt_tab, (size_t)G.nlat * 16 * sizeof(double)) != hipSuccess) return qd_fail(c, "k_ocn_tail_fast: row table");
+            c->tab_alloc.push_back(c->qt_tab);
+        }
+        hipLaunchKernelGGL(k_tail_tab, dim3((G.nlat + 255) / 256), dim3(256), 0, c->stream, c->tabs, G.nlat, P.a, c->qt_tab);
+        c->qt_tab_a = P.a;
+    }
+    P.tab = c->qt_tab;
+    P.flags = 0;
+    if (const char* e = std::getenv("QD_TAIL_GENERAL")) { if (e[0] == '1') P.flags |= 1; }      // every wave the general form (A/B runs, tests)
+    P.R = fast ? qt_fast_rows(c) : qt_rows(c);
+    P.Rp = qt_fast_pole_rows(c);
+    P.ntc = fast ? (G.nlon + QS_TCF - 1) / QS_TCF : (G.nlon + QS_TC2 - 1) / QS_TC2;
+    const QtPart part = qt_partition(G.row0, G.row0 + G.nrows, G.nlat, P.R, P.Rp);
+    P.nmid = part.nmid;
+    const int nrs = fast ? qt_part_strips(part) : (G.nrows + P.R - 1) / P.R;
     if (nrs * P.ntc > c->red_blocks) return qd_fail(c, "k_ocn_tail_stream: partial buffer too small");
 #ifdef QT_STAMPS
     static unsigned long long* stamps = nullptr;
@@ -936,7 +1280,8 @@ int qd_launch_ocn_tail(qd_ctx* c, const QdGeom& G, QdTailArgs& P) {
     if (!stamps) { hipMalloc(&stamps, stamp_words * 8); hipMemcpyToSymbol(HIP_SYMBOL(qt_stamp_buf), &stamps, sizeof(stamps)); }
     hipMemsetAsync(stamps, 0, stamp_words * 8, c->stream);
 #endif
-    if (qt_sst_waves(c) == 2) QD_LAUNCH_TIMED(sc, k_ocn_tail_stream<2>, dim3(nrs * P.ntc), dim3(192), c->stream, G, c->tabs, P);
+    if (fast) QD_LAUNCH_TIMED(sc, k_ocn_tail_fast, dim3(nrs * P.ntc), dim3(128), c->stream, G, c->tabs, P);
+    else if (qt_sst_waves(c) == 2) QD_LAUNCH_TIMED(sc, k_ocn_tail_stream<2>, dim3(nrs * P.ntc), dim3(192), c->stream, G, c->tabs, P);
     else QD_LAUNCH_TIMED(sc, k_ocn_tail_stream<1>, dim3(nrs * P.ntc), dim3(128), c->stream, G, c->tabs, P);
 #ifdef QT_STAMPS
     if (const char* f = std::getenv("QD_STAMPS_FILE")) {

@@ -137,6 +137,35 @@ def test_ocean_tail_kernel_matches_the_two_launch_form(gpu, shape, tail, monkeyp
         assert e < TAIL_TOL, (k, e)
 
 
+@pytest.mark.parametrize("shape", [(181, 360), (91, 144), (64, 97), (121, 240)])
+def test_fast_tail_waves_equal_the_general_ones_bit_for_bit(gpu, shape, monkeypatch):
+    """k_ocn_tail_fast: strips away from the poles run slim waves (two-slot streams, the SST gather taken from the nine cells
+    around the cell -- three streamed rows, DPP lane shifts, ds_bpermute in the waves that hold column 0 / n_lon - 1); a lane
+    whose departure point is a cell or more away or NaN sends its wave back to the general form.  Same arithmetic on the same
+    operands: every field must equal the all-general run (QD_TAIL_GENERAL=1) bit for bit -- with calm currents, with a current
+    of 1e6 m/s and a NaN injected next to the seam and in the interior (the fallback), on grids whose last column group is
+    partial (97, 144 columns) and whose strips do not divide evenly."""
+    nlat, nlon = shape
+
+    def spike(st):
+        st["UO"] = np.zeros((nlat, nlon)); st["VO"] = np.zeros((nlat, nlon))
+        st["UO"][nlat // 2, 0] = 1e6; st["VO"][nlat // 3, nlon - 1] = -2e6; st["UO"][nlat // 2 + 9, nlon // 2] = np.nan
+    over = dict(energy_w=1.0, ocean_cfl=0.05)
+    for mutate in (None, spike):
+        monkeypatch.setenv("QD_TAIL_GENERAL", "1")
+        gen, _ = _run(1, nlat, nlon, 3, over, True, True, mutate=mutate)
+        monkeypatch.setenv("QD_TAIL_GENERAL", "0")
+        fast, _ = _run(1, nlat, nlon, 3, over, True, True, mutate=mutate)
+        for k in fast:
+            assert np.array_equal(fast[k], gen[k], equal_nan=True), (k, mutate is not None, relerr(fast[k], gen[k]))
+        monkeypatch.setenv("QD_TAIL_V", "1")                     # the round-3 kernel: another strip cut, so another order of the eta sum
+        old, _ = _run(1, nlat, nlon, 3, over, True, True, mutate=mutate)
+        monkeypatch.delenv("QD_TAIL_V")
+        if mutate is None:
+            for k in fast:
+                assert relerr(fast[k], old[k]) < TAIL_TOL, (k, relerr(fast[k], old[k]))
+
+
 def test_nonfinite_values_fall_back_to_the_exact_path(gpu, monkeypatch):
     """The FAST path of the fused kernels omits nan_to_num and instead detects non-finite values (one v_cmp_class per
     owned output / clip input); a workgroup that sees one recomputes its tile on the EXACT path.  Poison interior, pole and
