@@ -27,8 +27,11 @@ struct QdColPtrs {
 };
 
 // PHASE 0: whole column in one pass (P_ref known up front or not needed)
-// PHASE 1: humidity part only (writes q, E, P_cond, LH, LH_release; counts P_cond > 0)
-// PHASE 2: everything after the humidity part (reads the phase-1 outputs back)
+// PHASE 1: the humidity part as far as P_cond, the only thing the median between the phases reads: ONE field written
+// PHASE 2: the whole column again, now with P_ref = median(P_cond > 0) on the device.  (Round 3b: phase 1 used to write q, E,
+//          P_cond, LH and LH_release and phase 2 to read them back -- 33 MB more written and the same number read as it costs phase 2
+//          to take q, u, v, T_s once more and redo ~100 f64 instructions; the humidity arithmetic is the same in both phases, so the
+//          P_cond phase 2 writes is the one the median saw.)
 template <int PHASE, bool HAS_ALB>
 __global__ void __launch_bounds__(QD_BLOCK)
 k_column(QdGeom G, QdColP P, QdColPtrs A) {
@@ -46,7 +49,7 @@ k_column(QdGeom G, QdColP P, QdColPtrs A) {
     const double qsat_air = qd_qsat(T_a, P.p0);
 
     double q, E, Pc, LH, LHrel;
-    if (PHASE != 2) {
+    {
         // ---- humidity column: dynamics.py:282-297
         const double fac = land ? P.s_land : ((hice > 1e-6) ? P.s_ice : P.s_ocean);
         const double V = sqrt(u * u + v * v);
@@ -62,10 +65,8 @@ k_column(QdGeom G, QdColP P, QdColPtrs A) {
         Pc = qd_nn(Pc);
         LHrel = P.L_v * Pc;
         q = qd_clip(qd_nn(q_next), 0.0, 0.5);
+        if (PHASE == 1) { A.Pcond[o] = Pc; return; }
         A.q[o] = q; A.E[o] = E; A.Pcond[o] = Pc; A.LH[o] = LH; A.LHrel[o] = LHrel;
-        if (PHASE == 1) return;
-    } else {
-        q = A.q[o]; E = A.E[o]; Pc = A.Pcond[o]; LH = A.LH[o]; LHrel = A.LHrel[o];
     }
 
     // ---- Newton path: dynamics.py:304-322

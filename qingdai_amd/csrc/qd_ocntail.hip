@@ -1225,9 +1225,19 @@ static bool qt_use_fast(const qd_ctx* c) {
 }
 // 240-step bench, 721 x 1440, ms per step (same box): R = 8 / 9 / 10 / 11 / 12 -> 0.926 / 0.895 / 0.894 / 0.907 / 0.896; pole strips of 3 / 4 / 5
 // rows: 0.894 / 0.893 / 0.893; the round-3 kernel on that box: 0.940
-static int qt_fast_rows(const qd_ctx*) {
+// 1441 x 2880 (48 column groups): R = 10 / 14 / 20 / 28 / 40 / 56 -> 5.13 / 5.09 / 4.87 / 4.84 / 4.79 / 4.88 ms per step (round-3 kernel: 5.28).  Both optima
+// are the strip height that makes ~3500 waves -- every wave resident from the start, three to four per SIMD.
+static int qt_fast_rows(const qd_ctx* c, const QdGeom& G) {
     if (const char* e = std::getenv("QD_TAIL_R")) { const int r = std::atoi(e); if (r > 0) return r; }
-    return 10;
+    const int ntc = (G.nlon + QS_TCF - 1) / QS_TCF;
+    if (c->n_cu <= 0) {
+        int n = 0;
+        const_cast<qd_ctx*>(c)->n_cu = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, c->desc.device) == hipSuccess && n > 0) ? n : 256;
+    }
+    const int cus = c->n_cu;
+    const double target = 13.7 * cus;                        // waves
+    const int r = (int)std::lround((double)G.nrows * ntc * 2.0 / target);
+    return r < 7 ? 7 : r;
 }
 static int qt_fast_pole_rows(const qd_ctx*) {
     if (const char* e = std::getenv("QD_TAIL_RP")) { const int r = std::atoi(e); if (r >= 3) return r; }
@@ -1238,7 +1248,7 @@ static int qt_fast_pole_rows(const qd_ctx*) {
 int qd_ocn_tail_tiles(const qd_ctx* c, const QdGeom& G) {
     if (c->ocn_tail >= 2) return ((G.nrows + QT_TR - 1) / QT_TR) * ((G.nlon + QT_TC - 1) / QT_TC);
     if (qt_use_fast(c))
-        return qt_part_strips(qt_partition(G.row0, G.row0 + G.nrows, G.nlat, qt_fast_rows(c), qt_fast_pole_rows(c))) * ((G.nlon + QS_TCF - 1) / QS_TCF);
+        return qt_part_strips(qt_partition(G.row0, G.row0 + G.nrows, G.nlat, qt_fast_rows(c, G), qt_fast_pole_rows(c))) * ((G.nlon + QS_TCF - 1) / QS_TCF);
     const int R = qt_rows(c);
     return ((G.nrows + R - 1) / R) * ((G.nlon + QS_TC2 - 1) / QS_TC2);
 }
@@ -1267,7 +1277,7 @@ int qd_launch_ocn_tail(qd_ctx* c, const QdGeom& G, QdTailArgs& P) {
     P.tab = c->qt_tab;
     P.flags = 0;
     if (const char* e = std::getenv("QD_TAIL_GENERAL")) { if (e[0] == '1') P.flags |= 1; }      // every wave the general form (A/B runs, tests)
-    P.R = fast ? qt_fast_rows(c) : qt_rows(c);
+    P.R = fast ? qt_fast_rows(c, G) : qt_rows(c);
     P.Rp = qt_fast_pole_rows(c);
     P.ntc = fast ? (G.nlon + QS_TCF - 1) / QS_TCF : (G.nlon + QS_TC2 - 1) / QS_TC2;
     const QtPart part = qt_partition(G.row0, G.row0 + G.nrows, G.nlat, P.R, P.Rp);

@@ -64,7 +64,7 @@ def main():
     fk = {"grid": [nlat, nlon], "kernel_sources_sha256_16": stamp, "source": f"rocprofv3 kernel trace + FETCH_SIZE / WRITE_SIZE passes of bench.py (scripts/profile_round.sh {tag}, "
                                          f"scripts/assemble_profiles.py); profiles/README.md", "kernels": {}}
     dyn = next(k for k in tr if "k_dyn_stream" in k)
-    tail = next(k for k in tr if "k_ocn_tail_stream" in k)      # a template since round 3: "void k_ocn_tail_stream<1>"
+    tail = next(k for k in tr if "k_ocn_tail_fast" in k or "k_ocn_tail_stream" in k)      # round 3b: k_ocn_tail_fast; before: "void k_ocn_tail_stream<1>"
     for grp, kn in (("k_dyn_hyper", dyn), ("k_ocn_hyper", "k_ocn_stream"), ("ocean_tail", tail)):
         fk["kernels"][grp] = {"trace_kernel": kn, "traffic_bytes": traffic["kernels"][kn]["traffic_bytes"],
                               "read_bytes": traffic["kernels"][kn]["read_bytes"], "write_bytes": traffic["kernels"][kn]["write_bytes"],
