@@ -264,6 +264,7 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
     hipError_t e;
     if ((e = hipSetDevice(d->device)) != hipSuccess) return bail("hipSetDevice", e);
     if ((e = hipStreamCreate(&c->stream)) != hipSuccess) return bail("hipStreamCreate", e);
+    { int ncu = 0; c->n_cu = (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, d->device) == hipSuccess && ncu > 0) ? ncu : 256; }
     // every slab is allocated with QD_PAD_ROWS rows of slack behind its last row: the row-streaming kernels prefetch a few rows
     // ahead of the row they work on without clamping (what they read there is never used)
     const size_t cells = c->geo.cells() + (size_t)QD_PAD_ROWS * c->geo.nlon;

@@ -222,7 +222,7 @@ struct qd_ctx {
     double qs_key[2][8] = {{NAN, 0, 0, 0, 0, 0, 0, 0}, {NAN, 0, 0, 0, 0, 0, 0, 0}};
     std::vector<double> h_lapK[2];  // host copies of QdTabs::lapK
     std::vector<double> h_k4[2];    // host copies of k4_atm / k4_ocn
-    int n_cu = 0;                    // compute units of the device (hipDeviceAttributeMultiprocessorCount, read at the first use)
+    int n_cu = 0;                    // compute units of the device (hipDeviceAttributeMultiprocessorCount, qd_create)
     int qs_wgs_per_cu[3] = {0, 0, 0};   // resident workgroups per CU of k_dyn_stream<false>, <true>, k_ocn_stream (occupancy query, cached)
     int cloud_eff_valid = 0;
     int last_nsub = 0;

@@ -1230,11 +1230,7 @@ static bool qt_use_fast(const qd_ctx* c) {
 static int qt_fast_rows(const qd_ctx* c, const QdGeom& G) {
     if (const char* e = std::getenv("QD_TAIL_R")) { const int r = std::atoi(e); if (r > 0) return r; }
     const int ntc = (G.nlon + QS_TCF - 1) / QS_TCF;
-    if (c->n_cu <= 0) {
-        int n = 0;
-        const_cast<qd_ctx*>(c)->n_cu = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, c->desc.device) == hipSuccess && n > 0) ? n : 256;
-    }
-    const int cus = c->n_cu;
+    const int cus = c->n_cu > 0 ? c->n_cu : 256;
     const double target = 13.7 * cus;                        // waves
     const int r = (int)std::lround((double)G.nrows * ntc * 2.0 / target);
     return r < 7 ? 7 : r;
