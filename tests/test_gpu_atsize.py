@@ -204,3 +204,26 @@ def test_config3_eight_bands_match_the_whole_globe_at_1441x2880(gpu):
         assert np.array_equal(got[k], ref[k]), (k, relerr(got[k], ref[k]))
     for k in ("UO", "VO", "ETA", "SST"):
         assert relerr(got[k], ref[k]) < 1e-12, (k, relerr(got[k], ref[k]))
+
+
+def test_fast_tail_waves_equal_the_general_ones_at_721x1440(gpu, monkeypatch):
+    """k_ocn_tail_fast at the benchmark's size and sub-step count: two coupled steps (26 launches, 74 strips x 24 column groups,
+    the two edge column groups on ds_bpermute, the pole strips on the general waves) with the slim waves against the same kernel
+    with every wave on the general form (QD_TAIL_GENERAL=1: memory gather, clamps, pole stencils).  Same strip cut, hence the same
+    order of the eta sum: every ocean field and what the SST write-back does to the atmosphere must agree bit for bit."""
+    import bench
+
+    def run(general):
+        monkeypatch.setenv("QD_TAIL_GENERAL", general)
+        grid, m, oc, forcing, mask, base_albedo, friction = bench.build_case(721, 1440, True)
+        import qingdai_amd as qa
+        lat = np.deg2rad(grid.lat_mesh); lon = np.deg2rad(grid.lon_mesh)
+        m.u, m.v = atsize_wind(lat, lon)
+        m._dev.step_n(forcing.star_table([0.0, 300.0]), 300.0, with_ocean=True, with_physics=True, pass_albedo=True)
+        assert m._dev.last_ocean_nsub() >= 12
+        out = {k: np.array(m._dev.get(k)) for k in ("UO", "VO", "ETA", "SST", "TS", "U", "V", "H", "Q")}
+        m._dev.close()
+        return out
+    fast, gen = run("0"), run("1")
+    for k in fast:
+        assert np.array_equal(fast[k], gen[k], equal_nan=True), (k, relerr(fast[k], gen[k]))
