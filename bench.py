@@ -208,9 +208,30 @@ def spawn_ranks(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc = 0
-    for pr in procs:
-        rc = max(rc, abs(pr.wait()))
+    # poll: the first rank that fails takes the others with it (they would block in the rendezvous or a collective for ever),
+    # and the whole launch has a deadline (QD_BENCH_SPAWN_TIMEOUT seconds, default 3000)
+    deadline = time.time() + float(os.environ.get("QD_BENCH_SPAWN_TIMEOUT", "3000"))
+    rc, live = 0, list(procs)
+    while live:
+        for pr in list(live):
+            r = pr.poll()
+            if r is None:
+                continue
+            live.remove(pr)
+            if r != 0:
+                rc = max(rc, abs(r))
+        if rc or time.time() > deadline:
+            rc = rc or 124
+            for pr in live:
+                pr.terminate()
+            t_kill = time.time() + 10.0
+            for pr in live:
+                try:
+                    pr.wait(timeout=max(0.1, t_kill - time.time()))
+                except subprocess.TimeoutExpired:
+                    pr.kill()
+            break
+        time.sleep(0.05)
     raise SystemExit(rc)
 
 
@@ -258,6 +279,11 @@ def main():
     if os.environ.get("QD_BENCH_ONE_DEVICE") == "1":     # rehearsal of the multi-rank flow on a 1-GPU box
         local_rank = 0
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # under rocprofv3 the profiler's preloaded library has already initialised the GPU in THIS process: forking rank processes
+        # from here is the exec-after-GPU-init this pool forbids -- profile one rank (or the self-ring) instead
+        if any(k.startswith("ROCP") or k.startswith("ROCPROF") for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+            raise SystemExit("bench.py --gpus N cannot start its own rank processes under rocprofv3 (the profiler has initialised the "
+                             "GPU in this process): use a launcher, or profile N=1 / QD_BENCH_SELF_RING")
         spawn_ranks(args.gpus)                                # never returns
     if args.spawn_check:
         print(json.dumps({k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}), flush=True)
@@ -285,9 +311,10 @@ def main():
     grid, m, oc, forcing, mask, base_albedo, friction = build_case(args.nlat, args.nlon, with_ocean, device=local_rank,
                                                                    band=band, rank=rank, world=world)
     dev = m._dev
+    transport = None
     if banded:
-        from qingdai_amd.bands import init_rccl
-        init_rccl(dev, rank, world)
+        from qingdai_amd.bands import init_comm
+        transport = init_comm(dev, rank, world)
     K, W = args.steps, args.warmup
     stars_w = forcing.star_table([i * dt for i in range(W)])
     stars_k = forcing.star_table([(W + i) * dt for i in range(K)])
@@ -337,7 +364,17 @@ def main():
         dev.lib.qd_comm_grouped_sum_count(dev.h, _ct.byref(ng))
         # of the all-reduces, those that went out inside a halo exchange's ncclGroup (counted over the whole run incl. warm-up)
         comm["allreduces_grouped_into_an_exchange_per_step"] = ng.value / max(1, K + W)
-        comm["collective_launches_per_step"] = comm["halo_exchanges_per_step"] + comm["rccl_allreduces_per_step"] - ng.value / max(1, K + W)
+        comm["transport"] = transport
+        if transport == "peer":
+            # every halo exchange and every reduction went through the device-side mailboxes (qd_peer.hip): small kernels on the
+            # handle's own stream, no collective launch at all
+            nph, npr = _ct.c_int(0), _ct.c_int(0)
+            dev.lib.qd_comm_peer_stats(dev.h, _ct.byref(nph), _ct.byref(npr))
+            comm["reductions_per_step"] = comm.pop("rccl_allreduces_per_step")
+            comm["peer_ops_whole_run"] = {"halo_exchanges": nph.value, "reductions": npr.value}
+            comm["collective_launches_per_step"] = 0.0
+        else:
+            comm["collective_launches_per_step"] = comm["halo_exchanges_per_step"] + comm["rccl_allreduces_per_step"] - ng.value / max(1, K + W)
     kern_ms, kern_n = dev.timing_get(args.profile_kernel)
     also_ms, also_n = dev.timing_get(also) if also else (0.0, 0)
     dev.timing(on=False)
@@ -348,7 +385,7 @@ def main():
     bpc = BYTES_PER_CELL.get(args.profile_kernel, 0.0)
     achieved = (bpc * cells / 1e9) / (kern_ms / 1e3) if kern_ms > 0 else 0.0
     out = {
-        "metric": "simulated planet-days/sec at 721x1440 f64", "value": value, "unit": "planet-days/s",
+        "metric": f"simulated planet-days/sec at {args.nlat}x{args.nlon} f64", "value": value, "unit": "planet-days/s",
         "n_gpus": args.gpus, "steps": K, "warmup": W, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{args.nlat}x{args.nlon} seed-42 planet, dt=300 s: forcing + time_step(Teq, dt, albedo) "

@@ -290,6 +290,14 @@ int qd_plansim_margin(qd_handle h, int field);
 int qd_plansim_segments(qd_handle h, int margin, int* row0_nrows_pairs);                    /* -> number of segments (<= 3) */
 int qd_plansim_pop_exchange(qd_handle h, int* fields_out, int max_fields, int* geom4);      /* geom4 = {H, owned rows, up, dn} */
 int qd_comm_barrier(qd_handle h);
+/* Device-side exchange over the peer mapping (round 4; QD_PEER_EXCHANGE=1): halo rows and global sums are STORED into the
+ * neighbours' memory by small kernels on the handle's own stream and polled there -- no collective launch, no host.  Every rank
+ * exports the IPC handle of its mailbox (64 bytes), the host side hands every rank all handles in rank order, qd_peer_connect
+ * maps them; from then on qd_comm_init is not needed.  In-process groups (qd_comm_init_local) switch to it through the environment
+ * variable.  Replaces nothing in the reference (single process: np.roll on whole arrays, pygcm/ocean.py:306-310,369-377). */
+int qd_peer_export(qd_handle h, void* handle64, size_t bytes);
+int qd_peer_connect(qd_handle h, const void* handles, size_t bytes_each, int world);
+int qd_comm_peer_stats(qd_handle h, int* halo_exchanges, int* reductions);   /* operations that went through the mailboxes */
 int qd_comm_allreduce_max(qd_handle h, double* inout, int n);     /* bench timing: max over ranks */
 
 /* ---- profiling hooks ----------------------------------------------------------------- */

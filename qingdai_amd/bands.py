@@ -216,6 +216,77 @@ def finish_rendezvous(rank, key, root="/tmp"):
                 pass
 
 
+def peer_exchange_wanted():
+    """QD_PEER_EXCHANGE: "1" (default) = halos and global sums through device-side mailboxes over the peer mapping (qd_peer.hip),
+    "0" = RCCL collectives."""
+    return os.environ.get("QD_PEER_EXCHANGE", "1") != "0"
+
+
+def init_peer(dev: Device, rank, world, tag="peer", timeout_s=180.0):
+    """One process per GPU, no communication library: every rank allocates its mailbox and exports its IPC handle
+    (qd_peer_export), the handles travel through the filesystem under a session token that rank 0 draws (exchange_unique_id: a
+    file of an earlier run cannot carry it), every rank maps all mailboxes (qd_peer_connect).  Returns True when the transport is
+    up on EVERY rank; False (on every rank alike) when any rank could not export or map -- the caller falls back to RCCL."""
+    lib = dev.lib
+    key = _rendezvous_key(world, tag)
+    token = exchange_unique_id(rank, world, lambda: os.urandom(32), key, timeout_s=timeout_s)[:16].hex()
+    base = os.path.join("/tmp", f"qd_rdzv_{key}.{token}")
+    buf = (ctypes.c_char * 64)()
+    ok = lib.qd_peer_export(dev.h, buf, 64) == 0
+    _write_atomic(f"{base}.ipc.{rank}", (b"\1" if ok else b"\0") + bytes(buf))
+
+    def gather(suffix, size):
+        out, t0 = [], time.time()
+        for k in range(world):
+            while True:
+                try:
+                    with open(f"{base}.{suffix}.{k}", "rb") as fh:
+                        d = fh.read()
+                    if len(d) == size:
+                        out.append(d)
+                        break
+                except OSError:
+                    pass
+                if time.time() - t0 > timeout_s:
+                    raise _lib.QdError(f"peer rendezvous timeout: rank {k} never posted .{suffix}")
+                time.sleep(0.002)
+        return out
+    recs = gather("ipc", 65)
+    good = all(r[:1] == b"\1" for r in recs)
+    if good:
+        blob = b"".join(r[1:] for r in recs)
+        arr = (ctypes.c_char * len(blob)).from_buffer_copy(blob)
+        good = lib.qd_peer_connect(dev.h, arr, 64, world) == 0
+    # second round: did EVERY rank map every mailbox?  (nobody may store into a mailbox before all ranks agree)
+    _write_atomic(f"{base}.map.{rank}", b"\1" if good else b"\0")
+    good = all(r == b"\1" for r in gather("map", 1))
+    if good:
+        dev._chk(lib.qd_comm_barrier(dev.h), "qd_comm_barrier")
+    _write_atomic(f"{base}.done.{rank}", b"\1")
+    if rank == 0:
+        gather("done", 1)
+        import glob
+        for f in glob.glob(os.path.join("/tmp", f"qd_rdzv_{key}") + "*"):
+            try:
+                os.remove(f)
+            except OSError:
+                pass
+    return good
+
+
+def init_comm(dev: Device, rank, world, timeout_s=180.0):
+    """Wire a one-process-per-GPU band handle to its peers: the device-side peer exchange (default), RCCL when QD_PEER_EXCHANGE=0
+    or when the mailboxes cannot be mapped on every rank.  Returns the transport's name."""
+    if peer_exchange_wanted():
+        if init_peer(dev, rank, world, timeout_s=timeout_s):
+            return "peer"
+        if os.environ.get("QD_PEER_EXCHANGE") == "1":
+            raise _lib.QdError("QD_PEER_EXCHANGE=1 but the peer mailboxes could not be mapped: "
+                               + (dev.lib.qd_last_error(dev.h) or b"?").decode())
+    init_rccl(dev, rank, world, timeout_s=timeout_s)
+    return "rccl"
+
+
 def init_rccl(dev: Device, rank, world, tag="id", timeout_s=180.0):
     """One process per GPU: rank 0 creates the ncclUniqueId and hands it to the others through exchange_unique_id(); everyone
     calls ncclCommInitRank through the library; a barrier; rank 0 removes the rendezvous files."""

@@ -1,0 +1,37 @@
+// qd_band.h -- structures shared by the transports of the latitude-band decomposition (qd_band.hip: RCCL, in-process group,
+// host ring; qd_peer.hip: device-side exchange over the peer mapping).
+#pragma once
+#include "qd_internal.h"
+#include <pthread.h>
+#include <atomic>
+
+#define QD_RING_MAXRANKS 64
+#define QD_RING_MAXVALS 8
+struct QdRingSeg {
+    std::atomic<unsigned long long> seq[QD_RING_MAXRANKS];
+    double vals[2][QD_RING_MAXRANKS][QD_RING_MAXVALS];
+};
+struct QdHostRing {
+    QdRingSeg* seg = nullptr;
+    int rank = 0, world = 1;
+    unsigned long long my_seq = 0;
+    bool mapped = false, owner = false;
+    std::string name;
+};
+
+struct QdLocalGroup {
+    std::vector<qd_ctx*> peers;
+    pthread_barrier_t bar;
+    std::vector<double> stage_d;        // [world][64]
+    std::vector<unsigned int> stage_u;  // [world][4096]
+    QdRingSeg ring;                     // the host ring of an in-process group lives in ordinary memory
+};
+
+// ---- qd_peer.hip: device-side exchange over the peer mapping (QD_PEER_EXCHANGE) -------------------------------------------
+struct QdPeer;
+bool qd_peer_on(const qd_ctx* c);
+int  qd_peer_halo(qd_ctx* c, const QdUse* slots, int n);                 // the ring halo exchange of qd_exchange
+int  qd_peer_allreduce(qd_ctx* c, void* dptr, int n, int kind);          // kind 0: f64 sum in rank order, 1: f64 max, 2: u32 sum
+int  qd_peer_allgather(qd_ctx* c, double* buf, int n_per_rank);          // buf[world][n_per_rank], own segment filled in
+int  qd_peer_init_group(QdLocalGroup* g);                                // in-process group: one mailbox per handle, pointers shared
+void qd_peer_release(qd_ctx* c);

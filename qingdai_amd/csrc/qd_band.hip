@@ -14,6 +14,7 @@
 // in-process group of handles on one device (device-to-device copies + a pthread barrier), used to
 // test the band logic on a single GPU.
 #include "qd_internal.h"
+#include "qd_band.h"
 #include <rccl/rccl.h>
 #include <pthread.h>
 #include <cstring>
@@ -32,19 +33,6 @@
 // in plain memory): every rank publishes its values under a sequence number, waits until all ranks have published that
 // sequence, and reduces the slots in rank order -- the same sum on every rank, bit for bit, in ~1-2 us.  Two buffers by
 // sequence parity: a rank can only be one call ahead of the slowest one, because call s + 1 needs everybody's s + 1.
-#define QD_RING_MAXRANKS 64
-#define QD_RING_MAXVALS 8
-struct QdRingSeg {
-    std::atomic<unsigned long long> seq[QD_RING_MAXRANKS];
-    double vals[2][QD_RING_MAXRANKS][QD_RING_MAXVALS];
-};
-struct QdHostRing {
-    QdRingSeg* seg = nullptr;
-    int rank = 0, world = 1;
-    unsigned long long my_seq = 0;
-    bool mapped = false, owner = false;
-    std::string name;
-};
 static_assert(std::atomic<unsigned long long>::is_always_lock_free, "the ring needs lock-free 64-bit atomics");
 
 static int ring_allreduce(QdHostRing* r, double* v, int n, int op, double timeout_s) {
@@ -124,13 +112,6 @@ extern "C" int qd_hostring_close(void* ring) {
 // perform the recorded exchanges itself (torch.distributed / gloo) on real arrays.
 struct QdPlanSim { std::vector<std::vector<int>> log; };
 
-struct QdLocalGroup {
-    std::vector<qd_ctx*> peers;
-    pthread_barrier_t bar;
-    std::vector<double> stage_d;        // [world][64]
-    std::vector<unsigned int> stage_u;  // [world][4096]
-    QdRingSeg ring;                     // the host ring of an in-process group lives in ordinary memory
-};
 
 // all-reduce of a few HOST doubles across the ranks of this handle's communicator; -1 when no host ring is attached
 int qd_host_allreduce(qd_ctx* c, double* v, int n, int op) {
@@ -212,7 +193,10 @@ int qd_exchange(qd_ctx* c, const QdUse* slots, int n) {
     if (nown < H) return qd_fail(c, "latitude band thinner than its halo");
     const int up = (rank + 1) % world, dn = (rank - 1 + world) % world;
     c->exchanges += 1;
-    if (c->comm) {
+    if (qd_peer_on(c)) {
+        // device-side exchange (qd_peer.hip): stores into the neighbours' mailboxes, no collective launch
+        if (qd_peer_halo(c, slots, n)) return -1;
+    } else if (c->comm) {
         ncclComm_t comm = (ncclComm_t)c->comm;
         ncclGroupStart();
         if (c->pending_sum) {                                 // a scalar sum nobody has needed yet rides in this group (qd_allreduce_sum_deferred)
@@ -287,6 +271,7 @@ int qd_allreduce_flush(qd_ctx* c) {
 int qd_allreduce_f64(qd_ctx* c, double* dptr, int n, int op) {
     if (c->geo.full) return 0;
     c->allreduces++;
+    if (qd_peer_on(c)) return qd_peer_allreduce(c, dptr, n, op ? 1 : 0);
     if (c->comm) {
         ncclResult_t r = ncclAllReduce(dptr, dptr, n, ncclDouble, op ? ncclMax : ncclSum, (ncclComm_t)c->comm, c->stream);
         if (r != ncclSuccess) { c->err = std::string("allreduce: ") + ncclGetErrorString(r); return -1; }
@@ -314,9 +299,18 @@ int qd_allreduce_f64(qd_ctx* c, double* dptr, int n, int op) {
 }
 
 #define QD_LOCAL_U32_MAX (64 * 2 * 4096)        // the gathered median segments of up to 64 in-process bands
+// buf[world][n_per_rank] with this rank's segment filled in -> every segment everywhere.  Transports without a gather of their own
+// all-reduce the zero-padded buffer as integers (x + 0 + ... + 0 is exact): the caller clears the other segments first.
+int qd_allgather_f64(qd_ctx* c, double* buf, int n_per_rank) {
+    if (c->geo.full) return 0;
+    if (qd_peer_on(c)) { c->allreduces++; return qd_peer_allgather(c, buf, n_per_rank); }
+    return qd_allreduce_u32(c, (unsigned int*)buf, 2 * c->desc.world * n_per_rank);
+}
+
 int qd_allreduce_u32(qd_ctx* c, unsigned int* dptr, int n) {
     if (c->geo.full) return 0;
     c->allreduces++;
+    if (qd_peer_on(c)) return qd_peer_allreduce(c, dptr, n, 2);
     if (c->comm) {
         ncclResult_t r = ncclAllReduce(dptr, dptr, n, ncclUint32, ncclSum, (ncclComm_t)c->comm, c->stream);
         if (r != ncclSuccess) { c->err = std::string("allreduce: ") + ncclGetErrorString(r); return -1; }
@@ -373,6 +367,10 @@ extern "C" int qd_comm_init_local(qd_handle* handles, int n) {
         handles[k]->lgroup = g;
     }
     for (int q = 0; q < QD_RING_MAXRANKS; ++q) g->ring.seq[q].store(0ull);
+    // QD_PEER_EXCHANGE=1: halos and reductions of the group go through the device-side mailboxes (qd_peer.hip); no host ring then
+    // (the ring would take the eta sums and CFL maxima away from the path under test)
+    const char* pe = std::getenv("QD_PEER_EXCHANGE");
+    if (pe && pe[0] == '1') return qd_peer_init_group(g);
     if (!std::getenv("QD_NO_HOST_RING"))
         for (int k = 0; k < n; ++k) {
             QdHostRing* r = new QdHostRing();
@@ -397,6 +395,7 @@ extern "C" int qd_comm_init_shm(qd_handle c, const char* name) {
 }
 // called by qd_destroy: communicator, host ring and (by the last peer) the in-process group
 void qd_comm_release(qd_ctx* c) {
+    qd_peer_release(c);
     if (c->comm) { ncclCommDestroy((ncclComm_t)c->comm); c->comm = nullptr; }
     if (c->hring) {
         QdHostRing* r = (QdHostRing*)c->hring;
@@ -416,7 +415,7 @@ extern "C" int qd_comm_host_allreduce_count(qd_handle c, int* n) { if (!c || !n)
 
 extern "C" int qd_comm_allreduce_max(qd_handle c, double* inout, int n) {
     if (!c || !inout || n < 1 || n > 8) return -1;
-    if (c->geo.full || (!c->comm && !c->lgroup)) return 0;     // single process: identity
+    if (c->geo.full || (!c->comm && !c->lgroup && !qd_peer_on(c))) return 0;     // single process: identity
     hipSetDevice(c->desc.device);
     double* d = c->dscal + QD_S_TMP0 + 2;
     QD_HIP(c, hipMemcpyAsync(d, inout, n * sizeof(double), hipMemcpyHostToDevice, c->stream));

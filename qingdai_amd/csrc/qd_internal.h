@@ -234,6 +234,7 @@ struct qd_ctx {
     // comm
     void* comm = nullptr;          // RCCL communicator (one process per GPU)
     struct QdLocalGroup* lgroup = nullptr;   // in-process peers on one device (tests of the band logic)
+    struct QdPeer* peer = nullptr;           // device-side exchange over the peer mapping (qd_peer.hip, QD_PEER_EXCHANGE)
     std::vector<struct QdUse> corefresh;   // slabs refreshed along with any halo exchange that happens anyway (set around loops)
     int exchanges = 0;             // statistics
     int allreduces = 0;
@@ -293,6 +294,8 @@ QdSegs qd_segments(qd_ctx* c, int margin);
 int qd_exchange(qd_ctx* c, const QdUse* slots, int n);
 int qd_allreduce_f64(qd_ctx* c, double* dptr, int n, int op);          // op 0 sum, 1 max (device scalars)
 int qd_allreduce_u32(qd_ctx* c, unsigned int* dptr, int n);            // sum
+int qd_allgather_f64(qd_ctx* c, double* buf, int n_per_rank);          // buf[world][n_per_rank]: own segment in, every segment out
+bool qd_peer_on(const qd_ctx* c);                                      // qd_peer.hip: the device-side exchange carries this handle's traffic
 int qd_host_allreduce(qd_ctx* c, double* host_vals, int n, int op);    // op 0 sum, 1 max; HOST scalars through the host ring
 bool qd_has_host_ring(const qd_ctx* c);
 extern "C" int qd_hostring_close(void* ring);

@@ -902,12 +902,12 @@ int qd_median_positive_dev(qd_ctx* c, const double* x, double dflt, int slot, in
         hipLaunchKernelGGL(k_med_hist, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, bpred, c->hist, 1);
         if (qd_allreduce_u32(c, c->hist, QD_HIST_BINS + 2)) return -1;
         hipLaunchKernelGGL(k_med_hist, dim3(1, 1), dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, bpred, c->hist, 2);
-        QD_HIP(c, hipMemsetAsync(c->med_gather, 0, (size_t)world * segd * sizeof(double), c->stream));
+        if (!qd_peer_on(c)) QD_HIP(c, hipMemsetAsync(c->med_gather, 0, (size_t)world * segd * sizeof(double), c->stream));
         double* seg = c->med_gather + (size_t)rank * segd;
         hipLaunchKernelGGL(k_med_bracket, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, bpred + 8, c->sel_state,
                            seg + 4, c->sel_ccount, cap);
         hipLaunchKernelGGL(k_med_pack, dim3(1), dim3(64), 0, c->stream, c->sel_state, c->sel_ccount, seg);
-        if (qd_allreduce_u32(c, (unsigned int*)c->med_gather, (int)(2 * world * segd))) return -1;     // x + 0 + ... + 0: exact
+        if (qd_allgather_f64(c, c->med_gather, (int)segd)) return -1;
         hipLaunchKernelGGL(k_med_final, dim3(1), dim3(QD_FIN_BLOCK), 0, c->stream, c->sel_state, c->med_gather, c->sel_ccount, bpred, x,
                            0ull, transform, tparam, dflt, c->dscal + slot, c->dcount, world, cap, c->dscal + QD_S_TMP1, (unsigned int*)nullptr);
         QD_HIP(c, hipMemcpyAsync(c->hpin + 32, c->dscal + QD_S_TMP1, sizeof(double), hipMemcpyDeviceToHost, c->stream));
