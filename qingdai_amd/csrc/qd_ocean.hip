@@ -21,6 +21,7 @@
 #include "qd_fluxes.h"
 #include "qd_fused.h"
 #include "qd_ocntail.h"
+#include "qd_band.h"
 
 QdColP qd_make_colp(const qd_ctx* c, double dt);   // qd_atmos.hip
 
@@ -915,16 +916,20 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
                 A.own0 = c->own_row0; A.own1 = c->own_row0 + c->own_nrows;
                 QdSegs S = qd_segments(c, m);
                 size_t off = 0;
+                // peer exchange: the finishing wave of the owned segment's launch all-reduces the band's share itself (no launch)
+                QdPeerFold pf;
+                const bool folded = qd_peer_fold_begin(c, &pf);
                 for (int k = 0; k < S.n; ++k) {
                     const QdGeom& Gs = S.g[k];
                     const bool owned = Gs.row0 <= c->own_row0 && c->own_row0 < Gs.row0 + Gs.nrows;      // the segment that holds the band's own rows
                     A.acc = owned ? c->eta_acc : nullptr;
+                    A.pf = owned ? pf : QdPeerFold();
                     A.partial = c->red_partial + off;
                     if (qd_launch_ocn_tail(c, Gs, A)) return -1;
                     off += (size_t)qd_ocn_tail_tiles(c, Gs);
                 }
                 // first read by the NEXT momentum kernel: if that kernel's inputs need a halo exchange, the sum rides in its group
-                if (qd_allreduce_sum_deferred(c, c->dscal + QD_S_ETA_MEAN)) return -1;
+                if (!folded && qd_allreduce_sum_deferred(c, c->dscal + QD_S_ETA_MEAN)) return -1;
                 qd_mark(c, {F[QD_F_ETA], A.Ts_out, A.uo_out, A.vo_out}, m);
             } else {
             if (qd_launch_ocn_tail(c, Gown, A)) return -1;

@@ -1,6 +1,7 @@
 // qd_ocntail.h -- argument block of k_ocn_tail (qd_ocntail.hip): the second half of an ocean sub-step in one launch
 #pragma once
 #include "qd_internal.h"
+#include "qd_peer_dev.h"
 
 struct QdTailArgs {
     const double *uo, *vo, *Ts, *qnet;
@@ -15,6 +16,7 @@ struct QdTailArgs {
     int use_q, has_ice, mean4, ntc, R, Rp;                   // R: strip height of the streaming forms; Rp: height of a pole strip (k_ocn_tail_fast)
     int nmid, flags;                                         // k_ocn_tail_fast: strips between the pole strips; bit0 = every wave takes the general form
     int own0, own1;                                          // rows whose eta enters the area-weighted sum (a band's owned rows; set by the launcher for whole-globe handles)
+    QdPeerFold pf;                                           // latitude bands over the peer exchange: the finishing wave all-reduces the band's share itself (qd_peer_dev.h)
 };
 
 int qd_ocn_tail_tiles(const qd_ctx* c, const QdGeom& G);

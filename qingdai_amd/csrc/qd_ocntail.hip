@@ -453,7 +453,8 @@ k_ocn_tail_stream(QdGeom G, QdTabs T, QdTailArgs P) {
     if (P.acc) {                                             // eta mean inside this launch: the last workgroup to arrive finishes it
         const bool last = W.lane == 0 && qd_acc_arrive(P.acc, w, gridDim.x, acc);
         if (__builtin_amdgcn_ballot_w64(last) != 0ull) {
-            const double m = qd_acc_finish(P.acc, P.partial, (int)gridDim.x, P.wsum);
+            double m = qd_acc_finish(P.acc, P.partial, (int)gridDim.x, P.wsum);
+            if (P.pf.pbox) m = qp_fold_sum(P.pf, m);          // bands over the peer exchange: the sum over the ranks, here and now
             if (W.lane == 0) *P.mean_out = m;
         }
     }
@@ -755,7 +756,8 @@ k_ocn_tail_fast(QdGeom G, QdTabs T, QdTailArgs P) {
     if (P.acc) {                                             // eta mean inside this launch: the last workgroup to arrive finishes it
         const bool last = W.lane == 0 && qd_acc_arrive(P.acc, w, gridDim.x, acc);
         if (__builtin_amdgcn_ballot_w64(last) != 0ull) {
-            const double mm = qd_acc_finish(P.acc, P.partial, (int)gridDim.x, P.wsum);
+            double mm = qd_acc_finish(P.acc, P.partial, (int)gridDim.x, P.wsum);
+            if (P.pf.pbox) mm = qp_fold_sum(P.pf, mm);        // bands over the peer exchange: the sum over the ranks, here and now
             if (W.lane == 0) *P.mean_out = mm;
         }
     }

@@ -9,8 +9,8 @@
 // POLL their own:
 //
 //   halo exchange   k_halo_push copies my H top rows of every slab of the exchange into `up`'s mailbox (staging area "from the
-//                   south") and my H bottom rows into `dn`'s ("from the north"), then bumps an arrival counter there;
-//                   k_halo_unpack waits until both of MY counters have reached the exchange's count and copies the staged rows
+//                   south") and my H bottom rows into `dn`'s ("from the north"), then publishes the exchange's number there;
+//                   k_halo_unpack waits until both of MY flags carry the exchange's number and copies the staged rows
 //                   into my slabs' halo rows.  Whatever the stream runs between the two launches overlaps the transfer
 //                   (qd_band.hip launches the consumer's INTERIOR rows there).
 //   scalar / histogram all-reduce, all-gather   k_peer_reduce: every rank deposits its n values in slot [rank] of EVERY mailbox,
@@ -23,10 +23,10 @@
 // buffer s % 2 with exchange s + 2 before it has been consumed.  (Every exchange is the symmetric ring exchange, every reduction
 // involves all ranks, and all ranks issue the same sequence of them: they run the same program on the same global scalars.)
 //
-// Memory model: data stores, then __threadfence_system() (release: L2 write-back of what is not already written through),
-// workgroup barrier, ONE system-scope atomic add on the consumer's counter; the consumer polls with system-scope atomic loads, then
-// fences (acquire) before it reads.  The mailbox is allocated fine-grained (hipDeviceMallocFinegrained: stores write through, loads
-// do not linger in L2), so the fences have nothing to flush.  Every poll loop has a deadline (QP_TIMEOUT_S of s_memrealtime): a
+// Memory model: data stores, release (qd_peer_dev.h: qp_release), workgroup barrier, ONE system-scope atomic on the consumer's flag
+// or counter; the consumer polls with system-scope atomic loads, then acquires (qp_acquire) before it reads.  The mailbox is
+// allocated fine-grained (hipDeviceMallocFinegrained: stores write through, loads do not linger in L2), which is what lets release
+// be a wait for the store acknowledgements instead of an L2 write-back.  Every poll loop has a deadline (QP_TIMEOUT_S of s_memrealtime): a
 // rank that never arrives turns into an error word in pinned host memory and a failed qd_* call, never into a hung GPU.
 //
 // In-process groups (N band handles on one device, one host thread each: the test vehicle) run the same kernels in two launches
@@ -34,16 +34,14 @@
 // that sits BEHIND it in a shared hardware queue (HIP multiplexes streams onto a few of those).
 #include "qd_internal.h"
 #include "qd_band.h"
+#include "qd_peer_dev.h"
 #include <cstring>
 #include <algorithm>
 
 #define QP_MAXSLABS 16
 #define QP_RV 4104                      // 8-byte units per rank slot of a reduction (median segment: 4096 + 4)
-#define QP_HDR 4096                     // header: arrival counters
-#define QP_OFF_HCNT 0                   // u64[2]: blocks of pushes arrived for my south halo (from dn) / my north halo (from up)
-#define QP_OFF_RCNT 512                 // u64[world]: blocks of deposits arrived from rank q
-#define QP_PUSH_BLOCKS 64
-#define QP_TIMEOUT_S 20.0
+#define QP_PART_BYTES 16384             // bytes of a halo segment one workgroup copies
+#define QP_MAX_PARTS 32
 
 struct QdPeerHalo {
     void* slab[QP_MAXSLABS];
@@ -58,10 +56,13 @@ struct QdPeer {
     char* pbox[QD_RING_MAXRANKS] = {nullptr};     // every rank's mailbox as THIS process maps it ([rank] == box)
     bool opened[QD_RING_MAXRANKS] = {false};      // mapped through hipIpcOpenMemHandle (to be closed)
     char** d_pbox = nullptr;                      // the same table on the device
-    unsigned long long hseq = 0, hexp = 0;        // halo exchanges so far, arrival count every exchange so far adds up to
+    unsigned long long hseq = 0;                  // halo exchanges so far
+    unsigned int* tick = nullptr;                 // ticket word of the push launches (ordinary device memory)
     unsigned long long rseq = 0, rexp = 0;        // reductions so far, deposits per source rank so far
     double* herr = nullptr;                       // pinned host word: a poll loop ran into its deadline
     long n_halo = 0, n_reduce = 0;
+    int coarse = 0;                               // QD_PEER_COARSE=1: mailbox in ordinary device memory, full fences in the kernels
+    int fold = 1;                                 // QD_PEER_FOLD=0: the eta sum of a sub-step as a k_peer_reduce launch of its own
     bool pushed = false;                          // a push is out whose unpack has not been launched yet
     QdPeerHalo pend;                              // its slabs
 };
@@ -69,54 +70,73 @@ struct QdPeer {
 bool qd_peer_on(const qd_ctx* c) { return c->peer && c->peer->on; }
 
 // ------------------------------------------------------------------ device side
-__device__ __forceinline__ bool qp_wait(const unsigned long long* p, unsigned long long expect, double* herr) {
-    const unsigned long long t0 = wall_clock64();                       // s_memrealtime: 100 MHz
-    const unsigned long long limit = (unsigned long long)(QP_TIMEOUT_S * 1.0e8);
-    while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < expect) {
-        __builtin_amdgcn_s_sleep(4);
-        if (wall_clock64() - t0 > limit) { *(volatile double*)herr = 1.0; return false; }
+// One (slab, direction) segment of an exchange is H rows; a launch is a 2-D grid: blockIdx.y = 2 k + direction, blockIdx.x = one of
+// nbx contiguous parts of the segment, four accesses in flight per lane.
+// Every access to a MAILBOX is a system-scope atomic (relaxed) load or store of 8 bytes (single bytes for u8 slabs whose rows are
+// not 8-byte aligned): such accesses go to the point of coherence whatever memory type the mapping has.  That matters between
+// processes: a mailbox is allocated fine-grained, but the mapping hipIpcOpenMemHandle hands to ANOTHER process behaves like ordinary
+// (coarse-grained, L2-cached) memory -- with plain stores and a wait for their acknowledgement, rank processes on one GPU read stale
+// halo rows (the in-process groups, which share the owner's own pointer, did not); and a full release fence per workgroup writes back
+// the whole L2, which the kernel before an exchange has just filled with the band (28 us for a push of 2 x 5.9 MB, 7 us like this).
+template <typename T, bool PUT>
+__device__ __forceinline__ void qp_copy_t(char* dst, const char* src, size_t bytes, int part, int nparts) {
+    const size_t n = bytes / sizeof(T);
+    const size_t per = (n + nparts - 1) / nparts;
+    const size_t i0 = (size_t)part * per, i1 = i0 + per < n ? i0 + per : n;
+    T* d = (T*)dst; const T* q = (const T*)src;
+    auto ld = [&](size_t i) -> T { return PUT ? q[i] : __hip_atomic_load(q + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+    auto st = [&](size_t i, T v) { if (PUT) __hip_atomic_store(d + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); else d[i] = v; };
+    size_t i = i0 + threadIdx.x;
+    for (; i + 3 * blockDim.x < i1; i += 4 * blockDim.x) {
+        const T a = ld(i), b = ld(i + blockDim.x), c = ld(i + 2 * blockDim.x), e = ld(i + 3 * blockDim.x);
+        st(i, a); st(i + blockDim.x, b); st(i + 2 * blockDim.x, c); st(i + 3 * blockDim.x, e);
     }
-    return true;
+    for (; i < i1; i += blockDim.x) st(i, ld(i));
+}
+// PUT: plain loads from a slab, atomic stores into a mailbox; !PUT: atomic loads from my mailbox, plain stores into a slab
+template <bool PUT>
+__device__ __forceinline__ void qp_copy(char* dst, const char* src, size_t bytes, int part, int nparts) {
+    const unsigned long long al = (unsigned long long)dst | (unsigned long long)src | (unsigned long long)bytes;
+    if ((al & 7ull) == 0) qp_copy_t<unsigned long long, PUT>(dst, src, bytes, part, nparts);
+    else qp_copy_t<unsigned char, PUT>(dst, src, bytes, part, nparts);
 }
 
-// copy of H rows per slab and direction: f64 slabs as doubles, u8 slabs as bytes
-__device__ __forceinline__ void qp_copy(char* dst, const char* src, size_t n_el, int u8, size_t tid, size_t nth) {
-    if (u8) { for (size_t i = tid; i < n_el; i += nth) dst[i] = src[i]; }
-    else { double* d = (double*)dst; const double* s = (const double*)src; for (size_t i = tid; i < n_el; i += nth) d[i] = s[i]; }
-}
-
+// `tick`: a word in this device's ordinary memory; the workgroup that takes the last ticket of the launch knows that every other
+// workgroup's stores are out (each fenced at system scope before it took its ticket) and publishes the exchange's sequence number in
+// both neighbours' mailboxes -- ONE remote store per direction instead of an atomic per workgroup.
 __global__ void __launch_bounds__(256)
-k_halo_push(QdPeerHalo A, char* up_south, char* dn_north, size_t slab_stride, unsigned long long* up_cnt, unsigned long long* dn_cnt) {
-    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
-    const size_t n_el = (size_t)A.H * A.nlon;
-    for (int k = 0; k < A.n; ++k) {
-        const size_t esz = A.u8[k] ? 1 : sizeof(double);
-        const char* base = (const char*)A.slab[k];
-        qp_copy(up_south + k * slab_stride, base + (size_t)A.nown * A.nlon * esz, n_el, A.u8[k], tid, nth);    // my top rows -> up's south halo
-        qp_copy(dn_north + k * slab_stride, base + (size_t)A.H * A.nlon * esz, n_el, A.u8[k], tid, nth);       // my bottom rows -> dn's north halo
-    }
-    __threadfence_system();
+k_halo_push(QdPeerHalo A, char* up_south, char* dn_north, size_t slab_stride, unsigned long long* up_flag, unsigned long long* dn_flag,
+            unsigned long long seq, unsigned int* tick, int coarse) {
+    const int k = blockIdx.y >> 1, dir = blockIdx.y & 1;
+    const size_t esz = A.u8[k] ? 1 : sizeof(double);
+    const size_t bytes = (size_t)A.H * A.nlon * esz;
+    const char* base = (const char*)A.slab[k];
+    if (dir == 0) qp_copy<true>(up_south + k * slab_stride, base + (size_t)A.nown * A.nlon * esz, bytes, blockIdx.x, gridDim.x);   // my top rows -> up's south halo
+    else qp_copy<true>(dn_north + k * slab_stride, base + (size_t)A.H * A.nlon * esz, bytes, blockIdx.x, gridDim.x);               // my bottom rows -> dn's north halo
+    qp_release(coarse);
     __syncthreads();
     if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(up_cnt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_fetch_add(dn_cnt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned int nb = gridDim.x * gridDim.y;
+        if (__hip_atomic_fetch_add(tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nb - 1u) {
+            __hip_atomic_store(tick, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(up_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(dn_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
 __global__ void __launch_bounds__(256)
-k_halo_unpack(QdPeerHalo A, const char* my_south, const char* my_north, size_t slab_stride, const unsigned long long* cnt,
-              unsigned long long expect, double* herr) {
-    if (threadIdx.x == 0) { qp_wait(cnt, expect, herr); qp_wait(cnt + 1, expect, herr); }
+k_halo_unpack(QdPeerHalo A, const char* my_south, const char* my_north, size_t slab_stride, const unsigned long long* flag,
+              unsigned long long expect, double* herr, int coarse) {
+    const int k = blockIdx.y >> 1, dir = blockIdx.y & 1;
+    if (threadIdx.x == 0) qp_wait(flag + dir, expect, herr);
     __syncthreads();
-    __threadfence_system();
-    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
-    const size_t n_el = (size_t)A.H * A.nlon;
-    for (int k = 0; k < A.n; ++k) {
-        const size_t esz = A.u8[k] ? 1 : sizeof(double);
-        char* base = (char*)A.slab[k];
-        qp_copy(base, my_south + k * slab_stride, n_el, A.u8[k], tid, nth);                                       // my south halo <- dn's top rows
-        qp_copy(base + (size_t)(A.H + A.nown) * A.nlon * esz, my_north + k * slab_stride, n_el, A.u8[k], tid, nth);   // my north halo <- up's bottom rows
-    }
+    qp_acquire(coarse);
+    const size_t esz = A.u8[k] ? 1 : sizeof(double);
+    const size_t bytes = (size_t)A.H * A.nlon * esz;
+    char* base = (char*)A.slab[k];
+    if (dir == 0) qp_copy<false>(base, my_south + k * slab_stride, bytes, blockIdx.x, gridDim.x);                                     // my south halo <- dn's top rows
+    else qp_copy<false>(base + (size_t)(A.H + A.nown) * A.nlon * esz, my_north + k * slab_stride, bytes, blockIdx.x, gridDim.x);     // my north halo <- up's bottom rows
 }
 
 // OP 0: f64 sum in rank order, 1: f64 max, 2: u32 sum (two per 8-byte unit), 3: gather (data[q][n8] <- slot q).
@@ -125,15 +145,15 @@ k_halo_unpack(QdPeerHalo A, const char* my_south, const char* my_north, size_t s
 template <int OP>
 __global__ void __launch_bounds__(256)
 k_peer_reduce(char* const* __restrict__ pbox, int world, int rank, size_t off_rv, size_t rv_stride, int parity, unsigned long long* data,
-              int n8, int per, unsigned long long expect, int phase, double* herr) {
+              int n8, int per, unsigned long long expect, int phase, double* herr, int coarse) {
     const int i0 = blockIdx.x * per, i1 = min(n8, i0 + per);
     if (phase & 1) {
         const unsigned long long* src = OP == 3 ? data + (size_t)rank * n8 : data;
         for (int q = 0; q < world; ++q) {
             unsigned long long* dst = (unsigned long long*)(pbox[q] + off_rv + ((size_t)parity * world + rank) * rv_stride);
-            for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) dst[i] = src[i];
+            for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
-        __threadfence_system();
+        qp_release(coarse);
         __syncthreads();
         if ((int)threadIdx.x < world)
             __hip_atomic_fetch_add((unsigned long long*)(pbox[threadIdx.x] + QP_OFF_RCNT) + rank, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -141,23 +161,23 @@ k_peer_reduce(char* const* __restrict__ pbox, int world, int rank, size_t off_rv
     if (phase & 2) {
         if ((int)threadIdx.x < world) qp_wait((const unsigned long long*)(pbox[rank] + QP_OFF_RCNT) + threadIdx.x, expect, herr);
         __syncthreads();
-        __threadfence_system();
+        qp_acquire(coarse);
         const char* base = pbox[rank] + off_rv + (size_t)parity * world * rv_stride;
         for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
             if (OP == 3) {
-                for (int q = 0; q < world; ++q) data[(size_t)q * n8 + i] = ((const unsigned long long*)(base + q * rv_stride))[i];
+                for (int q = 0; q < world; ++q) data[(size_t)q * n8 + i] = qp_ld((const unsigned long long*)(base + q * rv_stride) + i);
             } else if (OP == 2) {
-                unsigned long long a = ((const unsigned long long*)base)[i];
+                unsigned long long a = qp_ld((const unsigned long long*)base + i);
                 unsigned int lo = (unsigned int)a, hi = (unsigned int)(a >> 32);
                 for (int q = 1; q < world; ++q) {
-                    const unsigned long long b = ((const unsigned long long*)(base + q * rv_stride))[i];
+                    const unsigned long long b = qp_ld((const unsigned long long*)(base + q * rv_stride) + i);
                     lo += (unsigned int)b; hi += (unsigned int)(b >> 32);
                 }
                 data[i] = (unsigned long long)lo | ((unsigned long long)hi << 32);
             } else {
-                double a = ((const double*)base)[i];
+                double a = __longlong_as_double((long long)qp_ld((const unsigned long long*)base + i));
                 for (int q = 1; q < world; ++q) {
-                    const double b = ((const double*)(base + q * rv_stride))[i];
+                    const double b = __longlong_as_double((long long)qp_ld((const unsigned long long*)(base + q * rv_stride) + i));
                     a = OP == 1 ? (b > a ? b : a) : a + b;
                 }
                 ((double*)data)[i] = a;
@@ -196,7 +216,8 @@ static int qp_alloc(qd_ctx* c) {
     // fine-grained device memory: remote stores write through, polls see them without a cache flush.  QD_PEER_COARSE=1 (developer
     // switch) takes ordinary device memory instead; the fences in the kernels keep that correct, just slower.
     const char* co = std::getenv("QD_PEER_COARSE");
-    hipError_t e = (co && co[0] == '1') ? hipMalloc((void**)&P->box, P->box_bytes)
+    P->coarse = (co && co[0] == '1') ? 1 : 0;
+    hipError_t e = P->coarse ? hipMalloc((void**)&P->box, P->box_bytes)
                                         : hipExtMallocWithFlags((void**)&P->box, P->box_bytes, hipDeviceMallocFinegrained);
     if (e != hipSuccess) { delete P; return qd_fail(c, "peer exchange: mailbox allocation", e); }
     if ((e = hipMemset(P->box, 0, P->box_bytes)) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) {
@@ -205,6 +226,10 @@ static int qp_alloc(qd_ctx* c) {
     if ((e = hipMalloc((void**)&P->d_pbox, sizeof(char*) * QD_RING_MAXRANKS)) != hipSuccess) {
         hipFree(P->box); delete P; return qd_fail(c, "peer exchange: table allocation", e);
     }
+    if ((e = hipMalloc((void**)&P->tick, 64)) != hipSuccess || (e = hipMemset(P->tick, 0, 64)) != hipSuccess) {
+        hipFree(P->d_pbox); hipFree(P->box); delete P; return qd_fail(c, "peer exchange: ticket allocation", e);
+    }
+    { const char* ef = std::getenv("QD_PEER_FOLD"); if (ef && ef[0] == '0') P->fold = 0; }
     P->pbox[P->rank] = P->box;
     P->herr = c->hpin + 60;
     *P->herr = 0.0;
@@ -228,6 +253,7 @@ void qd_peer_release(qd_ctx* c) {
     hipSetDevice(c->desc.device);
     for (int q = 0; q < P->world; ++q) if (P->opened[q] && P->pbox[q]) hipIpcCloseMemHandle(P->pbox[q]);
     if (P->d_pbox) hipFree(P->d_pbox);
+    if (P->tick) hipFree(P->tick);
     if (P->box) hipFree(P->box);
     delete P;
 }
@@ -245,6 +271,11 @@ int qd_peer_init_group(QdLocalGroup* g) {
 }
 
 // ---- halo exchange: push now, unpack when the caller says so (qd_peer_halo = both at once)
+static dim3 qp_halo_grid(const qd_ctx* c, int n) {
+    const size_t seg = (size_t)c->geo.halo * c->geo.nlon * sizeof(double);
+    const int nbx = (int)std::min<size_t>(QP_MAX_PARTS, std::max<size_t>(1, seg / QP_PART_BYTES));
+    return dim3(nbx, 2 * n);
+}
 static int qp_halo_push(qd_ctx* c, const QdUse* slots, int n) {
     QdPeer* P = c->peer;
     if (P->pushed) return qp_fail(c, "peer exchange: a halo push is still waiting for its unpack");
@@ -253,11 +284,12 @@ static int qp_halo_push(qd_ctx* c, const QdUse* slots, int n) {
     A.n = n; A.H = c->geo.halo; A.nown = c->own_nrows; A.nlon = c->geo.nlon;
     for (int k = 0; k < n; ++k) { A.slab[k] = *slots[k].slot; A.u8[k] = slots[k].u8 ? 1 : 0; }
     const int par = (int)(P->hseq & 1ull);
-    P->hseq += 1; P->hexp += QP_PUSH_BLOCKS; P->n_halo += 1;
+    P->hseq += 1; P->n_halo += 1;
     char* up_south = P->pbox[P->up] + P->off_stage + par * P->par_stride;                      // dir 0: "from the south"
     char* dn_north = P->pbox[P->dn] + P->off_stage + par * P->par_stride + P->dir_stride;      // dir 1: "from the north"
-    hipLaunchKernelGGL(k_halo_push, dim3(QP_PUSH_BLOCKS), dim3(256), 0, c->stream, A, up_south, dn_north, P->slab_stride,
-                       (unsigned long long*)(P->pbox[P->up] + QP_OFF_HCNT), (unsigned long long*)(P->pbox[P->dn] + QP_OFF_HCNT) + 1);
+    hipLaunchKernelGGL(k_halo_push, qp_halo_grid(c, n), dim3(256), 0, c->stream, A, up_south, dn_north, P->slab_stride,
+                       (unsigned long long*)(P->pbox[P->up] + QP_OFF_HCNT), (unsigned long long*)(P->pbox[P->dn] + QP_OFF_HCNT) + 1,
+                       P->hseq, P->tick, P->coarse);
     P->pushed = true;
     return 0;
 }
@@ -269,8 +301,8 @@ static int qp_halo_unpack(qd_ctx* c) {
     const int par = (int)((P->hseq - 1) & 1ull);
     const char* my_south = P->box + P->off_stage + par * P->par_stride;
     const char* my_north = my_south + P->dir_stride;
-    hipLaunchKernelGGL(k_halo_unpack, dim3(QP_PUSH_BLOCKS), dim3(256), 0, c->stream, P->pend, my_south, my_north, P->slab_stride,
-                       (const unsigned long long*)(P->box + QP_OFF_HCNT), P->hexp, P->herr);
+    hipLaunchKernelGGL(k_halo_unpack, qp_halo_grid(c, P->pend.n), dim3(256), 0, c->stream, P->pend, my_south, my_north, P->slab_stride,
+                       (const unsigned long long*)(P->box + QP_OFF_HCNT), P->hseq, P->herr, P->coarse);
     P->pushed = false;
     return qp_check(c);
 }
@@ -292,7 +324,7 @@ template <int OP>
 static void qp_launch_reduce(qd_ctx* c, unsigned long long* data, int n8, int nb, int per, int par, int phase) {
     QdPeer* P = c->peer;
     hipLaunchKernelGGL(k_peer_reduce<OP>, dim3(nb), dim3(256), 0, c->stream, (char* const*)P->d_pbox, P->world, P->rank, P->off_rv,
-                       P->rv_stride, par, data, n8, per, P->rexp, phase, P->herr);
+                       P->rv_stride, par, data, n8, per, P->rexp, phase, P->herr, P->coarse);
 }
 
 static int qp_reduce(qd_ctx* c, unsigned long long* data, int n8, int op) {
@@ -313,6 +345,22 @@ static int qp_reduce(qd_ctx* c, unsigned long long* data, int n8, int op) {
     if (P->local) { launch(1); pthread_barrier_wait(&c->lgroup->bar); launch(2); }
     else launch(3);
     return qp_check(c);
+}
+
+// A one-double sum whose producer can finish it inside its own launch (qd_peer_dev.h: qp_fold_sum): hands out the argument block
+// and books the reduction; false (and an empty block) when the caller has to issue qd_allreduce_* itself -- in-process groups keep
+// the two-launch form (a wave that polls inside a compute kernel could wait for a deposit queued BEHIND it in a shared hardware queue).
+bool qd_peer_fold_begin(qd_ctx* c, QdPeerFold* F) {
+    *F = QdPeerFold();
+    QdPeer* P = c->peer;
+    if (!P || !P->on || P->local || !P->fold) return false;
+    F->pbox = (char* const*)P->d_pbox; F->herr = P->herr;
+    F->off_rv = (unsigned int)P->off_rv; F->rv_stride = (unsigned int)P->rv_stride;
+    F->world = P->world; F->rank = P->rank; F->parity = (int)(P->rseq & 1ull); F->coarse = P->coarse;
+    P->rseq += 1; P->rexp += 1ull; P->n_reduce += 1;
+    F->expect = P->rexp;
+    c->allreduces++;
+    return true;
 }
 
 int qd_peer_allreduce(qd_ctx* c, void* dptr, int n, int kind) {
