@@ -1,5 +1,7 @@
 // qd_api.hip -- the C-ABI of include/qingdai_hip.h: context, memory, tables, operator seam.
 #include "qd_internal.h"
+#include <chrono>
+#include <atomic>
 #include <cstring>
 #include <cstdio>
 #include <cstdlib>
@@ -231,6 +233,45 @@ static double host_qsat(double T, double p0) {
     return std::min(std::max(0.622 * e_s / denom, 0.0), 0.5);
 }
 
+
+// ------------------------------------------------------------------ small device -> host hand-overs without a stream sync
+int qd_wait_host_flag(qd_ctx* c, volatile double* flag, double seq, const char* what) {
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (*flag != seq) {
+        __builtin_ia32_pause();
+        if ((++spins & 0x3FFFu) == 0) {
+            // a stream that is no longer "not ready" cannot deliver the flag any more: either it drained without writing it, or a
+            // kernel faulted (sticky error) -- report that error instead of spinning out the timeout
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q != hipErrorNotReady && *flag != seq) return qd_fail(c, what, q);
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 60.0) return qd_fail(c, what);
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return 0;
+}
+
+
+// n <= 32 device doubles into pinned host memory behind a stamp (system-scope stores; the stamp leaves after the values have been
+// acknowledged): what the host needs to decide its next launches (CFL maxima -> n_sub, the miss flag of a band's median).
+__global__ void k_publish_host(const double* __restrict__ src, int n, double* dst, double* stamp, double seq) {
+    if ((int)threadIdx.x < n)
+        __hip_atomic_store((unsigned long long*)dst + threadIdx.x, (unsigned long long)__double_as_longlong(src[threadIdx.x]), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0)
+        __hip_atomic_store((unsigned long long*)stamp, (unsigned long long)__double_as_longlong(seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+int qd_fetch_scalars(qd_ctx* c, const double* dsrc, int n, double* hdst) {
+    if (n < 1 || n > 32) return qd_fail(c, "qd_fetch_scalars: bad count");
+    c->pub_seq += 1.0;
+    hipLaunchKernelGGL(k_publish_host, dim3(1), dim3(64), 0, c->stream, dsrc, n, hdst, c->hpin + 61, c->pub_seq);
+    if (qd_wait_host_flag(c, c->hpin + 61, c->pub_seq, "device scalars never reached the host")) return -1;
+    if (c->hpin[60] != 0.0) return qd_fail(c, "peer exchange: a rank did not arrive within the deadline");
+    return 0;
+}
+
 // ------------------------------------------------------------------ lifetime
 extern "C" int qd_abi_version(void) { return QD_ABI_VERSION; }
 extern "C" int qd_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
@@ -312,8 +353,9 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
         { const char* ef = std::getenv("QD_MERGE_POINTWISE"); if (ef) c->merge_pointwise = ef[0] == '0' ? 0 : 1; }
         { const char* ef = std::getenv("QD_HOIST_PRECIP"); if (ef) c->hoist_precip = ef[0] == '0' ? 0 : 1; }
     }
-    if ((e = hipHostMalloc((void**)&c->hpin, 64 * sizeof(double))) != hipSuccess) return bail("hipHostMalloc", e);
-    if ((e = hipHostMalloc((void**)&c->hpin_rows, (size_t)3 * c->geo.lrows() * sizeof(double))) != hipSuccess) return bail("hipHostMalloc", e);
+    if ((e = hipHostMalloc((void**)&c->hpin, 64 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return bail("hipHostMalloc", e);
+    if ((e = hipHostMalloc((void**)&c->hpin_rows, (size_t)3 * c->geo.lrows() * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return bail("hipHostMalloc", e);
+    std::memset(c->hpin, 0, 64 * sizeof(double));
     std::memset(c->hpin_rows, 0, (size_t)3 * c->geo.lrows() * sizeof(double));      // [2 n .. 3 n): per-row arrival stamps of k_stress_max
     // reference initial state
     const double q0 = std::min(std::max(q_init_rh, 0.0), 1.0) * host_qsat(288.0, params->p0);

@@ -33,6 +33,10 @@ bool qd_peer_on(const qd_ctx* c);
 int  qd_peer_halo(qd_ctx* c, const QdUse* slots, int n);                 // the ring halo exchange of qd_exchange
 int  qd_peer_allreduce(qd_ctx* c, void* dptr, int n, int kind);          // kind 0: f64 sum in rank order, 1: f64 max, 2: u32 sum
 int  qd_peer_allgather(qd_ctx* c, double* buf, int n_per_rank);          // buf[world][n_per_rank], own segment filled in
+int  qd_peer_halo_begin(qd_ctx* c, const QdUse* slots, int n);           // push only (n <= qd_peer_max_slabs()) ...
+int  qd_peer_halo_end(qd_ctx* c);                                        // ... wait + unpack
+int  qd_peer_max_slabs();
+bool qd_peer_overlap(const qd_ctx* c);                                   // QD_PEER_OVERLAP: consumers split into interior / boundary rows around an exchange
 struct QdPeerFold;
 bool qd_peer_fold_begin(qd_ctx* c, QdPeerFold* F);                       // a one-double sum finished inside its producer's launch (qd_peer_dev.h)
 int  qd_peer_init_group(QdLocalGroup* g);                                // in-process group: one mailbox per handle, pointers shared

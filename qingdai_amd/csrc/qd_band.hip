@@ -155,7 +155,40 @@ QdSegs qd_segments(qd_ctx* c, int margin) {
     return S;
 }
 
-int qd_plan(qd_ctx* c, const QdUse* in_, int n_in, int want) {
+QdSegList qd_segments_rows(qd_ctx* c, int vr, int cnt, QdSegList S) {
+    const QdGeom& G0 = c->geo;
+    const int n = G0.nlat;
+    while (cnt > 0 && S.n < 6) {
+        int g0, len;
+        if (vr < 0) { g0 = vr + n; len = std::min(cnt, -vr); }
+        else if (vr >= n) { g0 = vr - n; len = cnt; }
+        else { g0 = vr; len = std::min(cnt, n - vr); }
+        QdGeom g = G0; g.row0 = g0; g.nrows = len;
+        S.g[S.n++] = g;
+        vr += len; cnt -= len;
+    }
+    return S;
+}
+
+int qd_plan_peek(qd_ctx* c, const QdUse* in, int n) {
+    if (c->geo.full) return 0;
+    int out = INT_MAX;
+    for (int k = 0; k < n; ++k) if (*in[k].slot) out = std::min(out, qd_vm_get(c, *in[k].slot) - in[k].radius);
+    return out == INT_MAX ? c->geo.halo : out;
+}
+
+static int qd_plan_impl(qd_ctx* c, const QdUse* in_, int n_in, int want, bool* pending);
+int qd_plan(qd_ctx* c, const QdUse* in_, int n_in, int want) { return qd_plan_impl(c, in_, n_in, want, nullptr); }
+int qd_plan_begin(qd_ctx* c, const QdUse* in, int n, bool* pending) { *pending = false; return qd_plan_impl(c, in, n, INT_MAX, pending); }
+int qd_plan_end(qd_ctx* c) {
+    if (c->split_pending.empty()) return 0;
+    if (qd_peer_halo_end(c)) return -1;
+    for (const QdUse& u : c->split_pending) c->vm[*u.slot] = c->geo.halo;
+    c->split_pending.clear();
+    return 0;
+}
+
+static int qd_plan_impl(qd_ctx* c, const QdUse* in_, int n_in, int want, bool* pending) {
     struct { const QdUse* p; int n; const QdUse* begin() const { return p; } const QdUse* end() const { return p + n; } } in{in_, n_in};
     if (c->geo.full) return 0;
     const int H = c->geo.halo;
@@ -176,6 +209,14 @@ int qd_plan(qd_ctx* c, const QdUse* in_, int n_in, int want) {
             bool dup = false;
             for (const QdUse& e : ex) dup |= (*e.slot == *u.slot);
             if (!dup) ex.push_back(u);
+        }
+        if (pending && qd_peer_overlap(c) && (int)ex.size() <= qd_peer_max_slabs() && c->own_nrows >= H) {
+            // only the push: the caller computes what the old margins allow, then qd_plan_end()
+            c->exchanges += 1;
+            if (qd_peer_halo_begin(c, ex.data(), (int)ex.size())) return -1;
+            c->split_pending = ex;
+            *pending = true;
+            return 0;
         }
         if (qd_exchange(c, ex.data(), (int)ex.size())) return -1;
     }

@@ -43,3 +43,5 @@ bool qd_stream_ok(const qd_ctx* c, int margin);
 bool qd_ocn_stream_ok(const qd_ctx* c, int margin);
 int qd_launch_dyn_stream(qd_ctx* c, const QdDynArgs& P, int margin);
 int qd_launch_ocn_stream(qd_ctx* c, const QdOcnArgs& P, int margin);
+bool qd_ocn_stream_ok_list(const qd_ctx* c, const QdSegList& S);              // explicit row segments (interior / boundary rows around a halo exchange)
+int qd_launch_ocn_stream_list(qd_ctx* c, const QdOcnArgs& P, const QdSegList& S);

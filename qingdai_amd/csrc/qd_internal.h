@@ -235,9 +235,11 @@ struct qd_ctx {
     void* comm = nullptr;          // RCCL communicator (one process per GPU)
     struct QdLocalGroup* lgroup = nullptr;   // in-process peers on one device (tests of the band logic)
     struct QdPeer* peer = nullptr;           // device-side exchange over the peer mapping (qd_peer.hip, QD_PEER_EXCHANGE)
+    std::vector<struct QdUse> split_pending; // slabs of a pushed, not yet unpacked exchange (qd_plan_begin / qd_plan_end)
     std::vector<struct QdUse> corefresh;   // slabs refreshed along with any halo exchange that happens anyway (set around loops)
     int exchanges = 0;             // statistics
     int allreduces = 0;
+    double pub_seq = 0.0;          // stamp of the last k_publish_host hand-over (qd_fetch_scalars)
     double eta_seq = 0.0;          // sequence number of the eta sum the host is waiting for (bands with a host ring)
     void* hring = nullptr;         // host ring (shared-memory scalar all-reduce), see qd_band.hip
     void* plansim = nullptr;       // planner simulation (qd_plansim_*): a handle without a device, exchanges are logged
@@ -292,6 +294,14 @@ int qd_vm_get(qd_ctx* c, const void* slab);
 struct QdSegs { QdGeom g[3]; int n; };
 QdSegs qd_segments(qd_ctx* c, int margin);
 int qd_exchange(qd_ctx* c, const QdUse* slots, int n);
+// exchange overlapped with interior rows (peer exchange only): qd_plan_begin is qd_plan, except that a due exchange is only PUSHED
+// (*pending = true) when the transport can finish it later; the caller launches the rows it can compute from the OLD margins
+// (qd_plan_peek), calls qd_plan_end (wait + unpack, margins back to the halo width) and launches the remaining boundary rows
+struct QdSegList { QdGeom g[6]; int n; };
+QdSegList qd_segments_rows(qd_ctx* c, int vr0, int cnt, QdSegList S = QdSegList{{}, 0});   // rows [vr0, vr0 + cnt) of the ring (period n_lat), appended to S
+int qd_plan_begin(qd_ctx* c, const QdUse* in, int n, bool* pending);
+int qd_plan_end(qd_ctx* c);
+int qd_plan_peek(qd_ctx* c, const QdUse* in, int n);
 int qd_allreduce_f64(qd_ctx* c, double* dptr, int n, int op);          // op 0 sum, 1 max (device scalars)
 int qd_allreduce_u32(qd_ctx* c, unsigned int* dptr, int n);            // sum
 int qd_allgather_f64(qd_ctx* c, double* buf, int n_per_rank);          // buf[world][n_per_rank]: own segment in, every segment out
@@ -374,6 +384,8 @@ int qd_driver_physics_impl(qd_ctx* c, double dt, const QdForcingCall* fc = nullp
 int qd_hydrology_commit_impl(qd_ctx* c, double dt);
 
 // qd_api.hip
+int qd_wait_host_flag(qd_ctx* c, volatile double* flag, double seq, const char* what);   // spin on a stamp in pinned host memory
+int qd_fetch_scalars(qd_ctx* c, const double* dsrc, int n, double* hdst);                // n <= 32 device doubles -> pinned host memory, no stream sync
 int qd_build_k4_tables(qd_ctx* c, double dt, bool ocean, double sub_dt);
 double* qd_scratch(qd_ctx* c, int i);
 void qd_swap(qd_ctx* c, int field, int scratch_idx);

@@ -657,23 +657,6 @@ __global__ void k_host_flag(double* flag, double seq) {
     if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // spin on a flag in pinned host memory: no HIP call on the wait path, the stream keeps executing what is queued behind
-static int qd_wait_host_flag(qd_ctx* c, volatile double* flag, double seq, const char* what) {
-    const auto t0 = std::chrono::steady_clock::now();
-    unsigned spins = 0;
-    while (*flag != seq) {
-        __builtin_ia32_pause();
-        if ((++spins & 0x3FFFu) == 0) {
-            // a stream that is no longer "not ready" cannot deliver the flag any more: either it drained without writing it, or a
-            // kernel faulted (sticky error) -- report that error instead of spinning out the timeout
-            const hipError_t q = hipStreamQuery(c->stream);
-            if (q != hipErrorNotReady && *flag != seq) return qd_fail(c, what, q);
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 60.0) return qd_fail(c, what);
-        }
-    }
-    std::atomic_thread_fence(std::memory_order_acquire);
-    return 0;
-}
-
 int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask, int inject_sst) {
     const qd_params& p = c->p;
     const QdGeom& G0 = c->geo;
@@ -756,8 +739,9 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
         } else {
         // ONE collective of fixed size on every band (polar bands have more segments than interior ones)
         if (qd_allreduce_f64(c, c->dscal + QD_S_TMP0, 6, 1)) return -1;
-        QD_HIP(c, hipMemcpyAsync(c->hpin, c->dscal + QD_S_TMP0, 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        QD_HIP(c, hipStreamSynchronize(c->stream));
+        // a one-wave kernel stores them into pinned host memory behind a stamp the host polls (no hipStreamSynchronize: its wake-up
+        // alone idled the stream for ~20 us per step)
+        if (qd_fetch_scalars(c, c->dscal + QD_S_TMP0, 6, c->hpin)) return -1;
         }
         for (int k = 0; k < 3; ++k) { maxVa = std::max(maxVa, c->hpin[2 * k]); maxUo = std::max(maxUo, c->hpin[2 * k + 1]); }
         }
@@ -791,7 +775,9 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
     // latitude bands WITHOUT a host ring run the same two kernels per sub-step as the whole globe (round 3): the streaming tail kernel
     // on the band's segments, its in-launch sum finished as the band's SHARE of the mean (sum_b / (W + 1e-15), W the global ocean
     // weight), one all-reduce of that scalar, applied by the next momentum kernel on load.  QD_BAND_TAIL=0: the round-2 band path.
-    const bool band_tail = band && can_defer && !band_defer && c->ocn_tail == 1 && c->tail_acc && c->band_tail && G0.nlon >= 64;
+    // (the sub-step is then planned two rows wider -- eta 7, currents 6, SST Ro + 2 --: handles with a thinner halo keep the round-2 path)
+    const bool band_tail = band && can_defer && !band_defer && c->ocn_tail == 1 && c->tail_acc && c->band_tail && G0.nlon >= 64 &&
+                           G0.halo >= std::max(7, Ro + 2);
     const bool defer_eta = (!band && can_defer) || band_defer || band_tail;
     double* const mean_ptr = band_defer ? c->hpin + 42 : c->dscal + QD_S_ETA_MEAN;
     // latitude bands: whenever a sub-step has to exchange halos, every slab of the sub-step loop is refreshed in the same group
@@ -844,13 +830,15 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
             // band_tail: every exchange of the sub-step happens HERE, so that the previous sub-step's eta sum (still pending) can ride
             // in its group: the momentum kernel is planned two rows wider than it needs (its outputs then carry the margin the tail's
             // T1 rows want) and the tail's other inputs are checked now instead of between the two launches
-            if (band_tail && qd_plan(c, {QD_IN(F[QD_F_ETA], 7), QD_IN(F[QD_F_UO], 6), QD_IN(F[QD_F_VO], 6), QD_IN(taux, 6), QD_IN(tauy, 6),
-                                         QD_IN(F[QD_F_SST], Ro + 2), QD_IN(F[QD_F_QNET], 0), QD_IN8(c->icemask, 0)}) < 0) return -1;
-            // (after the wide plan this one never exchanges: it only tells how far the momentum kernel can go -- at least two rows
-            //  beyond what the tail will store)
-            const int m = qd_plan(c, {QD_IN(F[QD_F_ETA], 5), QD_IN(F[QD_F_UO], 4), QD_IN(F[QD_F_VO], 4), QD_IN(taux, 4), QD_IN(tauy, 4)});
-            if (m < 0) return -1;
-            if (qd_allreduce_flush(c)) return -1;             // the previous sub-step's eta sum, unless the exchange above took it along
+            const QdUse narrow[5] = {QD_IN(F[QD_F_ETA], 5), QD_IN(F[QD_F_UO], 4), QD_IN(F[QD_F_VO], 4), QD_IN(taux, 4), QD_IN(tauy, 4)};
+            bool pending = false;                             // the exchange of this sub-step has been pushed, not yet unpacked
+            int m_old = 0;
+            if (band_tail) {
+                const QdUse wide[8] = {QD_IN(F[QD_F_ETA], 7), QD_IN(F[QD_F_UO], 6), QD_IN(F[QD_F_VO], 6), QD_IN(taux, 6), QD_IN(tauy, 6),
+                                       QD_IN(F[QD_F_SST], Ro + 2), QD_IN(F[QD_F_QNET], 0), QD_IN8(c->icemask, 0)};
+                if (qd_plan_begin(c, wide, 8, &pending) < 0) return -1;
+                if (pending) m_old = qd_plan_peek(c, narrow, 5);      // what the momentum kernel can compute BEFORE the halos arrive
+            }
             QdOcnArgs O;
             O.uo = F[QD_F_UO]; O.vo = F[QD_F_VO]; O.eta = F[QD_F_ETA]; O.taux = taux; O.tauy = tauy; O.land = c->land;
             O.uo_out = qd_scratch(c, 0); O.vo_out = qd_scratch(c, 1); O.eta_out = qd_scratch(c, 2);
@@ -864,7 +852,35 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
             O.inv_2dlon = 1.0 / (2.0 * c->dlon); O.inv_2dlat = 1.0 / (2.0 * c->dlat); O.inv_a = 1.0 / p.a; O.inv_rhoH = 1.0 / (p.rho_w * H);
             O.eta_mean = (defer_eta && s > 0) ? mean_ptr : nullptr;
             O.eta_cap = p.eta_cap;
-            if (qd_launch_ocn_hyper(c, O, m)) return -1;
+            // Exchange overlapped with interior compute (peer exchange, QD_PEER_OVERLAP): the rows whose stencils stay inside the OLD
+            // margins are launched between the push and the unpack -- the halo rows travel while they run -- and only the two
+            // boundary strips wait for the neighbours.  Rows do not depend on the strip they are computed in: bit-identical.
+            int m_int = 0;
+            bool split = false;
+            if (pending) {
+                // a negative old margin shrinks the interior; streaming segments must start / end at a pole or >= 5 rows from it
+                m_int = m_old >= 0 ? m_old : -12;
+                const QdSegList Si = qd_segments_rows(c, c->own_row0 - m_int, c->own_nrows + 2 * m_int);
+                if (c->own_nrows + 2 * m_int >= 12 && qd_ocn_stream_ok_list(c, Si)) {
+                    if (qd_launch_ocn_stream_list(c, O, Si)) return -1;
+                    split = true;
+                }
+                if (qd_plan_end(c)) return -1;                // wait for both neighbours' rows, copy them into the halos
+            }
+            // (after the wide plan this one never exchanges: it only tells how far the momentum kernel can go -- at least two rows
+            //  beyond what the tail will store)
+            const int m = qd_plan(c, narrow, 5);
+            if (m < 0) return -1;
+            if (qd_allreduce_flush(c)) return -1;             // the previous sub-step's eta sum, unless the exchange above took it along
+            if (split && m > m_int) {
+                QdSegList Sb = qd_segments_rows(c, c->own_row0 - m, m - m_int);
+                Sb = qd_segments_rows(c, c->own_row0 + c->own_nrows + m_int, m - m_int, Sb);
+                if (!qd_ocn_stream_ok_list(c, Sb)) {          // boundary strips too thin for the streaming kernel: redo the whole launch (same values)
+                    if (qd_launch_ocn_hyper(c, O, m)) return -1;
+                } else if (qd_launch_ocn_stream_list(c, O, Sb)) return -1;
+            } else if (!split) {
+                if (qd_launch_ocn_hyper(c, O, m)) return -1;
+            }
             qd_mark(c, {O.uo_out, O.vo_out, O.eta_out}, m);
             qd_swap(c, QD_F_UO, 0); qd_swap(c, QD_F_VO, 1); qd_swap(c, QD_F_ETA, 2);
         } else {

@@ -62,12 +62,15 @@ struct QdPeer {
     double* herr = nullptr;                       // pinned host word: a poll loop ran into its deadline
     long n_halo = 0, n_reduce = 0;
     int coarse = 0;                               // QD_PEER_COARSE=1: mailbox in ordinary device memory, full fences in the kernels
+    int overlap = 0;                              // QD_PEER_OVERLAP: 1 = consumers of an exchange run their interior rows between push and unpack (default: world > 1)
     int fold = 1;                                 // QD_PEER_FOLD=0: the eta sum of a sub-step as a k_peer_reduce launch of its own
     bool pushed = false;                          // a push is out whose unpack has not been launched yet
     QdPeerHalo pend;                              // its slabs
 };
 
 bool qd_peer_on(const qd_ctx* c) { return c->peer && c->peer->on; }
+bool qd_peer_overlap(const qd_ctx* c) { return c->peer && c->peer->on && c->peer->overlap; }
+int qd_peer_max_slabs() { return QP_MAXSLABS; }
 
 // ------------------------------------------------------------------ device side
 // One (slab, direction) segment of an exchange is H rows; a launch is a 2-D grid: blockIdx.y = 2 k + direction, blockIdx.x = one of
@@ -230,6 +233,8 @@ static int qp_alloc(qd_ctx* c) {
         hipFree(P->d_pbox); hipFree(P->box); delete P; return qd_fail(c, "peer exchange: ticket allocation", e);
     }
     { const char* ef = std::getenv("QD_PEER_FOLD"); if (ef && ef[0] == '0') P->fold = 0; }
+    P->overlap = world > 1 ? 1 : 0;
+    { const char* ef = std::getenv("QD_PEER_OVERLAP"); if (ef) P->overlap = ef[0] == '0' ? 0 : 1; }
     P->pbox[P->rank] = P->box;
     P->herr = c->hpin + 60;
     *P->herr = 0.0;

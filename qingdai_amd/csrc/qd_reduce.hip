@@ -910,8 +910,7 @@ int qd_median_positive_dev(qd_ctx* c, const double* x, double dflt, int slot, in
         if (qd_allgather_f64(c, c->med_gather, (int)segd)) return -1;
         hipLaunchKernelGGL(k_med_final, dim3(1), dim3(QD_FIN_BLOCK), 0, c->stream, c->sel_state, c->med_gather, c->sel_ccount, bpred, x,
                            0ull, transform, tparam, dflt, c->dscal + slot, c->dcount, world, cap, c->dscal + QD_S_TMP1, (unsigned int*)nullptr);
-        QD_HIP(c, hipMemcpyAsync(c->hpin + 32, c->dscal + QD_S_TMP1, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        QD_HIP(c, hipStreamSynchronize(c->stream));
+        if (qd_fetch_scalars(c, c->dscal + QD_S_TMP1, 1, c->hpin + 32)) return -1;
         if (c->hpin[32] == 0.0) return 0;
     }
     for (int p = 0; p < 6; ++p) {

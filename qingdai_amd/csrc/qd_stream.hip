@@ -243,6 +243,35 @@ bool qd_stream_ocn_args(qd_ctx* c, const QdOcnArgs& P, QsOcnArgs& A) {
     return true;
 }
 
+static bool qs_seg_ok(const QdGeom& G) {
+    const int s0 = G.row0, s1 = G.row0 + G.nrows;
+    return !((s0 > 0 && s0 < 5) || (s1 < G.nlat && s1 > G.nlat - 5) || G.nrows < 10);
+}
+// the same conditions as qd_ocn_stream_ok, for an explicit list of row segments (interior / boundary launches around a halo exchange)
+bool qd_ocn_stream_ok_list(const qd_ctx* c, const QdSegList& S) {
+    if (!(c->fused_fast >= 1 && c->fused_fast <= 2 && c->geo.nlon >= 64 && c->geo.nlat >= 12 &&
+          (size_t)(c->geo.lrows_ + QD_PAD_ROWS) * (size_t)c->geo.nlon * 8u < 0x7fffffffull)) return false;
+    for (int k = 0; k < S.n; ++k) {
+        const QdGeom& G = S.g[k];
+        if (!qs_seg_ok(G)) return false;
+        const bool pole = G.row0 == 0 || G.row0 + G.nrows == G.nlat;
+        if (!c->geo.full && pole && !(host_lrow(G, 0) < G.lrows_ && host_lrow(G, G.nlat - 1) < G.lrows_)) return false;
+    }
+    return S.n > 0;
+}
+
+int qd_launch_ocn_stream_list(qd_ctx* c, const QdOcnArgs& P, const QdSegList& S) {
+    QsOcnArgs A;
+    if (!qd_stream_ocn_args(c, P, A)) return qd_fail(c, "fused kernel: coefficient row tables");
+    for (int k = 0; k < S.n; ++k) {
+        const QdGeom& G = S.g[k];
+        const QsShape sh = qs_shape(c, G.nrows, G.nlon, 2, G.row0 + G.nrows == G.nlat);
+        A.G = G; A.vb = sh.vb; A.nrs = sh.nrs; A.ntc = (G.nlon + QS_TC - 1) / QS_TC;
+        hipLaunchKernelGGL(k_ocn_stream, dim3(A.nrs * A.ntc), dim3(192), 0, c->stream, A);
+    }
+    return 0;
+}
+
 int qd_launch_ocn_stream(qd_ctx* c, const QdOcnArgs& P, int margin) {
     QsOcnArgs A;
     A.poleA = c->tabs.lapPoleA[1];

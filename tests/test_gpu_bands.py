@@ -451,3 +451,44 @@ def test_streaming_kernels_at_awkward_grid_sizes(gpu, shape, monkeypatch):
     for k in lds:
         e = relerr(tail[k], lds[k])
         assert e < 1e-11, (shape, k, e)
+
+
+@pytest.mark.parametrize("halo", [5, 6, 7, 9])
+def test_ocean_step_on_thin_halo_bands(gpu, halo, monkeypatch):
+    """WindDrivenSlabOcean.step (pygcm/ocean.py:265-533) on 3 latitude bands whose halo is at or just above the thinnest width
+    qd_create accepts: with fewer than max(7, Ro + 2) halo rows the band sub-step falls back to the round-2 kernels (the round-3
+    form plans eta 7 rows out) instead of failing in the planner; every width must reproduce the whole globe."""
+    from qingdai_amd.bands import BandGroup
+    from qingdai_amd.device import Device
+    monkeypatch.setenv("QD_NO_HOST_RING", "1")
+    nlat, nlon = 91, 144
+    qa, grid, mask, alb, fric, p = _setup(nlat, nlon, dict(energy_w=1.0, ocean_cfl=0.05))
+    st = _seed_state(nlat, nlon, 5)
+    r = np.random.default_rng(9)
+    lat = np.linspace(-np.pi / 2, np.pi / 2, nlat)[:, None]
+    oc = {"UO": 0.3 * np.cos(lat) * r.normal(0, 1, (nlat, nlon)), "VO": 0.2 * r.normal(0, 1, (nlat, nlon)),
+          "ETA": 0.5 * r.normal(0, 1, (nlat, nlon)), "SST": 285.0 + 10 * np.cos(lat) + r.normal(0, 0.5, (nlat, nlon)),
+          "QNET": r.normal(0, 50.0, (nlat, nlon))}
+    static = {"LAND_MASK": mask, "FRICTION": fric, "BASE_ALBEDO": alb}
+    names = ["UO", "VO", "ETA", "SST", "TS"]
+
+    def run(dev):
+        for _ in range(2):
+            dev.ocean_step(300.0, False, False, True)
+    ref_dev = Device(grid, p)
+    for k, v in {**static, **st, **oc}.items():
+        ref_dev.upload_now(k, v)
+    run(ref_dev)
+    ref = {k: ref_dev.get(k).copy() for k in names}
+    nsub = ref_dev.last_ocean_nsub()
+    ref_dev.close()
+    grp = BandGroup(grid, 3, p, halo=halo)
+    for k, v in {**static, **st, **oc}.items():
+        grp.set(k, v)
+    grp.run(lambda d, rk: run(d))
+    got = {k: grp.get(k) for k in names}
+    grp.close()
+    assert nsub >= 2
+    for k in names:
+        e = relerr(got[k], ref[k])
+        assert e < 1e-12, (halo, k, e)

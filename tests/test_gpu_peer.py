@@ -36,11 +36,13 @@ def test_peer_bands_atmosphere_bit_identical(gpu, world, monkeypatch):
         assert np.array_equal(got[k], ref[k]), (k, relerr(got[k], ref[k]))
 
 
+@pytest.mark.parametrize("overlap", ["1", "0"])
 @pytest.mark.parametrize("world", [2, 4])
-def test_peer_bands_full_step_with_ocean_and_physics(gpu, world, monkeypatch):
+def test_peer_bands_full_step_with_ocean_and_physics(gpu, world, overlap, monkeypatch):
     """The coupled step: eta sums, CFL maxima, precipitation sums, both median paths (histogram all-reduce + gathered candidate
     segments) and the halo exchanges of the sub-step loop all go through the mailboxes."""
     monkeypatch.setenv("QD_PEER_EXCHANGE", "1")
+    monkeypatch.setenv("QD_PEER_OVERLAP", overlap)
     ref, _ = _run(1, 91, 144, 4, dict(energy_w=1.0, ocean_cfl=0.05), True, True)
     got, ex = _run(world, 91, 144, 4, dict(energy_w=1.0, ocean_cfl=0.05), True, True)
     print("halo exchanges per band:", ex)
@@ -49,7 +51,8 @@ def test_peer_bands_full_step_with_ocean_and_physics(gpu, world, monkeypatch):
         assert e < 1e-12, (k, e)          # only the band-wise order of the global sums differs
 
 
-def test_peer_self_ring_equals_in_process_transport(gpu, monkeypatch):
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_peer_self_ring_equals_in_process_transport(gpu, overlap, monkeypatch):
     """One rank whose ring neighbours are the rank itself: every operation in its fused one-launch form (push + poll + unpack,
     deposit + poll + reduce in one kernel), mailboxes mapped through qd_peer_export / qd_peer_connect.  Must move exactly the
     bytes the in-process host transport moves (cf. test_rccl_transport_equals_in_process_transport)."""
@@ -57,6 +60,9 @@ def test_peer_self_ring_equals_in_process_transport(gpu, monkeypatch):
     from qingdai_amd.device import Device
     monkeypatch.setenv("MASTER_PORT", "29741")
     monkeypatch.setenv("QD_NO_HOST_RING", "1")
+    # overlap = 1: the ocean momentum kernel of a sub-step that exchanges runs its interior rows between push and unpack, the two
+    # boundary strips after the unpack (the default of a multi-rank run; a one-rank ring has to ask for it)
+    monkeypatch.setenv("QD_PEER_OVERLAP", overlap)
     nlat, nlon, nsteps = 91, 144, 5
     qa, grid, mask, alb, fric, p = _setup(nlat, nlon, dict(energy_w=1.0))
     forcing = qa.ThermalForcing(qa.SphericalGrid(nlat, nlon), qa.OrbitalSystem())
