@@ -306,6 +306,10 @@ int qd_comm_allreduce_max(qd_handle h, double* inout, int n);     /* bench timin
 /* measured streaming ceiling of the device ("also report a measured device-copy ceiling"): a device-to-device copy of
  * `bytes` (choose > 256 MiB to get past the Infinity Cache), `reps` times; *gbs = (read + written bytes) / time. */
 int qd_copy_ceiling(qd_handle h, size_t bytes, int reps, double* gbs);
+/* Launcher tuning switches (QD_STREAM_R*, QD_TAIL_R / _RP / _V / _GENERAL, QD_MED_BLOCKS, QD_SHAPIRO_R, QD_TILE_TR: README.md) are
+ * read from the environment once, in qd_create; the developer scripts that sweep one of them on a live handle call this to have
+ * them read again.  Nothing the reference has (it re-reads its own QD_* variables every step: pygcm/dynamics.py:330-348). */
+int qd_tune_reload(qd_handle h);
 int qd_timing_enable(qd_handle h, int on);           /* 0 off, 1 every kernel group */
 int qd_timing_select(qd_handle h, const char* name); /* time only the groups "name[:stride],..." (implies on); with a stride
                                                        * only every stride-th launch of the group is bracketed */

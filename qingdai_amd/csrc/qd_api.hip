@@ -276,6 +276,25 @@ int qd_fetch_scalars(qd_ctx* c, const double* dsrc, int n, double* hdst) {
 extern "C" int qd_abi_version(void) { return QD_ABI_VERSION; }
 extern "C" int qd_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
 
+// launcher tuning switches (QdTune): read at qd_create and, for the developer scripts that sweep them on one handle, by qd_tune_reload
+static void qd_read_tuning(qd_ctx* c) {
+    c->tune = QdTune();
+    auto geti = [](const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; };
+    QdTune& t = c->tune;
+    c->stream_rows = std::max(0, geti("QD_STREAM_R", 0));
+    { const int r = geti("QD_TAIL_R", 0); if (r > 0) t.tail_r = r; }
+    { const int r = geti("QD_TAIL_RP", 0); if (r >= 3) t.tail_rp = r; }
+    t.tail_v = geti("QD_TAIL_V", 0) == 1 ? 1 : 0;
+    t.tail_general = geti("QD_TAIL_GENERAL", 0) == 1 ? 1 : 0;
+    t.stream_r_dyn = std::max(0, geti("QD_STREAM_R_DYN", 0));
+    t.stream_r_ocn = std::max(0, geti("QD_STREAM_R_OCN", 0));
+    t.stream_vb = geti("QD_STREAM_VB", -1);
+    { const int b = geti("QD_MED_BLOCKS", 0); if (b >= 16) t.med_blocks = b; }
+    t.shapiro_r = std::max(0, geti("QD_SHAPIRO_R", 0));
+    t.tile_tr = std::max(0, geti("QD_TILE_TR", 0));
+}
+extern "C" int qd_tune_reload(qd_handle c) { if (!c) return -1; qd_read_tuning(c); c->tile = QdTileShape{0, 0, 0, 0}; return 0; }
+
 extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double q_init_rh, qd_handle* out) {
     if (!d || !params || !out) return qd_fail(nullptr, "qd_create: null argument");
     if (d->n_lat < 5 || d->n_lon < 4) return qd_fail(nullptr, "qd_create: grid too small (need n_lat>=5, n_lon>=4)");
@@ -293,11 +312,12 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
     c->desc = *d; c->p = *params;
     { const char* ef = std::getenv("QD_FUSED"); if (ef && ef[0] == '0') c->use_fused = 0; }
     { const char* ef = std::getenv("QD_FUSED_FAST"); if (ef) c->fused_fast = std::atoi(ef); }
-    { const char* ef = std::getenv("QD_STREAM_R"); if (ef) c->stream_rows = std::max(1, std::atoi(ef)); }
     { const char* ef = std::getenv("QD_TAIL_ACC"); if (ef) c->tail_acc = std::atoi(ef); }
     { const char* ef = std::getenv("QD_SHAPIRO_STREAM"); if (ef) c->shapiro_stream = std::atoi(ef); }
-    { const char* ef = std::getenv("QD_OCN_TAIL"); if (ef) c->ocn_tail = std::atoi(ef); }   // 0: two launches (k_cont_sstadv, k_sst_outlier_fused); 1: k_ocn_tail_stream (default); 2: LDS-tiled k_ocn_tail; 3: k_ocn_tail_tile; 4: k_ocn_step (the whole sub-step in one launch)
+    { const char* ef = std::getenv("QD_OCN_TAIL"); if (ef) c->ocn_tail = std::atoi(ef); }   // 0: two launches (k_cont_sstadv, k_sst_outlier_fused); anything else: k_ocn_tail_fast (QD_TAIL_V=1: k_ocn_tail_stream).  The LDS-tile forms and the one-launch sub-step of round 3 (2, 3, 4) are retired: tools/retired/
+    if (c->ocn_tail != 0) c->ocn_tail = 1;
     { const char* ef = std::getenv("QD_BAND_TAIL"); if (ef) c->band_tail = ef[0] == '0' ? 0 : 1; }
+    qd_read_tuning(c);
     { const char* ef = std::getenv("QD_GROUP_SUMS"); if (ef) c->group_sums = ef[0] == '0' ? 0 : 1; }
     c->geo = QdGeom{d->n_lat, d->n_lon, d->row0, d->n_rows, d->halo, full ? 1 : 0, d->row0 - d->halo, d->n_rows + 2 * d->halo};
     c->own_row0 = d->row0; c->own_nrows = d->n_rows;

@@ -802,9 +802,8 @@ QdTileShape qd_pick_tile(const QdGeom& G) {
 static void qd_tile_init(qd_ctx* c) {
     if (c->tile.tr != 0) return;
     c->tile = qd_pick_tile(c->geo);
-    const char* etr = std::getenv("QD_TILE_TR");              // tuning override
-    if (etr) {
-        const int tr = std::atoi(etr);
+    if (c->tune.tile_tr > 0) {                                // QD_TILE_TR: tuning override (read at create)
+        const int tr = c->tune.tile_tr;
         for (int t = 0; t < kNTileRows; ++t)
             if (kTileRows[t] == tr)
                 c->tile = QdTileShape{tr, QD_TC, (c->geo.nrows + tr - 1) / tr, (c->geo.nlon + QD_TC - 1) / QD_TC};

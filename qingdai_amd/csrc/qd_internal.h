@@ -154,6 +154,19 @@ struct QdEco {
 };
 
 struct QdTimer { double total_ms = 0; int64_t n = 0; };
+// Tuning switches of the launchers, read from the environment ONCE in qd_create (qd_read_tuning): nothing that qd_step_n reaches
+// calls getenv.  0 / -1 = "pick per launch from the grid".
+struct QdTune {
+    int tail_r = 0;           // QD_TAIL_R: strip height of the ocean tail kernel
+    int tail_rp = 3;          // QD_TAIL_RP: rows of its pole strips (>= 3)
+    int tail_v = 0;           // QD_TAIL_V=1: k_ocn_tail_stream (the round-3 general form) instead of k_ocn_tail_fast
+    int tail_general = 0;     // QD_TAIL_GENERAL=1: every wave of k_ocn_tail_fast takes the general form (A/B runs, tests)
+    int stream_r_dyn = 0, stream_r_ocn = 0;   // QD_STREAM_R_DYN / _OCN (QD_STREAM_R for both is qd_ctx::stream_rows)
+    int stream_vb = -1;       // QD_STREAM_VB: rows the north-pole strip is shorter by
+    int med_blocks = 256;     // QD_MED_BLOCKS: fat workgroups of the median passes
+    int shapiro_r = 0;        // QD_SHAPIRO_R: strip height of k_shapiro_stream
+    int tile_tr = 0;          // QD_TILE_TR: tile height of the LDS fallback kernels
+};
 struct QdTileShape { int tr, tc, ntr, ntc; };
 
 struct qd_ctx {
@@ -222,6 +235,7 @@ struct qd_ctx {
     double qs_key[2][8] = {{NAN, 0, 0, 0, 0, 0, 0, 0}, {NAN, 0, 0, 0, 0, 0, 0, 0}};
     std::vector<double> h_lapK[2];  // host copies of QdTabs::lapK
     std::vector<double> h_k4[2];    // host copies of k4_atm / k4_ocn
+    QdTune tune;                     // launcher tuning switches (environment, read once at create)
     int n_cu = 0;                    // compute units of the device (hipDeviceAttributeMultiprocessorCount, qd_create)
     int qs_wgs_per_cu[3] = {0, 0, 0};   // resident workgroups per CU of k_dyn_stream<false>, <true>, k_ocn_stream (occupancy query, cached)
     int cloud_eff_valid = 0;

@@ -791,41 +791,8 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
     const bool use_tail = c->use_fused && (!band || band_tail) && defer_eta && G0.nlon >= 64 && c->ocn_tail;
     // QD_TAIL_ACC (default): the streaming tail kernel reduces its own strip sums (fixed-point atomics + spread tickets, qd_wave.h)
     // and its last workgroup writes the mean -- no k_eta_mean_tail launch (4.5 us of launch floor per sub-step)
-    const bool tail_acc = use_tail && (c->ocn_tail == 1 || c->ocn_tail >= 3) && c->tail_acc;
-    // QD_OCN_TAIL=4: the WHOLE sub-step is one launch (k_ocn_step, qd_ocntail.hip): momentum + del^4 streamed into LDS, the tail from LDS
-    const bool use_step = use_tail && c->ocn_tail == 4 && do_diff && p.ocean_k4_nsub == 1 && !do_shap && qd_ocn_step_ok(c);
+    const bool tail_acc = use_tail && c->tail_acc;
     for (int s = 0; s < n_sub; ++s) {
-        if (use_step) {
-            QdOcnArgs O;
-            O.uo = F[QD_F_UO]; O.vo = F[QD_F_VO]; O.eta = F[QD_F_ETA]; O.taux = taux; O.tauy = tauy; O.land = c->land;
-            O.uo_out = nullptr; O.vo_out = nullptr; O.eta_out = nullptr;
-            for (int f = 0; f < 3; ++f) {
-                const bool sc1 = !(ov[f] != ov[f]);
-                O.k4row[f] = sc1 ? nullptr : c->k4_ocn + (size_t)f * G0.nlat;
-                O.k4s[f] = sc1 ? ov[f] : 0.0;
-                O.skip[f] = c->k4_ocn_skip[f];
-            }
-            O.a = p.a; O.g = p.g_ocean; O.dlat = c->dlat; O.dlon = c->dlon; O.sub_dt = sub_dt; O.rhoH = p.rho_w * H; O.r_bot = p.r_bot;
-            O.inv_2dlon = 1.0 / (2.0 * c->dlon); O.inv_2dlat = 1.0 / (2.0 * c->dlat); O.inv_a = 1.0 / p.a; O.inv_rhoH = 1.0 / (p.rho_w * H);
-            O.eta_mean = s > 0 ? mean_ptr : nullptr;
-            O.eta_cap = p.eta_cap;
-            QdTailArgs A;
-            A.uo = nullptr; A.vo = nullptr; A.Ts = F[QD_F_SST]; A.qnet = F[QD_F_QNET]; A.land = c->land; A.ice = c->icemask;
-            A.uo_out = qd_scratch(c, 0); A.vo_out = qd_scratch(c, 1); A.eta = qd_scratch(c, 2); A.Ts_out = qd_scratch(c, 3); A.partial = c->red_partial;
-            A.a = p.a; A.dlat = c->dlat; A.dlon = c->dlon; A.sub_dt = sub_dt; A.msdtH = -sub_dt * H; A.alpha = p.ocean_adv_alpha;
-            A.K_h = HP.K_h; A.rcH = HP.rcH; A.ice_qfac = HP.ice_qfac; A.cap = p.ocean_max_u;
-            A.use_q = HP.use_q; A.has_ice = HP.has_ice; A.mean4 = p.ocean_outlier == 0 ? 1 : 0;
-            A.r_a = 1.0 / p.a; A.r_dlon = 1.0 / c->dlon; A.r_dlat = 1.0 / c->dlat; A.r_2dlon = 1.0 / (2 * c->dlon); A.r_2dlat = 1.0 / (2 * c->dlat);
-            A.r_rcH = 1.0 / HP.rcH;
-            A.acc = tail_acc ? c->eta_acc : nullptr; A.mean_out = c->dscal + QD_S_ETA_MEAN; A.wsum = c->wsum_ocean;
-            A.ntc = 0; A.R = 0; A.Rp = 0; A.nmid = 0; A.flags = 0;
-            if (qd_launch_ocn_step(c, O, A)) return -1;
-            if (!tail_acc)
-                hipLaunchKernelGGL(k_eta_mean_tail, dim3(1), dim3(256), 0, c->stream, c->red_partial, qd_ocn_step_tiles(c), c->wsum_ocean,
-                                   c->dscal + QD_S_ETA_MEAN);
-            qd_swap(c, QD_F_UO, 0); qd_swap(c, QD_F_VO, 1); qd_swap(c, QD_F_ETA, 2); qd_swap(c, QD_F_SST, 3);
-            continue;
-        }
         if (do_diff && c->use_fused && p.ocean_k4_nsub == 1) {
             // band_tail: every exchange of the sub-step happens HERE, so that the previous sub-step's eta sum (still pending) can ride
             // in its group: the momentum kernel is planned two rows wider than it needs (its outputs then carry the margin the tail's

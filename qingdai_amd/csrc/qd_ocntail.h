@@ -21,9 +21,3 @@ struct QdTailArgs {
 
 int qd_ocn_tail_tiles(const qd_ctx* c, const QdGeom& G);
 int qd_launch_ocn_tail(qd_ctx* c, const QdGeom& G, QdTailArgs& P);
-
-// the whole sub-step in one launch (QD_OCN_TAIL=4; qd_ocntail.hip, k_ocn_step)
-struct QdOcnArgs;
-bool qd_ocn_step_ok(const qd_ctx* c);
-int qd_ocn_step_tiles(const qd_ctx* c);
-int qd_launch_ocn_step(qd_ctx* c, const QdOcnArgs& O, QdTailArgs& P);

@@ -135,12 +135,13 @@ k_cloud_from_p(QdGeom G, const double* __restrict__ precip, const double* __rest
 }
 
 
-// np.clip(tanh(x), 0, 1) without the tanh where it cannot matter: tanh(x) <= 0 for x <= 0 (and the clip of a NaN is 0 as well), so
-// those lanes take 0 -- and a wavefront in which every lane does (cold rows, anticyclonic regions) skips the ~45 instructions of the
-// f64 tanh altogether.  Same result bit for bit: for x > 0 the same tanh is evaluated.
+// np.clip(tanh(x), 0, 1) without the tanh where it cannot matter: tanh(x) <= 0 for x <= 0, so those lanes take 0 -- and a wavefront in
+// which every lane does (cold rows, anticyclonic regions) skips the ~45 instructions of the f64 tanh altogether.  Same result bit for
+// bit: for every other x, NaN included, the same tanh is evaluated -- np.clip(np.tanh(nan), 0, 1) is nan (physics.py:85-107), and a
+// blown-up T_s / u / v has to reach the cloud source like it does in the reference (qd_tanh_nonneg and qd_clip propagate NaN).
 __device__ __forceinline__ double qd_tanh01(double x) {
     double t = 0.0;
-    if (x > 0.0) t = qd_tanh_nonneg(x);
+    if (!(x <= 0.0)) t = qd_tanh_nonneg(x);
     return qd_clip(t, 0.0, 1.0);
 }
 

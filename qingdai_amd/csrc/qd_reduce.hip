@@ -852,8 +852,7 @@ int qd_median_positive_dev(qd_ctx* c, const double* x, double dflt, int slot, in
     // digits from the top: bits 63..53, 52..42, 41..31, 30..20 (11 wide), 19..10, 9..0 (10 wide)
     const int shifts[6] = {53, 42, 31, 20, 10, 0};
     const int widths[6] = {11, 11, 11, 11, 10, 10};
-    int nblk = 256;               // few, fat workgroups; round 3b with the finisher-less histogram pass: 128 / 192 / 256 / 384 / 512 / 721 -> 0.897 / 0.895 / 0.893 / 0.899 / 0.913 / 0.921 ms/step; (ms/step at 721x1440 with 64/128/256/512/721: 1.371/1.324/1.307/1.323/1.345)
-    if (const char* e = std::getenv("QD_MED_BLOCKS")) { const int b = std::atoi(e); if (b >= 16) nblk = b; }      // tuning override, read per call
+    const int nblk = c->tune.med_blocks;               // few, fat workgroups; round 3b with the finisher-less histogram pass: 128 / 192 / 256 / 384 / 512 / 721 -> 0.897 / 0.895 / 0.893 / 0.899 / 0.913 / 0.921 ms/step; (ms/step at 721x1440 with 64/128/256/512/721: 1.371/1.324/1.307/1.323/1.345)
     dim3 grid(1, std::min(G.nrows, nblk));
     if (c->geo.full && c->sel_cand && c->med_pred && c->med_predict && site >= 0 && site < QD_MED_SITES) {
         // windowed histogram around the site's last median, one collecting pass, one finishing workgroup

@@ -226,17 +226,14 @@ k_shapiro_stream(QdGeom G, QdFieldList fl, int scrub, int R, int ntc, int nstrip
 // strip height of the one-launch Shapiro filter (QD_SHAPIRO_R: tuning override).  rocprofv3 kernel trace, u v h at 721 x 1440, two
 // passes, R = 8 / 12 / 16 / 24 / 32: 14.4 / 14.1 / 14.4 / 14.9 / 15.2 us with the straight-line steady-state blocks (15.8 / 16.1 / 17.1 /
 // 18.9 / 19.7 with the general tick everywhere; two k_shapiro_pass launches: 42 us); 4 instead of 8 rows in flight: +1 us.
-static int qd_shapiro_rows() {
-    if (const char* e = std::getenv("QD_SHAPIRO_R")) { const int r = std::atoi(e); if (r > 0) return r; }
-    return 12;
-}
+static int qd_shapiro_rows(const qd_ctx* c) { return c->tune.shapiro_r > 0 ? c->tune.shapiro_r : 12; }
 
 int qd_shapiro_fields(qd_ctx* c, double** fields, int n, int npass, int m_out) {
     if (npass < 1) npass = 1;
     QdFieldList a; a.n = n;
     if (npass <= 3 && c->geo.nlon >= 64 && c->shapiro_stream) {
         for (int k = 0; k < n; ++k) { a.in[k] = fields[k]; a.out[k] = qd_scratch(c, k); a.aux[k] = nullptr; a.k4row[k] = nullptr; a.k4s[k] = 0; }
-        const int R = qd_shapiro_rows(), W = 64 - 2 * npass, ntc = (c->geo.nlon + W - 1) / W;
+        const int R = qd_shapiro_rows(c), W = 64 - 2 * npass, ntc = (c->geo.nlon + W - 1) / W;
         QD_ROWS(c, m_out, G, {
             const int ns = ((G.nrows + R - 1) / R) * ntc;
             const dim3 grid((ns + QD_SH_WAVES - 1) / QD_SH_WAVES, n), blk(64 * QD_SH_WAVES);

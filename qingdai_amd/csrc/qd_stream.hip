@@ -110,8 +110,7 @@ struct QsShape { int R, nrs, vb; };
 static QsShape qs_shape(qd_ctx* c, int nrows, int nlon, int which, bool north_pole) {
     const int ntc = (nlon + QS_TC - 1) / QS_TC;
     int R = 0;
-    if (const char* e = std::getenv(which == 2 ? "QD_STREAM_R_OCN" : "QD_STREAM_R_DYN")) R = std::atoi(e);    // tuning overrides, read per launch
-    if (R <= 0) if (const char* e = std::getenv("QD_STREAM_R")) R = std::atoi(e);
+    R = which == 2 ? c->tune.stream_r_ocn : c->tune.stream_r_dyn;      // tuning overrides (QD_STREAM_R_OCN / _DYN, QD_STREAM_R: read at create)
     if (R <= 0) R = c->stream_rows;
     int nrs;
     if (R > 0) nrs = std::max(1, nrows / std::max(R, 5));
@@ -123,7 +122,7 @@ static QsShape qs_shape(qd_ctx* c, int nrows, int nlon, int which, bool north_po
     int vb = 0;
     if (north_pole && nrs > 1) {
         vb = 6;
-        if (const char* e = std::getenv("QD_STREAM_VB")) vb = std::max(0, std::atoi(e));             // tuning override, read per launch
+        if (c->tune.stream_vb >= 0) vb = c->tune.stream_vb;                                          // QD_STREAM_VB (read at create)
         while (vb > 0 && nrows - qs_cut(nrows, nrs, vb, nrs - 1) < 12) --vb;                         // the pole strip keeps >= 12 rows
     }
     return QsShape{(nrows + nrs - 1) / nrs, nrs, vb};

@@ -20,6 +20,7 @@ def main():
     dev.step_n(stars[:8], 300.0, with_ocean=False, with_physics=False, pass_albedo=True)
     for k, R in enumerate(rs):
         os.environ["QD_SHAPIRO_R"] = str(R)
+        dev.lib.qd_tune_reload(dev.h)
         dev.step_n(stars[8 * (k + 1):8 * (k + 2)], 300.0, with_ocean=False, with_physics=False, pass_albedo=True)
     dev.sync()
 

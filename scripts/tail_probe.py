@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Developer tool: the coupled 721x1440 loop with a list of strip heights of k_ocn_tail_stream (QD_TAIL_R is read per launch);
+"""Developer tool: the coupled 721x1440 loop with a list of strip heights of k_ocn_tail_stream (QD_TAIL_R is read at create; qd_tune_reload re-reads it);
 run under `rocprofv3 --kernel-trace --output-format csv` and read the durations with scripts/trace_summary.py (the workgroup counts
 tell the strip heights apart).  python scripts/tail_probe.py [R ...]"""
 import os
@@ -18,6 +18,7 @@ def main():
     dev.step_n(stars[:24], 300.0, with_ocean=True, with_physics=True, pass_albedo=True)
     for k, R in enumerate(rs):
         os.environ["QD_TAIL_R"] = str(R)
+        dev.lib.qd_tune_reload(dev.h)
         dev.step_n(stars[24 + 6 * k:30 + 6 * k], 300.0, with_ocean=True, with_physics=True, pass_albedo=True)
     dev.sync()
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer tool: HIP-event time of the two fused kernels (k_dyn_hyper / k_ocn_hyper groups) at 721x1440 for a list of
-strip heights of the row-streaming kernels (QD_STREAM_R is read per launch).  python scripts/tune_stream.py [R ...]"""
+strip heights of the row-streaming kernels (QD_STREAM_R is read at create; qd_tune_reload re-reads it).  python scripts/tune_stream.py [R ...]"""
 import os
 import sys
 import time
@@ -29,6 +29,7 @@ def main():
             os.environ["QD_STREAM_R"] = str(R)
         else:
             os.environ.pop("QD_STREAM_R", None)                  # 0: the library's own choice
+        dev.lib.qd_tune_reload(dev.h)
         dev.timing(select="k_dyn_hyper,k_ocn_hyper")
         t0 = time.perf_counter()
         dev.step_n(stars[k:k + 12], dt, with_ocean=True, with_physics=True, pass_albedo=True)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer tool: HIP-event time of the ocean tail launch (timer group ocean_tail) and of the whole step at 721x1440 for a list of
-strip heights of the streaming tail kernel (QD_TAIL_R is read per launch).  python scripts/tune_tail.py [R ...]"""
+strip heights of the streaming tail kernel (QD_TAIL_R is read at create; qd_tune_reload re-reads it).  python scripts/tune_tail.py [R ...]"""
 import os
 import sys
 import time
@@ -22,6 +22,7 @@ def main():
     k = 24
     for R in rs:
         os.environ["QD_TAIL_R"] = str(R)
+        dev.lib.qd_tune_reload(dev.h)
         dev.timing(select="ocean_tail,k_ocn_hyper,ocean_step")
         t0 = time.perf_counter()
         dev.step_n(stars[k:k + 12], dt, with_ocean=True, with_physics=True, pass_albedo=True)

@@ -111,9 +111,18 @@ def test_fused_kernel_paths_agree(gpu, shape, monkeypatch):
         assert e < (1e-7 if k in ("UO", "VO", "ETA") else 1e-9), (k, e)
 
 
-# forms of the one-launch ocean tail (QD_OCN_TAIL): 1 row-streaming, 2 LDS tile, 3 LDS tile with every load of a phase in flight,
-# 4 the whole sub-step (momentum + del^4 + tail) in one launch
-TAIL_FORMS = ("1", "2", "3", "4")
+# forms of the one-launch ocean tail: "fast" = k_ocn_tail_fast (the shipped form), "stream" = k_ocn_tail_stream (QD_TAIL_V=1: the
+# general waves on every strip, the reference form of the slim ones); the LDS-tile forms and the one-launch sub-step of round 3
+# are retired (tools/retired/)
+TAIL_FORMS = ("fast", "stream")
+
+
+def _set_tail(monkeypatch, tail):
+    monkeypatch.setenv("QD_OCN_TAIL", "0" if tail == "0" else "1")
+    if tail == "stream":
+        monkeypatch.setenv("QD_TAIL_V", "1")
+    else:
+        monkeypatch.delenv("QD_TAIL_V", raising=False)
 # bound on the agreement with the two-launch form: the forms differ in the ORDER of the area-weighted eta sum only (per row / per
 # strip / per tile, f64 tree or fixed-point slots); over 2-3 coupled steps that rounding difference grows to ~2e-12 on the currents
 TAIL_TOL = 1e-11
@@ -127,9 +136,9 @@ def test_ocean_tail_kernel_matches_the_two_launch_form(gpu, shape, tail, monkeyp
     only the order of the area-weighted eta sum differs (per 16 x 62 tile instead of per row)."""
     nlat, nlon = shape
     over = dict(energy_w=1.0, ocean_cfl=0.05)
-    monkeypatch.setenv("QD_OCN_TAIL", "0")
+    _set_tail(monkeypatch, "0")
     two, _ = _run(1, nlat, nlon, 3, over, True, True)
-    monkeypatch.setenv("QD_OCN_TAIL", tail)
+    _set_tail(monkeypatch, tail)
     one, _ = _run(1, nlat, nlon, 3, over, True, True)
     errs = {k: relerr(one[k], two[k]) for k in one}
     print(errs)
@@ -363,7 +372,7 @@ def test_one_launch_shapiro_equals_one_launch_per_pass(gpu, shape, monkeypatch):
         dev.close()
 
 
-@pytest.mark.parametrize("tail", ("1", "3", "4"))
+@pytest.mark.parametrize("tail", TAIL_FORMS)
 @pytest.mark.parametrize("outlier", ["mean4", "clamp"])
 def test_ocean_tail_outlier_filter_with_isolated_spikes(gpu, monkeypatch, outlier, tail):
     """The velocity outlier filter of the ocean sub-step (ocean.py:409-434) with ISOLATED spikes: a cell faster than QD_OCEAN_MAX_U
@@ -388,7 +397,7 @@ def test_ocean_tail_outlier_filter_with_isolated_spikes(gpu, monkeypatch, outlie
     sst = 288.0 + 8.0 * np.cos(lat) ** 2 + r.normal(0, 0.3, (nlat, nlon))
     out = {}
     for mode in ("0", tail):
-        monkeypatch.setenv("QD_OCN_TAIL", mode)
+        _set_tail(monkeypatch, mode)
         oc = qa.WindDrivenSlabOcean(qa.SphericalGrid(nlat, nlon), mask, 50.0, init_Ts=sst, params=p)
         oc.uo, oc.vo, oc.eta = uo, vo, np.zeros((nlat, nlon))
         oc.step(300.0, st["U"], st["V"])
@@ -416,15 +425,15 @@ def test_ocean_tail_outlier_filter_with_isolated_spikes(gpu, monkeypatch, outlie
 @pytest.mark.parametrize("over", [dict(K_h=0.0), dict(ocean_use_qnet=0), dict(ocean_ice_qfac=0.0), dict(ocean_adv_alpha=1.0),
                                   dict(ocean_adv_alpha=0.0, K_h=2.0e4), dict(eta_cap=0.05), dict(ocean_cfl=0.9)],
                          ids=lambda o: ",".join(f"{k}={v}" for k, v in o.items()))
-@pytest.mark.parametrize("tail", ("1", "3", "4"))
+@pytest.mark.parametrize("tail", TAIL_FORMS)
 def test_ocean_tail_kernel_parameter_branches(gpu, monkeypatch, over, tail):
     """The wave-uniform switches of the streaming tail kernel (no diffusion, no Q_net heating, no heating under ice, pure advection /
     no advection, a tight eta clip, one sub-step per step) against the two-launch form, 2 coupled steps at 91 x 144."""
     base = dict(energy_w=1.0, ocean_cfl=0.05)
     base.update(over)
-    monkeypatch.setenv("QD_OCN_TAIL", "0")
+    _set_tail(monkeypatch, "0")
     two, _ = _run(1, 91, 144, 2, base, True, True)
-    monkeypatch.setenv("QD_OCN_TAIL", tail)
+    _set_tail(monkeypatch, tail)
     one, _ = _run(1, 91, 144, 2, base, True, True)
     for k in one:
         e = relerr(one[k], two[k])

@@ -544,3 +544,34 @@ def test_step_n_precipitation_block_inside_the_ocean_step_changes_nothing(gpu, m
     a, b = run("1"), run("0")
     for k in a:
         assert np.array_equal(a[k], b[k], equal_nan=True), k
+
+
+def test_cloud_source_propagates_nan_like_the_reference(gpu):
+    """parameterize_cloud_cover (physics.py:72-114) on a state with a NaN surface temperature and a NaN wind cell:
+    np.clip(np.tanh(nan), 0, 1) is nan, so the poisoned cells -- and what the sigma = 1 blur spreads them to -- must be NaN in
+    CLOUD_SRC exactly where the oracle has them (a blown-up state must not come back as finite clouds), and everything else
+    must agree to rounding."""
+    import types
+    import qingdai_amd as qa
+    from qd_oracle import physics as ophys
+    meta, d = load_golden("driverphys_37x72")
+    nlat, nlon = 37, 72
+    og, mask, alb, fric = surface(nlat, nlon)
+    grid = qa.SphericalGrid(nlat, nlon)
+    Cs_ocean = 1000.0 * 4200.0 * 50.0
+    m = qa.SpectralModel(grid, fric, H=8000, tau_rad=10 * 24 * 3600, greenhouse_factor=0.40,
+                         C_s_map=np.where(mask == 1, 3e6, Cs_ocean).astype(float), land_mask=mask,
+                         Cs_ocean=Cs_ocean, Cs_land=3e6, Cs_ice=5e6, params=qa.QdParams())
+    st = {k: d["init_" + k].copy() for k in STATE}
+    st["T_s"][12, 30] = np.nan
+    st["u"][25, 5] = np.nan
+    for k in STATE:
+        setattr(m, k, st[k])
+    m._dev.upload_now("BASE_ALBEDO", alb)
+    m._dev.driver_physics(meta["dt"])
+    got = m._dev.get("CLOUD_SRC")
+    want = ophys.parameterize_cloud_cover(types.SimpleNamespace(T_s=st["T_s"], u=st["u"], v=st["v"]), og)
+    assert np.isnan(want).sum() > 20
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    ok = ~np.isnan(want)
+    assert np.max(np.abs(got[ok] - want[ok])) < 1e-12
