@@ -32,6 +32,7 @@ struct QdPeer;
 bool qd_peer_on(const qd_ctx* c);
 int  qd_peer_halo(qd_ctx* c, const QdUse* slots, int n);                 // the ring halo exchange of qd_exchange
 int  qd_peer_allreduce(qd_ctx* c, void* dptr, int n, int kind);          // kind 0: f64 sum in rank order, 1: f64 max, 2: u32 sum
+int  qd_peer_allreduce_publish(qd_ctx* c, double* dptr, int n, int op_max, double* hdst, double hseq);   // ... and straight on to pinned host memory
 int  qd_peer_allgather(qd_ctx* c, double* buf, int n_per_rank);          // buf[world][n_per_rank], own segment filled in
 int  qd_peer_halo_begin(qd_ctx* c, const QdUse* slots, int n);           // push only (n <= qd_peer_max_slabs()) ...
 int  qd_peer_halo_end(qd_ctx* c);                                        // ... wait + unpack

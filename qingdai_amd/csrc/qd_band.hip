@@ -339,6 +339,23 @@ int qd_allreduce_f64(qd_ctx* c, double* dptr, int n, int op) {
     return qd_fail(c, "band handle without a communicator");
 }
 
+// all-reduce of a few device doubles that the host needs next (CFL maxima): result in dptr AND in pinned host memory hdst, the call
+// returns when the host can read it.  Peer exchange: the reduction kernel publishes it itself; other transports: reduce, then
+// qd_fetch_scalars.
+int qd_allreduce_fetch(qd_ctx* c, double* dptr, int n, int op, double* hdst) {
+    if (c->geo.full) return qd_fetch_scalars(c, dptr, n, hdst);
+    if (qd_peer_on(c) && n <= 256) {
+        c->allreduces++;
+        c->pub_seq += 1.0;
+        if (qd_peer_allreduce_publish(c, dptr, n, op, hdst, c->pub_seq)) return -1;
+        if (qd_wait_host_flag(c, c->hpin + 61, c->pub_seq, "reduced scalars never reached the host")) return -1;
+        if (c->hpin[60] != 0.0) return qd_fail(c, "peer exchange: a rank did not arrive within the deadline");
+        return 0;
+    }
+    if (qd_allreduce_f64(c, dptr, n, op)) return -1;
+    return qd_fetch_scalars(c, dptr, n, hdst);
+}
+
 #define QD_LOCAL_U32_MAX (64 * 2 * 4096)        // the gathered median segments of up to 64 in-process bands
 // buf[world][n_per_rank] with this rank's segment filled in -> every segment everywhere.  Transports without a gather of their own
 // all-reduce the zero-padded buffer as integers (x + 0 + ... + 0 is exact): the caller clears the other segments first.

@@ -318,6 +318,7 @@ int qd_plan_end(qd_ctx* c);
 int qd_plan_peek(qd_ctx* c, const QdUse* in, int n);
 int qd_allreduce_f64(qd_ctx* c, double* dptr, int n, int op);          // op 0 sum, 1 max (device scalars)
 int qd_allreduce_u32(qd_ctx* c, unsigned int* dptr, int n);            // sum
+int qd_allreduce_fetch(qd_ctx* c, double* dptr, int n, int op, double* hdst);   // all-reduce + hand-over to pinned host memory (the call returns when the host can read hdst)
 int qd_allgather_f64(qd_ctx* c, double* buf, int n_per_rank);          // buf[world][n_per_rank]: own segment in, every segment out
 bool qd_peer_on(const qd_ctx* c);                                      // qd_peer.hip: the device-side exchange carries this handle's traffic
 int qd_host_allreduce(qd_ctx* c, double* host_vals, int n, int op);    // op 0 sum, 1 max; HOST scalars through the host ring

@@ -171,7 +171,7 @@ k_stress_max(QdGeom G, const double* __restrict__ ua, const double* __restrict__
 }
 
 __global__ void __launch_bounds__(QD_BLOCK)
-k_max2_finish(const double* __restrict__ partial, int n, double* __restrict__ out) {
+k_max2_finish(const double* __restrict__ partial, int n, double* __restrict__ out, int nzero) {
     __shared__ double sm[2][QD_BLOCK / 64];
     double a = 0.0, b = 0.0;
     for (int k = threadIdx.x; k < n; k += QD_BLOCK) { a = partial[k] > a ? partial[k] : a; b = partial[n + k] > b ? partial[n + k] : b; }
@@ -182,6 +182,7 @@ k_max2_finish(const double* __restrict__ partial, int n, double* __restrict__ ou
     if (threadIdx.x == 0) {
         for (int k = 1; k < QD_BLOCK / 64; ++k) { a = sm[0][k] > a ? sm[0][k] : a; b = sm[1][k] > b ? sm[1][k] : b; }
         out[0] = a; out[1] = b;
+        for (int k = 0; k < nzero; ++k) out[2 + k] = 0.0;    // the slots of segments this band does not have (no memset launch)
     }
 }
 
@@ -720,7 +721,6 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
                 if (qd_wait_host_flag(c, c->hpin_rows + (size_t)2 * G0.lrows() + k, c->eta_seq, "ocean step: the CFL maxima never arrived")) return -1;
             for (int k = 0; k < G.nrows; ++k) { maxVa = std::max(maxVa, c->hpin_rows[k]); maxUo = std::max(maxUo, c->hpin_rows[G.nrows + k]); }
         } else {
-        QD_HIP(c, hipMemsetAsync(c->dscal + QD_S_TMP0, 0, 6 * sizeof(double), c->stream));
         for (int k = 0; k < S.n; ++k) {
             const QdGeom& G = S.g[k];
             // partial maxima of halo segments are harmless (a max over more valid rows of the globe)
@@ -728,7 +728,7 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
                                F[QD_F_VO], p.vcap, p.rho_a_ocean * p.CD, p.tau_scale, taux, tauy,
                                c->red_partial + (size_t)k * 2 * G0.lrows(), (double*)nullptr, 0.0);
             hipLaunchKernelGGL(k_max2_finish, dim3(1), blk, 0, c->stream, c->red_partial + (size_t)k * 2 * G0.lrows(), G.nrows,
-                               c->dscal + QD_S_TMP0 + 2 * k);
+                               c->dscal + QD_S_TMP0 + 2 * k, k == S.n - 1 ? 2 * (3 - S.n) : 0);
         }
         qd_mark(c, {taux, tauy}, m);
         if (qd_has_host_ring(c)) {
@@ -738,10 +738,9 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
             if (qd_host_allreduce(c, c->hpin, 6, 1)) return -1;
         } else {
         // ONE collective of fixed size on every band (polar bands have more segments than interior ones)
-        if (qd_allreduce_f64(c, c->dscal + QD_S_TMP0, 6, 1)) return -1;
-        // a one-wave kernel stores them into pinned host memory behind a stamp the host polls (no hipStreamSynchronize: its wake-up
-        // alone idled the stream for ~20 us per step)
-        if (qd_fetch_scalars(c, c->dscal + QD_S_TMP0, 6, c->hpin)) return -1;
+        // ... stored into pinned host memory behind a stamp the host polls (no hipStreamSynchronize: its wake-up alone idled the stream
+        // for ~20 us per step; over the peer exchange the reducing kernel publishes them itself)
+        if (qd_allreduce_fetch(c, c->dscal + QD_S_TMP0, 6, 1, c->hpin)) return -1;
         }
         for (int k = 0; k < 3; ++k) { maxVa = std::max(maxVa, c->hpin[2 * k]); maxUo = std::max(maxUo, c->hpin[2 * k + 1]); }
         }

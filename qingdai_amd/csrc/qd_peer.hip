@@ -148,7 +148,7 @@ k_halo_unpack(QdPeerHalo A, const char* my_south, const char* my_north, size_t s
 template <int OP>
 __global__ void __launch_bounds__(256)
 k_peer_reduce(char* const* __restrict__ pbox, int world, int rank, size_t off_rv, size_t rv_stride, int parity, unsigned long long* data,
-              int n8, int per, unsigned long long expect, int phase, double* herr, int coarse) {
+              int n8, int per, unsigned long long expect, int phase, double* herr, int coarse, double* hdst, double* hstamp, double hseq) {
     const int i0 = blockIdx.x * per, i1 = min(n8, i0 + per);
     if (phase & 1) {
         const unsigned long long* src = OP == 3 ? data + (size_t)rank * n8 : data;
@@ -184,7 +184,15 @@ k_peer_reduce(char* const* __restrict__ pbox, int world, int rank, size_t off_rv
                     a = OP == 1 ? (b > a ? b : a) : a + b;
                 }
                 ((double*)data)[i] = a;
+                // the host is waiting for these few numbers (CFL maxima -> n_sub): they leave for pinned host memory from here
+                if (hdst) __hip_atomic_store((unsigned long long*)hdst + i, (unsigned long long)__double_as_longlong(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
+        }
+        if (hdst) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0)
+                __hip_atomic_store((unsigned long long*)hstamp, (unsigned long long)__double_as_longlong(hseq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -326,13 +334,13 @@ int qd_peer_halo_end(qd_ctx* c) { return qp_halo_unpack(c); }
 
 // ---- reductions
 template <int OP>
-static void qp_launch_reduce(qd_ctx* c, unsigned long long* data, int n8, int nb, int per, int par, int phase) {
+static void qp_launch_reduce(qd_ctx* c, unsigned long long* data, int n8, int nb, int per, int par, int phase, double* hdst, double hseq) {
     QdPeer* P = c->peer;
     hipLaunchKernelGGL(k_peer_reduce<OP>, dim3(nb), dim3(256), 0, c->stream, (char* const*)P->d_pbox, P->world, P->rank, P->off_rv,
-                       P->rv_stride, par, data, n8, per, P->rexp, phase, P->herr, P->coarse);
+                       P->rv_stride, par, data, n8, per, P->rexp, phase, P->herr, P->coarse, hdst, c->hpin + 61, hseq);
 }
 
-static int qp_reduce(qd_ctx* c, unsigned long long* data, int n8, int op) {
+static int qp_reduce(qd_ctx* c, unsigned long long* data, int n8, int op, double* hdst = nullptr, double hseq = 0.0) {
     QdPeer* P = c->peer;
     if (n8 < 1 || n8 > QP_RV) return qp_fail(c, "peer exchange: reduction longer than a mailbox slot");
     const int per = 512;                                          // 8-byte units per workgroup
@@ -341,10 +349,10 @@ static int qp_reduce(qd_ctx* c, unsigned long long* data, int n8, int op) {
     P->rseq += 1; P->rexp += (unsigned long long)nb; P->n_reduce += 1;
     auto launch = [&](int phase) {
         switch (op) {
-            case 0: qp_launch_reduce<0>(c, data, n8, nb, per, par, phase); break;
-            case 1: qp_launch_reduce<1>(c, data, n8, nb, per, par, phase); break;
-            case 2: qp_launch_reduce<2>(c, data, n8, nb, per, par, phase); break;
-            default: qp_launch_reduce<3>(c, data, n8, nb, per, par, phase); break;
+            case 0: qp_launch_reduce<0>(c, data, n8, nb, per, par, phase, (phase & 2) ? hdst : nullptr, hseq); break;
+            case 1: qp_launch_reduce<1>(c, data, n8, nb, per, par, phase, (phase & 2) ? hdst : nullptr, hseq); break;
+            case 2: qp_launch_reduce<2>(c, data, n8, nb, per, par, phase, nullptr, 0.0); break;
+            default: qp_launch_reduce<3>(c, data, n8, nb, per, par, phase, nullptr, 0.0); break;
         }
     };
     if (P->local) { launch(1); pthread_barrier_wait(&c->lgroup->bar); launch(2); }
@@ -374,6 +382,13 @@ int qd_peer_allreduce(qd_ctx* c, void* dptr, int n, int kind) {
         return qp_reduce(c, (unsigned long long*)dptr, (n + 1) / 2, 2);
     }
     return qp_reduce(c, (unsigned long long*)dptr, n, kind ? 1 : 0);
+}
+
+// all-reduce of n <= 256 doubles whose result the HOST needs at once: the collecting workgroup also stores it into pinned host
+// memory (hdst) and stamps c->hpin[61] with hseq (the caller polls the stamp: qd_wait_host_flag)
+int qd_peer_allreduce_publish(qd_ctx* c, double* dptr, int n, int op_max, double* hdst, double hseq) {
+    if (n > 256) return qp_fail(c, "peer exchange: published reduction longer than 256 values");
+    return qp_reduce(c, (unsigned long long*)dptr, n, op_max ? 1 : 0, hdst, hseq);
 }
 
 int qd_peer_allgather(qd_ctx* c, double* buf, int n_per_rank) {

@@ -826,9 +826,21 @@ __device__ __forceinline__ void qd_med_final_body(unsigned long long* st, const 
 __global__ void __launch_bounds__(QD_FIN_BLOCK)
 k_med_final(unsigned long long* st, const double* __restrict__ cand, unsigned int* ccount, double* pred,
             const double* __restrict__ field, unsigned long long n_field, int transform, double tparam, double dflt, double* out,
-            unsigned long long* count_out, int world, unsigned int cap, double* miss_flag, unsigned int* hist_reset) {
+            unsigned long long* count_out, int world, unsigned int cap, double* miss_flag, unsigned int* hist_reset,
+            double* host_flag, double* host_stamp, double seq) {
     qd_med_final_body<QD_FIN_BLOCK>(st, cand, ccount, pred, field, n_field, transform, tparam, dflt, out, count_out, world, cap, miss_flag,
                                     hist_reset);
+    if (host_flag) {
+        // latitude bands: the host decides on the miss flag whether the six-pass select has to run -- it goes out from here, behind a
+        // stamp the host polls (no k_publish_host launch, no stream synchronisation)
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double f = __hip_atomic_load(miss_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store((unsigned long long*)host_flag, (unsigned long long)__double_as_longlong(f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store((unsigned long long*)host_stamp, (unsigned long long)__double_as_longlong(seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // result + reset of the select state for the next call; `count_out` (optional) keeps the count
@@ -863,7 +875,7 @@ int qd_median_positive_dev(qd_ctx* c, const double* x, double dflt, int slot, in
                                c->sel_cand, c->sel_ccount, (unsigned int)c->geo.cells());
             hipLaunchKernelGGL(k_med_final, dim3(1), dim3(QD_FIN_BLOCK), 0, c->stream, c->sel_state, c->sel_cand, c->sel_ccount, pred, x,
                                (unsigned long long)c->geo.cells(), transform, tparam, dflt, c->dscal + slot, c->dcount, 0, 0u,
-                               (double*)nullptr, c->hist);
+                               (double*)nullptr, c->hist, (double*)nullptr, (double*)nullptr, 0.0);
             return 0;
         }
         c->med_seen[site] = 1;                                // first use: the digit-by-digit select below, then seed the window
@@ -900,16 +912,20 @@ int qd_median_positive_dev(qd_ctx* c, const double* x, double dflt, int slot, in
         const size_t segd = (size_t)cap + 4u;
         hipLaunchKernelGGL(k_med_hist, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, bpred, c->hist, 1);
         if (qd_allreduce_u32(c, c->hist, QD_HIST_BINS + 2)) return -1;
-        hipLaunchKernelGGL(k_med_hist, dim3(1, 1), dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, bpred, c->hist, 2);
         if (!qd_peer_on(c)) QD_HIP(c, hipMemsetAsync(c->med_gather, 0, (size_t)world * segd * sizeof(double), c->stream));
         double* seg = c->med_gather + (size_t)rank * segd;
-        hipLaunchKernelGGL(k_med_bracket, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, bpred + 8, c->sel_state,
+        // every workgroup of the collecting pass scans the all-reduced histogram for itself (the whole globe's k_med_scan_bracket: no
+        // one-workgroup scan launch in between); k_med_final resets the histogram and hands the miss flag to the host
+        hipLaunchKernelGGL(k_med_scan_bracket, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, bpred, c->hist, c->sel_state,
                            seg + 4, c->sel_ccount, cap);
         hipLaunchKernelGGL(k_med_pack, dim3(1), dim3(64), 0, c->stream, c->sel_state, c->sel_ccount, seg);
         if (qd_allgather_f64(c, c->med_gather, (int)segd)) return -1;
+        c->pub_seq += 1.0;
         hipLaunchKernelGGL(k_med_final, dim3(1), dim3(QD_FIN_BLOCK), 0, c->stream, c->sel_state, c->med_gather, c->sel_ccount, bpred, x,
-                           0ull, transform, tparam, dflt, c->dscal + slot, c->dcount, world, cap, c->dscal + QD_S_TMP1, (unsigned int*)nullptr);
-        if (qd_fetch_scalars(c, c->dscal + QD_S_TMP1, 1, c->hpin + 32)) return -1;
+                           0ull, transform, tparam, dflt, c->dscal + slot, c->dcount, world, cap, c->dscal + QD_S_TMP1, c->hist,
+                           c->hpin + 32, c->hpin + 61, c->pub_seq);
+        if (qd_wait_host_flag(c, c->hpin + 61, c->pub_seq, "band median: the miss flag never reached the host")) return -1;
+        if (c->hpin[60] != 0.0) return qd_fail(c, "peer exchange: a rank did not arrive within the deadline");
         if (c->hpin[32] == 0.0) return 0;
     }
     for (int p = 0; p < 6; ++p) {
