@@ -428,12 +428,17 @@ def main():
                     if e.get("avg_kernel_ms_rocprof"):
                         out[key]["frac_rocprof"] = (out[key]["bytes_per_cell"] * cells / 1e9) / (e["avg_kernel_ms_rocprof"] / 1e3) / HBM_PEAK_GBS
                     out[key]["profile_source"] = "profiles/" + os.path.basename(prof) + " (" + pj.get("source", "") + ")"
-                    # the committed profile carries a hash of the kernel sources it was measured on: say so when they have changed since
-                    import hashlib
-                    cs = os.path.join(os.path.dirname(os.path.abspath(__file__)), "qingdai_amd", "csrc")
-                    stale = [f for f, h in pj.get("kernel_sources_sha256_16", {}).items()
-                             if not os.path.exists(os.path.join(cs, f)) or hashlib.sha256(open(os.path.join(cs, f), "rb").read()).hexdigest()[:16] != h]
-                    out[key]["profile_stale"] = bool(stale)
+                    # the committed profile carries the hash of the DEVICE code it was measured on (qingdai_amd/_codehash.py: the
+                    # .hip_fatbin of the profiled translation units; host-only edits do not touch it): say so when that has changed
+                    from qingdai_amd import _codehash
+                    if pj.get("device_code_sha256_16"):
+                        out[key]["profile_stale"] = bool(_codehash.stale_against(pj["device_code_sha256_16"]))
+                    else:                                     # profiles of rounds 1-3: source-file hashes
+                        import hashlib
+                        cs = os.path.join(os.path.dirname(os.path.abspath(__file__)), "qingdai_amd", "csrc")
+                        stale = [f for f, h in pj.get("kernel_sources_sha256_16", {}).items()
+                                 if not os.path.exists(os.path.join(cs, f)) or hashlib.sha256(open(os.path.join(cs, f), "rb").read()).hexdigest()[:16] != h]
+                        out[key]["profile_stale"] = bool(stale)
     except Exception:
         pass
     # supplementary, outside the timed region: the same grid with the driver's full iteration (+ hydrology commit) and the

@@ -61,7 +61,9 @@ def main():
     import hashlib
     srcs = ["qd_stream.hip", "qd_stream.h", "qd_ocntail.hip", "qd_wave.h"]
     stamp = {f: hashlib.sha256(open(os.path.join(ROOT, "qingdai_amd", "csrc", f), "rb").read()).hexdigest()[:16] for f in srcs}
-    fk = {"grid": [nlat, nlon], "kernel_sources_sha256_16": stamp, "source": f"rocprofv3 kernel trace + FETCH_SIZE / WRITE_SIZE passes of bench.py (scripts/profile_round.sh {tag}, "
+    sys.path.insert(0, ROOT)
+    from qingdai_amd import _codehash
+    fk = {"grid": [nlat, nlon], "kernel_sources_sha256_16": stamp, "device_code_sha256_16": _codehash.device_code_stamp(), "source": f"rocprofv3 kernel trace + FETCH_SIZE / WRITE_SIZE passes of bench.py (scripts/profile_round.sh {tag}, "
                                          f"scripts/assemble_profiles.py); profiles/README.md", "kernels": {}}
     dyn = next(k for k in tr if "k_dyn_stream" in k)
     tail = next(k for k in tr if "k_ocn_tail_fast" in k or "k_ocn_tail_stream" in k)      # round 3b: k_ocn_tail_fast; before: "void k_ocn_tail_stream<1>"

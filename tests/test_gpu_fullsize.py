@@ -89,7 +89,14 @@ def test_fused_paths_agree_at_benchmark_tile_shape(gpu, monkeypatch):
         assert relerr(fast[k], unfused[k]) < (1e-7 if k in ("UO", "VO", "ETA") else 1e-9), k
 
 
-def test_eight_bands_match_the_whole_globe(gpu):
+@pytest.mark.parametrize("transport", ["host", "peer"])
+def test_eight_bands_match_the_whole_globe(gpu, transport, monkeypatch):
+    """721 x 1440 in 8 latitude bands against the whole globe.  host: the in-process transport (device-to-device copies, host ring);
+    peer: the device-side exchange over the peer mapping (qd_peer.hip: halo rows and global sums through the mailboxes, the ocean
+    momentum kernel split into interior / boundary rows around every exchange) -- the transport a multi-GPU run takes."""
+    if transport == "peer":
+        monkeypatch.setenv("QD_PEER_EXCHANGE", "1")
+        monkeypatch.setenv("QD_PEER_OVERLAP", "1")
     ref, _ = _run(1, NLAT, NLON, 2, dict(energy_w=1.0), True, True)
     got, ex = _run(8, NLAT, NLON, 2, dict(energy_w=1.0), True, True)
     print("halo exchanges per band:", ex)
