@@ -292,6 +292,8 @@ static void qd_read_tuning(qd_ctx* c) {
     { const int b = geti("QD_MED_BLOCKS", 0); if (b >= 16) t.med_blocks = b; }
     t.shapiro_r = std::max(0, geti("QD_SHAPIRO_R", 0));
     t.tile_tr = std::max(0, geti("QD_TILE_TR", 0));
+    t.fused_r = std::max(0, geti("QD_FUSED_R", 0));
+    t.fused_seq = geti("QD_FUSED_SEQ", 0) == 1 ? 1 : 0;
 }
 extern "C" int qd_tune_reload(qd_handle c) { if (!c) return -1; qd_read_tuning(c); c->tile = QdTileShape{0, 0, 0, 0}; return 0; }
 
@@ -316,6 +318,7 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
     { const char* ef = std::getenv("QD_SHAPIRO_STREAM"); if (ef) c->shapiro_stream = std::atoi(ef); }
     { const char* ef = std::getenv("QD_OCN_TAIL"); if (ef) c->ocn_tail = std::atoi(ef); }   // 0: two launches (k_cont_sstadv, k_sst_outlier_fused); anything else: k_ocn_tail_fast (QD_TAIL_V=1: k_ocn_tail_stream).  The LDS-tile forms and the one-launch sub-step of round 3 (2, 3, 4) are retired: tools/retired/
     if (c->ocn_tail != 0) c->ocn_tail = 1;
+    { const char* ef = std::getenv("QD_OCN_FUSED"); if (ef) c->ocn_fused = ef[0] == '1' ? 1 : 0; }
     { const char* ef = std::getenv("QD_BAND_TAIL"); if (ef) c->band_tail = ef[0] == '0' ? 0 : 1; }
     qd_read_tuning(c);
     { const char* ef = std::getenv("QD_GROUP_SUMS"); if (ef) c->group_sums = ef[0] == '0' ? 0 : 1; }

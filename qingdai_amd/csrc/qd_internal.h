@@ -166,6 +166,8 @@ struct QdTune {
     int med_blocks = 256;     // QD_MED_BLOCKS: fat workgroups of the median passes
     int shapiro_r = 0;        // QD_SHAPIRO_R: strip height of k_shapiro_stream
     int tile_tr = 0;          // QD_TILE_TR: tile height of the LDS fallback kernels
+    int fused_r = 0;          // QD_FUSED_R: strip height of k_ocn_fused
+    int fused_seq = 0;        // QD_FUSED_SEQ=1: every strip of k_ocn_fused takes its sequential form (tests)
 };
 struct QdTileShape { int tr, tc, ntr, ntc; };
 
@@ -227,6 +229,7 @@ struct qd_ctx {
     int tail_acc = 1;               // QD_TAIL_ACC=0: the eta mean of a sub-step from k_eta_mean_tail instead of the tail kernel's own last workgroup
     unsigned long long* eta_acc = nullptr;   // accumulator + tickets of the tail kernel's strip sums (qd_wave.h: QD_ACC_WORDS)
     int shapiro_stream = 1;         // QD_SHAPIRO_STREAM=0: one k_shapiro_pass launch per pass
+    int ocn_fused = 0;              // QD_OCN_FUSED=1: the whole ocean sub-step as ONE launch (k_ocn_fused, qd_ocntail.hip)
     int ocn_tail = 1;               // QD_OCN_TAIL=0: continuity + SST + outlier filter as the two launches of qd_ocean.hip
     int stream_rows = 0;            // QD_STREAM_R: strip height of the row-streaming kernels (0 = pick per launch)
     // row-streaming kernels (qd_stream.hip): per-field packed row tables {lapA[r+1], lapP[r], lapQ[r], k4[r]}, [0] atmosphere

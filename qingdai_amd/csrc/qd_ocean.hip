@@ -791,7 +791,39 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
     // QD_TAIL_ACC (default): the streaming tail kernel reduces its own strip sums (fixed-point atomics + spread tickets, qd_wave.h)
     // and its last workgroup writes the mean -- no k_eta_mean_tail launch (4.5 us of launch floor per sub-step)
     const bool tail_acc = use_tail && c->tail_acc;
+    // QD_OCN_FUSED=1: the WHOLE sub-step is one launch (k_ocn_fused, qd_ocntail.hip): the momentum + del^4 waves hand their rows to the
+    // tail waves of the same strip through LDS rings; uo', vo', eta' never reach memory
+    const bool use_fused1 = use_tail && !band && c->ocn_fused && c->ocn_tail == 1 && tail_acc && c->fused_fast == 1 && do_diff &&
+                            p.ocean_k4_nsub == 1 && !do_shap && HP.use_q && HP.K_h > 0.0 && qd_ocn_fused_ok(c);
     for (int s = 0; s < n_sub; ++s) {
+        if (use_fused1) {
+            QdOcnArgs O;
+            O.uo = F[QD_F_UO]; O.vo = F[QD_F_VO]; O.eta = F[QD_F_ETA]; O.taux = taux; O.tauy = tauy; O.land = c->land;
+            // (scratch slabs of the sequential form: the polar tiles and any strip whose fast waves gave up)
+            O.uo_out = qd_scratch(c, 0); O.vo_out = qd_scratch(c, 1); O.eta_out = qd_scratch(c, 6);
+            for (int f = 0; f < 3; ++f) {
+                const bool sc1 = !(ov[f] != ov[f]);
+                O.k4row[f] = sc1 ? nullptr : c->k4_ocn + (size_t)f * G0.nlat;
+                O.k4s[f] = sc1 ? ov[f] : 0.0;
+                O.skip[f] = c->k4_ocn_skip[f];
+            }
+            O.a = p.a; O.g = p.g_ocean; O.dlat = c->dlat; O.dlon = c->dlon; O.sub_dt = sub_dt; O.rhoH = p.rho_w * H; O.r_bot = p.r_bot;
+            O.inv_2dlon = 1.0 / (2.0 * c->dlon); O.inv_2dlat = 1.0 / (2.0 * c->dlat); O.inv_a = 1.0 / p.a; O.inv_rhoH = 1.0 / (p.rho_w * H);
+            O.eta_mean = s > 0 ? mean_ptr : nullptr;
+            O.eta_cap = p.eta_cap;
+            QdTailArgs A;
+            A.uo = O.uo_out; A.vo = O.vo_out; A.eta_in = O.eta_out; A.Ts = F[QD_F_SST]; A.qnet = F[QD_F_QNET]; A.land = c->land; A.ice = c->icemask;
+            A.eta = qd_scratch(c, 2); A.Ts_out = qd_scratch(c, 3); A.uo_out = qd_scratch(c, 12); A.vo_out = qd_scratch(c, 13); A.partial = c->red_partial;
+            A.a = p.a; A.dlat = c->dlat; A.dlon = c->dlon; A.sub_dt = sub_dt; A.msdtH = -sub_dt * H; A.alpha = p.ocean_adv_alpha;
+            A.K_h = HP.K_h; A.rcH = HP.rcH; A.ice_qfac = HP.ice_qfac; A.cap = p.ocean_max_u;
+            A.use_q = HP.use_q; A.has_ice = HP.has_ice; A.mean4 = p.ocean_outlier == 0 ? 1 : 0;
+            A.r_a = 1.0 / p.a; A.r_dlon = 1.0 / c->dlon; A.r_dlat = 1.0 / c->dlat; A.r_2dlon = 1.0 / (2 * c->dlon); A.r_2dlat = 1.0 / (2 * c->dlat);
+            A.r_rcH = 1.0 / HP.rcH;
+            A.acc = c->eta_acc; A.mean_out = c->dscal + QD_S_ETA_MEAN; A.wsum = c->wsum_ocean;
+            if (qd_launch_ocn_fused(c, O, A)) return -1;
+            qd_swap(c, QD_F_UO, 12); qd_swap(c, QD_F_VO, 13); qd_swap(c, QD_F_ETA, 2); qd_swap(c, QD_F_SST, 3);
+            continue;
+        }
         if (do_diff && c->use_fused && p.ocean_k4_nsub == 1) {
             // band_tail: every exchange of the sub-step happens HERE, so that the previous sub-step's eta sum (still pending) can ride
             // in its group: the momentum kernel is planned two rows wider than it needs (its outputs then carry the margin the tail's

@@ -16,8 +16,15 @@ struct QdTailArgs {
     int use_q, has_ice, mean4, ntc, R, Rp;                   // R: strip height of the streaming forms; Rp: height of a pole strip (k_ocn_tail_fast)
     int nmid, flags;                                         // k_ocn_tail_fast: strips between the pole strips; bit0 = every wave takes the general form
     int own0, own1;                                          // rows whose eta enters the area-weighted sum (a band's owned rows; set by the launcher for whole-globe handles)
+    const double* eta_in = nullptr;                          // k_ocn_fused, sequential form: eta' comes from this slab, the new eta goes to `eta` (nullptr: `eta` in place)
     QdPeerFold pf;                                           // latitude bands over the peer exchange: the finishing wave all-reduces the band's share itself (qd_peer_dev.h)
 };
 
 int qd_ocn_tail_tiles(const qd_ctx* c, const QdGeom& G);
 int qd_launch_ocn_tail(qd_ctx* c, const QdGeom& G, QdTailArgs& P);
+
+// the whole sub-step in one launch, streaming form (QD_OCN_FUSED=1; qd_ocntail.hip, k_ocn_fused)
+struct QdOcnArgs;
+bool qd_ocn_fused_ok(const qd_ctx* c);
+int qd_ocn_fused_tiles(const qd_ctx* c);
+int qd_launch_ocn_fused(qd_ctx* c, const QdOcnArgs& O, QdTailArgs& P);

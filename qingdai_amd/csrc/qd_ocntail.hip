@@ -125,17 +125,18 @@ __device__ __forceinline__ unsigned qt_row_roll(const QtW& W, int g) { if (g < 0
 __device__ __forceinline__ double qt_currents_wave(const QdTabs& T, const QdTailArgs& P, const QtW& W) {
     const unsigned sb = W.slab;
     const qt_rsrc U = qt_make_rsrc(P.uo, sb), V = qt_make_rsrc(P.vo, sb), E = qt_make_rsrc(P.eta, sb), L = qt_make_rsrc(P.land, sb / 8u);
+    const qt_rsrc EI = qt_make_rsrc(P.eta_in ? P.eta_in : P.eta, sb);       // (k_ocn_fused's sequential form reads eta' from a slab of its own)
     const qt_rsrc UO = qt_make_rsrc(P.uo_out, sb), VO = qt_make_rsrc(P.vo_out, sb);
     // np.roll rows: mean4 of the outlier filter reads row -1 as row n-1 and row n as row 0
     double us = qt_ld(U, qt_row_roll(W, W.o0 - 1), W.vo), vs = qt_ld(V, qt_row_roll(W, W.o0 - 1), W.vo);
     double uc = qt_ld(U, qt_row(W, W.o0), W.vo), vc = qt_ld(V, qt_row(W, W.o0), W.vo);
-    double en = qt_ld(E, qt_row(W, W.o0), W.vo); int ln = qt_ld8(L, qt_row(W, W.o0), W.vo8);
+    double en = qt_ld(EI, qt_row(W, W.o0), W.vo); int ln = qt_ld8(L, qt_row(W, W.o0), W.vo8);
     double acc = 0.0;
     for (int g = W.o0; g < W.o1; ++g) {
         const unsigned rn = qt_row_roll(W, g + 1), r1 = qt_row(W, g + 1);
         const double un = qt_ld(U, rn, W.vo), vn = qt_ld(V, rn, W.vo);                 // row g+1 (in flight while row g is worked on)
         const double e0 = en; const int l0 = ln;
-        en = qt_ld(E, r1, W.vo); ln = qt_ld8(L, r1, W.vo8);
+        en = qt_ld(EI, r1, W.vo); ln = qt_ld8(L, r1, W.vo8);
         // divergence (grid.py:41-88 through qt_div_point's expressions)
         const double dp = qt_div(qd_east(uc) - qd_west(uc), 2 * P.dlon, P.r_2dlon);
         double dq = 0.0;
@@ -394,14 +395,30 @@ __device__ __forceinline__ double qt_vreg(double x) {
     return y;
 }
 
+// k_ocn_fused (below): uo', vo', eta' rows arrive through an LDS ring instead of global memory.  prog[0..2]: rows produced so far by the
+// uo / vo / eta waves (= first row not yet there), prog[3], prog[4]: first row the currents / the SST wave still needs.
+#define QFU_NR 16                 // rows of a ring (power of two)
+struct QfuRing { double* u; double* v; double* e; int* prog; };
+__device__ __forceinline__ void qfu_wait_gt(const int* p, int row) {          // until *p > row (LDS poll; all waves of the workgroup are resident)
+    while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= row) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ double qfu_ring_ld(const double* plane, int row, int lane) { return plane[(row & (QFU_NR - 1)) * 64 + lane]; }
+
 struct QtCurSlot { double u, v, e; int l; qt_f64x2 k0, k1; };
 struct QtCurK { double dlon2, r_2dlon, dlat2, r_2dlat, msdtH, cap, cap81; int mean4; };
 
 // one row of the continuity + caps wave away from the poles; `ro`: element offset of row g in the slab
+// RING: u, v of row g + 1 and eta of row g come from the LDS ring of k_ocn_fused (R), everything else as before
+template <bool RING = false>
 __device__ __forceinline__ void qt_cur_fast_step(const QtCurK& P, const QtW& W, qt_rsrc U, qt_rsrc V, qt_rsrc E, qt_rsrc L,
                                                  qt_rsrc UO, qt_rsrc VO, qt_rsrc KT, double& us, double& uc, double& vs, double& vc, double& acc,
-                                                 QtCurSlot& sl, int g, unsigned ro) {
-    const double un = qs_own(sl.u), vn = qs_own(sl.v), e0 = sl.e;
+                                                 QtCurSlot& sl, int g, unsigned ro, const QfuRing* R = nullptr) {
+    double un, vn, e0;
+    if (RING) {
+        qfu_wait_gt(R->prog + 0, g + 1); qfu_wait_gt(R->prog + 1, g + 1); qfu_wait_gt(R->prog + 2, g);
+        un = qfu_ring_ld(R->u, g + 1, W.lane); vn = qfu_ring_ld(R->v, g + 1, W.lane); e0 = qfu_ring_ld(R->e, g, W.lane);
+    } else { un = qs_own(sl.u); vn = qs_own(sl.v); e0 = sl.e; }
     const bool island = sl.l == 1;
     const double ue = qd_east(uc), uw = qd_west(uc), ve = qd_east(vc), vw = qd_west(vc);
     const double dp = qt_div(ue - uw, P.dlon2, P.r_2dlon);
@@ -432,9 +449,11 @@ __device__ __forceinline__ void qt_cur_fast_step(const QtCurK& P, const QtW& W, 
     }
     qt_st(UO, ro, W.vs, u); qt_st(VO, ro, W.vs, v);
     us = uc; uc = un; vs = vc; vc = vn;
+    if (RING) { if (W.lane == 0) __hip_atomic_store(R->prog + 3, g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }     // rows <= g are done with
     __builtin_amdgcn_sched_barrier(0);
     const unsigned r2 = ro + 2u * (unsigned)W.m;              // what step g + 2 consumes: u, v of row g + 3, eta and land of row g + 2
-    sl.u = qt_ld(U, r2 + (unsigned)W.m, W.vo); sl.v = qt_ld(V, r2 + (unsigned)W.m, W.vo); sl.e = qt_ld(E, r2, W.vo); sl.l = qt_ld8(L, r2, W.vo8);
+    if (!RING) { sl.u = qt_ld(U, r2 + (unsigned)W.m, W.vo); sl.v = qt_ld(V, r2 + (unsigned)W.m, W.vo); sl.e = qt_ld(E, r2, W.vo); }
+    sl.l = qt_ld8(L, r2, W.vo8);
     sl.k0 = qt_ldk(KT, 16u * (unsigned)(g + 2), 4u); sl.k1 = qt_ldk(KT, 16u * (unsigned)(g + 2), 5u);
     __builtin_amdgcn_sched_barrier(0);                       // (else the next step's arithmetic is scheduled in front of these loads)
 }
@@ -477,15 +496,20 @@ __device__ __forceinline__ double qt_shfl(double x, int src_lane) {
 
 // One row step of the SST wave away from the poles.  g: the row whose T1 is computed; ro: element offset of row g.  OUT: row g - 2 is
 // finished (K_h lap of the window + heating) and stored.  Returns through `bad` whether a lane needed the general gather.
-template <bool EDGE, bool OUT>
+template <bool EDGE, bool OUT, bool RING = false>
 __device__ __forceinline__ void qt_sst_fast_step(const QtSstK& K, const QtW& W, qt_rsrc U, qt_rsrc V, qt_rsrc S, qt_rsrc Q,
                                                  qt_rsrc L, qt_rsrc I, qt_rsrc SO, qt_rsrc KT, double& Tm, double& T0, double& Wm, double& W0, double& Em,
                                                  double& E0, double& w0, double& w1, double& w2, double& w3, double& w4, bool& bad,
-                                                 QtSstSlot& sl, int g, unsigned ro) {
+                                                 QtSstSlot& sl, int g, unsigned ro, const QfuRing* R = nullptr) {
     const double Tp = qs_own(sl.s);                           // SST row g + 1: lives on as row g of the next step
     double Wp = 0.0, Ep = 0.0;
     if (!EDGE) { Wp = qd_west(Tp); Ep = qd_east(Tp); }
-    const double u = sl.u, v = sl.v;
+    double u, v;
+    if (RING) {                                               // k_ocn_fused: the currents of row g come out of the LDS ring
+        qfu_wait_gt(R->prog + 0, g); qfu_wait_gt(R->prog + 1, g);
+        u = qfu_ring_ld(R->u, g, W.lane); v = qfu_ring_ld(R->v, g, W.lane);
+        if (W.lane == 0) __hip_atomic_store(R->prog + 4, g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else { u = sl.u; v = sl.v; }
     // qt_departure's arithmetic, piece by piece
     const double acos = sl.k0.x, r_acos = sl.k0.y;
     const double dl = qt_div_fin(u * K.dt, acos, r_acos);
@@ -542,7 +566,8 @@ __device__ __forceinline__ void qt_sst_fast_step(const QtSstK& K, const QtW& W, 
     }
     __builtin_amdgcn_sched_barrier(0);
     const unsigned r2 = ro + 2u * (unsigned)W.m;              // what step g + 2 consumes
-    sl.u = qt_ld(U, r2, W.vo); sl.v = qt_ld(V, r2, W.vo); sl.s = qt_ld(S, r2 + (unsigned)W.m, W.vo);
+    if (!RING) { sl.u = qt_ld(U, r2, W.vo); sl.v = qt_ld(V, r2, W.vo); }
+    sl.s = qt_ld(S, r2 + (unsigned)W.m, W.vo);
     sl.q = qt_ld(Q, ro, W.vo); sl.l = qt_ld8(L, ro, W.vo8); sl.ic = qt_ld8(I, ro, W.vo8);
     sl.k0 = qt_ldk(KT, 16u * (unsigned)(g + 2), 0u); sl.k1 = qt_ldk(KT, 16u * (unsigned)(g + 2), 1u); sl.k2 = qt_ldk(KT, 16u * (unsigned)(g + 2), 2u);
     __builtin_amdgcn_sched_barrier(0);                       // (else the next step's arithmetic is scheduled in front of these loads)
@@ -634,6 +659,272 @@ k_ocn_tail_fast(QdGeom G, QdTabs T, QdTailArgs P) {
             if (W.lane == 0) *P.mean_out = mm;
         }
     }
+}
+
+// =========================================================================================
+// the WHOLE ocean sub-step in one launch, streaming form (round 4; QD_OCN_FUSED=1)
+// =========================================================================================
+// k_ocn_stream writes uo', vo', eta' (the momentum update + del^4: ocean.py:306-356) and k_ocn_tail_fast reads them back (continuity,
+// SST, outlier filter: ocean.py:365-444): 25 MB out, 33 MB in again, two launches with a ramp each.  Here a 320-thread workgroup owns
+// a strip of R rows x 56 columns (lanes 4 .. 59 of 64) and its five waves run CONCURRENTLY:
+//   waves 0, 1, 2   the uo / vo / eta waves of qd_stream.h on rows o0 - 2 .. o1 + 1 (what the SST advection needs), their output rows
+//                   going into three LDS rings of QFU_NR rows instead of global memory (QsOutRing),
+//   wave 3          the currents wave of k_ocn_tail_fast (continuity, eta sum, outlier filter / caps), uo', vo', eta' from the rings,
+//   wave 4          its SST wave (register gather, K_h lap, heating), uo', vo' from the rings;
+// producers publish "rows so far" in LDS, consumers "first row still needed"; a producer waits when it is a ring ahead.  uo', vo',
+// eta' never reach memory; the same device functions in the same order as the two launches: bit-identical fields, the eta sum in
+// another strip order.
+// What cannot stream takes the SEQUENTIAL form inside the same launch -- K1 of the strip into the global scratch slabs, workgroup
+// barrier, the general tail waves from there --: (a) the two polar tiles of a column strip (rows 0 .. 6 and n-7 .. n-1; np.roll(axis=0)
+// couples them: mean4 reads row -1 as row n-1), which ONE workgroup owns, (b) any strip whose fast waves raised `bad` (a non-finite
+// value, a departure point a cell away): the strip is done again -- every output goes to a buffer nobody reads during the launch.
+#define QFU_TC 56
+#define QFU_PH 7
+typedef double __attribute__((address_space(3)))* qfu_ldp;
+typedef int __attribute__((address_space(3)))* qfu_lip;
+struct QfuArgs { int ntc, nmid, R, mode; };                  // mode bit0: every strip takes the sequential form (tests)
+
+struct QsOutRing {                // where a streaming K1 wave's rows go
+    double* plane; int* prod; const int* c3; const int* c4; int row, chk, lane;
+    __device__ __forceinline__ void put(double v) {
+        if (row >= chk) {                                    // room for rows row .. row + 3 ?
+            for (;;) {
+                const int a = __hip_atomic_load(c3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int b = __hip_atomic_load(c4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (row + 3 - (a < b ? a : b) < QFU_NR) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            chk = row + 4;
+        }
+        plane[(row & (QFU_NR - 1)) * 64 + lane] = v;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the row is in LDS before its number is
+        if (lane == 0) __hip_atomic_store(prod, row + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        ++row;
+    }
+};
+
+// the strip as the K1 waves see it: rows [k0, k1) to produce, lanes 3 .. 60 hold valid columns (stored at the WRAPPED column: a
+// duplicate of a neighbouring strip's column carries the same bits)
+__device__ __forceinline__ void qfu_k1w(const QdGeom& G, int cs, int k0, int k1, QsW& W) {
+    W.n = G.nlat; W.nlon = G.nlon; W.lane = threadIdx.x & 63;
+    const int jraw = cs * QFU_TC - 4 + W.lane;
+    W.j = jraw < 0 ? jraw + G.nlon : (jraw >= G.nlon ? jraw - G.nlon : jraw);
+    W.vo = (unsigned)W.j * 8u; W.vo8 = (unsigned)W.j;
+    W.vs = (W.lane >= 3 && W.lane <= 60) ? (unsigned)W.j * 8u : QS_OOB;
+    W.slab_bytes = (unsigned)(G.lrows_ + QD_PAD_ROWS) * (unsigned)G.nlon * 8u;
+    W.west_edge = W.j == 0; W.east_edge = W.j == G.nlon - 1;
+    W.o0 = k0; W.o1 = k1;
+}
+__device__ __forceinline__ void qfu_tailw(const QdGeom& G, const QdTailArgs& P, int cs, int o0, int o1, QtW& W) {
+    W.n = G.nlat; W.m = G.nlon; W.lane = threadIdx.x & 63;
+    W.jbase = cs * QFU_TC - 4;
+    const int jraw = W.jbase + W.lane;
+    W.j = jraw < 0 ? jraw + W.m : (jraw >= W.m ? jraw - W.m : jraw);
+    W.own = W.lane >= 4 && W.lane <= 3 + QFU_TC && jraw < W.m;
+    W.vo = (unsigned)W.j * 8u; W.vo8 = (unsigned)W.j; W.vs = W.own ? (unsigned)jraw * 8u : 0x80000000u;
+    W.slab = (unsigned)(G.lrows_ + QD_PAD_ROWS) * (unsigned)G.nlon * 8u;
+    W.lbase = G.lbase; W.lrows = G.lrows_; W.own0 = P.own0; W.own1 = P.own1;
+    W.o0 = o0; W.o1 = o1;
+}
+
+// K1 of rows [k0, k1) into the global scratch slabs (FAST, and EXACT again for a wave that saw a non-finite value: k_ocn_stream's logic)
+__device__ __forceinline__ void qfu_k1_global(const QsOcnArgs& A, int cs, int k0, int k1, int wv, const QsRec QD_CONST* fp) {
+    QsW W;
+    qfu_k1w(A.G, cs, k0, k1, W);
+    if (!A.exact) {
+        QsOutGlobal out{qs_make_rsrc(fp->out, W.slab_bytes), qs_off(A.G, W.o0), W.vs, (unsigned)W.nlon};
+        const bool bad = qs_ocn_wave<QS_FAST>(A, W, wv, fp, out);
+        if (__builtin_amdgcn_ballot_w64(bad) == 0ull) return;
+    }
+    QsOutGlobal out{qs_make_rsrc(fp->out, W.slab_bytes), qs_off(A.G, W.o0), W.vs, (unsigned)W.nlon};
+    qs_ocn_wave<QS_EXACT>(A, W, wv, fp, out);
+}
+
+// the ring-fed currents wave: qt_currents_fast with uo', vo', eta' out of LDS
+__device__ __forceinline__ double qfu_currents(const QdTailArgs& P, const QtW& W, const QfuRing& R) {
+    const unsigned sb = W.slab, m = (unsigned)W.m;
+    const qt_rsrc E = qt_make_rsrc(P.eta, sb), L = qt_make_rsrc(P.land, sb / 8u);
+    const qt_rsrc UO = qt_make_rsrc(P.uo_out, sb), VO = qt_make_rsrc(P.vo_out, sb), KT = qt_make_rsrc(P.tab, (unsigned)W.n * 128u);
+    unsigned ro = (unsigned)(W.o0 - W.lbase) * m;
+    double acc = 0.0;
+    QtCurK K;
+    K.dlon2 = qt_vreg(2 * P.dlon); K.r_2dlon = qt_vreg(P.r_2dlon); K.dlat2 = qt_vreg(2 * P.dlat); K.r_2dlat = qt_vreg(P.r_2dlat);
+    K.msdtH = qt_vreg(P.msdtH); K.cap = qt_vreg(P.cap); K.cap81 = qt_vreg(0.81 * (P.cap * P.cap)); K.mean4 = P.mean4;
+    QtCurSlot a, b;
+    a.u = a.v = a.e = b.u = b.v = b.e = 0.0;
+    a.l = qt_ld8(L, ro, W.vo8); a.k0 = qt_ldk(KT, 16u * (unsigned)W.o0, 4u); a.k1 = qt_ldk(KT, 16u * (unsigned)W.o0, 5u);
+    b.l = qt_ld8(L, ro + m, W.vo8); b.k0 = qt_ldk(KT, 16u * (unsigned)(W.o0 + 1), 4u); b.k1 = qt_ldk(KT, 16u * (unsigned)(W.o0 + 1), 5u);
+    qfu_wait_gt(R.prog + 0, W.o0); qfu_wait_gt(R.prog + 1, W.o0);
+    double us = qfu_ring_ld(R.u, W.o0 - 1, W.lane), vs = qfu_ring_ld(R.v, W.o0 - 1, W.lane);
+    double uc = qfu_ring_ld(R.u, W.o0, W.lane), vc = qfu_ring_ld(R.v, W.o0, W.lane);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    int g = W.o0;
+    for (; g + 1 < W.o1; g += 2) {
+        qt_cur_fast_step<true>(K, W, E, E, E, L, UO, VO, KT, us, uc, vs, vc, acc, a, g, ro, &R);
+        qt_cur_fast_step<true>(K, W, E, E, E, L, UO, VO, KT, us, uc, vs, vc, acc, b, g + 1, ro + m, &R);
+        ro += 2u * m;
+    }
+    if (g < W.o1) qt_cur_fast_step<true>(K, W, E, E, E, L, UO, VO, KT, us, uc, vs, vc, acc, a, g, ro, &R);
+    if (W.lane == 0) __hip_atomic_store(R.prog + 3, 0x3fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // done: never in a producer's way
+    return acc;
+}
+
+// the ring-fed SST wave: qt_sst_fast with uo', vo' out of LDS; true: a lane needed the general gather
+template <bool EDGE>
+__device__ __forceinline__ bool qfu_sst(const QdTailArgs& P, const QtW& W, const QfuRing& R) {
+    const unsigned sb = W.slab, m = (unsigned)W.m;
+    const qt_rsrc S = qt_make_rsrc(P.Ts, sb), Q = qt_make_rsrc(P.qnet, sb);
+    const qt_rsrc L = qt_make_rsrc(P.land, sb / 8u), I = qt_make_rsrc(P.ice, sb / 8u), SO = qt_make_rsrc(P.Ts_out, sb);
+    const qt_rsrc KT = qt_make_rsrc(P.tab, (unsigned)W.n * 128u);
+    QtSstK K;
+    K.a = qt_vreg(P.a); K.r_a = qt_vreg(P.r_a); K.dt = qt_vreg(P.sub_dt); K.dlon = qt_vreg(P.dlon); K.r_dlon = qt_vreg(P.r_dlon);
+    K.dlat = qt_vreg(P.dlat); K.r_dlat = qt_vreg(P.r_dlat); K.alpha = qt_vreg(P.alpha); K.om_alpha = qt_vreg(1.0 - P.alpha);
+    K.dtK = qt_vreg(P.sub_dt * P.K_h); K.rcH = qt_vreg(P.rcH); K.r_rcH = qt_vreg(P.r_rcH); K.dtq = qt_vreg(P.sub_dt * P.ice_qfac);
+    K.has_ice = P.has_ice; K.qfac_on = P.ice_qfac > 0.0 ? 1 : 0;
+    const int t0 = W.o0 - 2;
+    unsigned ro = (unsigned)(t0 - W.lbase) * m;
+    double Tm = qt_ld(S, ro - m, W.vo), T0 = qt_ld(S, ro, W.vo);
+    QtSstSlot a, b;
+    a.u = a.v = b.u = b.v = 0.0;
+    a.s = qt_ld(S, ro + m, W.vo);
+    a.k0 = qt_ldk(KT, 16u * (unsigned)t0, 0u); a.k1 = qt_ldk(KT, 16u * (unsigned)t0, 1u); a.k2 = qt_ldk(KT, 16u * (unsigned)t0, 2u);
+    b.s = qt_ld(S, ro + 2u * m, W.vo);
+    b.k0 = qt_ldk(KT, 16u * (unsigned)(t0 + 1), 0u); b.k1 = qt_ldk(KT, 16u * (unsigned)(t0 + 1), 1u); b.k2 = qt_ldk(KT, 16u * (unsigned)(t0 + 1), 2u);
+    a.q = b.q = 0.0; a.l = b.l = 0; a.ic = b.ic = 0;
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    double Wm = 0.0, W0 = 0.0, Em = 0.0, E0 = 0.0;
+    if (!EDGE) { Wm = qd_west(Tm); W0 = qd_west(T0); Em = qd_east(Tm); E0 = qd_east(T0); }
+    double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0, w4 = 0.0;
+    bool bad = false;
+#define QFU_FS(OUTF, SL, GG, RO) qt_sst_fast_step<EDGE, OUTF, true>(K, W, S, S, S, Q, L, I, SO, KT, Tm, T0, Wm, W0, Em, E0, w0, w1, w2, w3, w4, bad, SL, GG, RO, &R)
+    int g = t0;
+    QFU_FS(false, a, g, ro); QFU_FS(false, b, g + 1, ro + m); QFU_FS(false, a, g + 2, ro + 2u * m); QFU_FS(false, b, g + 3, ro + 3u * m);
+    g += 4; ro += 4u * m;
+    const int gend = W.o1 + 2;
+    for (; g + 1 < gend; g += 2) { QFU_FS(true, a, g, ro); QFU_FS(true, b, g + 1, ro + m); ro += 2u * m; }
+    if (g < gend) QFU_FS(true, a, g, ro);
+#undef QFU_FS
+    if (W.lane == 0) __hip_atomic_store(R.prog + 4, 0x3fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return __builtin_amdgcn_ballot_w64(bad) != 0ull;
+}
+
+__global__ void __launch_bounds__(320)
+k_ocn_fused(QsOcnArgs A, QdTabs T, QdTailArgs P, QfuArgs F) {
+    __shared__ double s_ring[3][QFU_NR][64];
+    __shared__ int s_prog[8];
+    const QdGeom& G = A.G;
+    const int n = G.nlat;
+    const unsigned w = qd_xcd_chunk(blockIdx.x, gridDim.x);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const QsOcnArgs QD_CONST* Ak = (const QsOcnArgs QD_CONST*)__builtin_amdgcn_kernarg_segment_ptr();
+    const QsRec QD_CONST* fp = &Ak->rec[wv < 3 ? wv : 0];
+    double acc = 0.0;
+    if ((int)w < F.ntc) {
+        // ---- the two polar tiles of column strip w, sequential form
+        const int cs = (int)w;
+        if (wv < 3) { qfu_k1_global(A, cs, 0, QFU_PH + 2, wv, fp); qfu_k1_global(A, cs, n - QFU_PH - 2, n, wv, fp); }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        QtW W;
+        if (wv == 3) { qfu_tailw(G, P, cs, 0, QFU_PH, W); acc = qt_currents_wave(T, P, W); qfu_tailw(G, P, cs, n - QFU_PH, n, W); acc += qt_currents_wave(T, P, W); }
+        if (wv == 4) { qfu_tailw(G, P, cs, 0, QFU_PH, W); qt_sst_wave(G, T, P, W); qfu_tailw(G, P, cs, n - QFU_PH, n, W); qt_sst_wave(G, T, P, W); }
+    } else {
+        const unsigned k = w - (unsigned)F.ntc;
+        const int rs = (int)(k / (unsigned)F.ntc), cs = (int)(k % (unsigned)F.ntc);
+        const int M = n - 2 * QFU_PH;
+        const int o0 = QFU_PH + (int)(((long long)rs * M) / F.nmid), o1 = QFU_PH + (int)(((long long)(rs + 1) * M) / F.nmid);
+        bool redo = (F.mode & 1) != 0;
+        if (!redo) {
+            // ---- streaming form
+            if (threadIdx.x < 8) s_prog[threadIdx.x] = threadIdx.x < 3 ? o0 - 2 : (threadIdx.x == 3 ? o0 - 1 : (threadIdx.x == 4 ? o0 - 2 : 0));
+            __syncthreads();
+            QfuRing R{&s_ring[0][0][0], &s_ring[1][0][0], &s_ring[2][0][0], s_prog};
+            bool bad = false;
+            if (wv < 3) {
+                __builtin_amdgcn_s_setprio(2);
+                QsW W;
+                qfu_k1w(G, cs, o0 - 2, o1 + 2, W);
+                QsOutRing out{&s_ring[wv][0][0], s_prog + wv, s_prog + 3, s_prog + 4, o0 - 2, o0 - 2, lane};
+                bad = qs_ocn_wave<QS_FAST>(A, W, wv, fp, out);
+                __builtin_amdgcn_s_setprio(0);
+            } else {
+                QtW W;
+                qfu_tailw(G, P, cs, o0, o1, W);
+                if (wv == 3) acc = qfu_currents(P, W, R);
+                else {
+                    const bool edge_lane = W.lane >= 1 && W.lane <= 62 && (W.j == 0 || W.j == W.m - 1);
+                    bad = __builtin_amdgcn_ballot_w64(edge_lane) != 0ull ? qfu_sst<true>(P, W, R) : qfu_sst<false>(P, W, R);
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) __hip_atomic_store(s_prog + 5, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __syncthreads();
+            redo = __hip_atomic_load(s_prog + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
+        }
+        if (redo) {
+            // ---- sequential form of this strip (test mode, or the fast waves raised `bad`): everything it stores overwrites the above
+            if (wv < 3) qfu_k1_global(A, cs, o0 - 2, o1 + 2, wv, fp);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            QtW W;
+            qfu_tailw(G, P, cs, o0, o1, W);
+            if (wv == 3) acc = qt_currents_wave(T, P, W);
+            if (wv == 4) qt_sst_wave(G, T, P, W);
+        }
+    }
+    if (wv != 3) return;
+    acc = qt_wave_sum(acc);
+    if (lane == 0) __hip_atomic_store(P.partial + w, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (P.acc) {
+        const bool last = lane == 0 && qd_acc_arrive(P.acc, w, gridDim.x, acc);
+        if (__builtin_amdgcn_ballot_w64(last) != 0ull) {
+            const double mm = qd_acc_finish(P.acc, P.partial, (int)gridDim.x, P.wsum);
+            if (lane == 0) *P.mean_out = mm;
+        }
+    }
+}
+
+static bool qfu_shape(const qd_ctx* c, QfuArgs& F) {
+    const QdGeom& G = c->geo;
+    if (!G.full || G.nlon < 64 || G.nlat < 2 * QFU_PH + 24) return false;
+    F.ntc = (G.nlon + QFU_TC - 1) / QFU_TC;
+    const int M = G.nlat - 2 * QFU_PH;
+    // strip height: QD_FUSED_R, else about three workgroups of five waves per CU resident at once (256 CUs: see qt_fast_rows for why
+    // the device is not asked)
+    int R = c->tune.fused_r;
+    if (R <= 0) { const int nrs = std::max(1, (768 - F.ntc) / F.ntc); R = (M + nrs - 1) / nrs; }
+    R = std::max(R, 12);
+    F.nmid = std::max(1, M / R);
+    F.R = (M + F.nmid - 1) / F.nmid;
+    F.mode = c->tune.fused_seq ? 1 : 0;
+    return true;
+}
+bool qd_ocn_fused_ok(const qd_ctx* c) { QfuArgs F; return qfu_shape(c, F); }
+int qd_ocn_fused_tiles(const qd_ctx* c) { QfuArgs F; return qfu_shape(c, F) ? F.ntc * (1 + F.nmid) : 0; }
+
+// O: the momentum kernel's arguments with uo_out / vo_out / eta_out = the scratch slabs of the sequential form; P: the tail's
+// arguments with uo / vo = those slabs, eta = the eta_out slab (in: eta' of the sequential form, out: the new eta)
+int qd_launch_ocn_fused(qd_ctx* c, const QdOcnArgs& O, QdTailArgs& P) {
+    QfuArgs F;
+    if (!qfu_shape(c, F)) return qd_fail(c, "k_ocn_fused: whole-globe handles of >= 64 columns and >= 38 rows only");
+    QsOcnArgs A;
+    if (!qd_stream_ocn_args(c, O, A)) return qd_fail(c, "k_ocn_fused: coefficient row tables");
+    A.G = c->geo;
+    if (F.ntc * (1 + F.nmid) > c->red_blocks) return qd_fail(c, "k_ocn_fused: partial buffer too small");
+    if (!c->qt_tab || c->qt_tab_a != P.a) {
+        if (!c->qt_tab) {
+            if (hipMalloc(&c->qt_tab, (size_t)c->geo.nlat * 16 * sizeof(double)) != hipSuccess) return qd_fail(c, "k_ocn_fused: row table");
+            c->tab_alloc.push_back(c->qt_tab);
+        }
+        hipLaunchKernelGGL(k_tail_tab, dim3((c->geo.nlat + 255) / 256), dim3(256), 0, c->stream, c->tabs, c->geo.nlat, P.a, c->qt_tab);
+        c->qt_tab_a = P.a;
+    }
+    P.tab = c->qt_tab; P.own0 = 0; P.own1 = c->geo.nlat; P.flags = 0; P.R = F.R; P.Rp = QFU_PH; P.ntc = F.ntc; P.nmid = F.nmid;
+    QdScope sc(c, "ocean_step", true);
+    QD_LAUNCH_TIMED(sc, k_ocn_fused, dim3(F.ntc * (1 + F.nmid)), dim3(320), c->stream, A, c->tabs, P, F);
+    return 0;
 }
 
 // Strip height of the round-3 streaming form (k_ocn_tail_stream, QD_TAIL_V=1).  Measured (rocprofv3 kernel trace, 721 x 1440), with the

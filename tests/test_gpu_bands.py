@@ -114,7 +114,10 @@ def test_fused_kernel_paths_agree(gpu, shape, monkeypatch):
 # forms of the one-launch ocean tail: "fast" = k_ocn_tail_fast (the shipped form), "stream" = k_ocn_tail_stream (QD_TAIL_V=1: the
 # general waves on every strip, the reference form of the slim ones); the LDS-tile forms and the one-launch sub-step of round 3
 # are retired (tools/retired/)
-TAIL_FORMS = ("fast", "stream")
+# "fused" = k_ocn_fused (QD_OCN_FUSED=1): the WHOLE sub-step in one launch, the momentum waves handing their rows to the tail waves
+# through LDS rings; "fused_seq": the same launch with every strip on its sequential form (what the polar tiles and a strip with a
+# non-finite value or a far departure point take)
+TAIL_FORMS = ("fast", "stream", "fused", "fused_seq")
 
 
 def _set_tail(monkeypatch, tail):
@@ -123,6 +126,8 @@ def _set_tail(monkeypatch, tail):
         monkeypatch.setenv("QD_TAIL_V", "1")
     else:
         monkeypatch.delenv("QD_TAIL_V", raising=False)
+    monkeypatch.setenv("QD_OCN_FUSED", "1" if tail.startswith("fused") else "0")
+    monkeypatch.setenv("QD_FUSED_SEQ", "1" if tail == "fused_seq" else "0")
 # bound on the agreement with the two-launch form: the forms differ in the ORDER of the area-weighted eta sum only (per row / per
 # strip / per tile, f64 tree or fixed-point slots); over 2-3 coupled steps that rounding difference grows to ~2e-12 on the currents
 TAIL_TOL = 1e-11

@@ -80,8 +80,11 @@ __global__ void __launch_bounds__(320) k_strip2(P p, const double* tab) {
     const unsigned vo = j * 8u, vs = ok ? jraw * 8u : 0x80000000u;
     const int o0 = rs * p.R, o1 = rs == p.nrs - 1 ? p.nlat : o0 + p.R;
     const int g0 = o0 - 4 > 0 ? o0 - 4 : 0, g1 = o1 + 4 < p.nlat ? o1 + 4 : p.nlat;
-    unsigned ro_ = g0 * p.nlon * 8u, so = o0 * p.nlon * 8u;
-    const unsigned stride = p.nlon * 8u;
+    // mode & 16: "head to head" -- odd row strips stream their rows in DESCENDING order, so that both neighbours of every strip
+    // boundary touch the shared halo rows at the same time (both at their start, or both at their end): the second reader finds them in L2
+    const bool desc = (p.mode & 16) && (rs & 1);
+    unsigned ro_ = (desc ? g1 - 1 : g0) * p.nlon * 8u, so = (desc ? o1 - 1 : o0) * p.nlon * 8u;
+    const unsigned stride = desc ? 0u - p.nlon * 8u : p.nlon * 8u;
     double q[PD], e[PD], e2[PD];
     auto ld = [&](int k) {
         q[k] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(ri, vo, ro_, 0));
@@ -93,7 +96,8 @@ __global__ void __launch_bounds__(320) k_strip2(P p, const double* tab) {
     for (int k = 0; k < PD; ++k) ld(k);
     typedef const double __attribute__((address_space(4)))* cptr;
     double acc = 0.0;
-    for (int g = g0; g < g1; ++g) {
+    for (int t = 0; t < g1 - g0; ++t) {
+        const int g = desc ? g1 - 1 - t : g0 + t;
         double c = q[0] + (e[0] + e2[0]) * 1e-300;
 #pragma unroll
         for (int k = 0; k + 1 < PD; ++k) { q[k] = q[k + 1]; e[k] = e[k + 1]; e2[k] = e2[k + 1]; }
@@ -201,6 +205,15 @@ int main(int argc, char** argv) {
         RUN(2, 0, 0, 0, 0) RUN(2, 1, 0, 0, 0) RUN(2, 2, 0, 0, 0) RUN(2, 2, 4, 0, 0) RUN(2, 2, 0, 30, 0) RUN(2, 2, 4, 30, 0) RUN(2, 2, 4, 60, 0)
         RUN(2, 2, 4, 30, 32768) RUN(2, 2, 4, 30, 40000) RUN(3, 2, 4, 30, 0)
     }
+    for (int R : {16, 24, 32}) for (int mode : {0, 16}) {
+        p.own = 58; p.lead = 3; p.R = R; p.ntc = (nlon + 57) / 58; p.nrs = nlat / R; p.mode = mode;
+        char nm[96];
+        snprintf(nm, 96, "HEAD-TO-HEAD mode=%d R=%d PD=2 extra=2 sload=4 valu=30", mode, R);
+        time(nm, [&] { hipLaunchKernelGGL((k_strip2<2, 2, 4, 30, 0>), dim3(p.ntc * p.nrs), dim3(320), 0, 0, p, tab); });
+        snprintf(nm, 96, "HEAD-TO-HEAD mode=%d R=%d PD=3 extra=2 sload=4 valu=30", mode, R);
+        time(nm, [&] { hipLaunchKernelGGL((k_strip2<3, 2, 4, 30, 0>), dim3(p.ntc * p.nrs), dim3(320), 0, 0, p, tab); });
+    }
+    p.mode = 0;
     for (int R : {8, 12, 16, 24}) {
         p.R = R; p.ntc = 12; p.nrs = nlat / R;
         char nm[96];
