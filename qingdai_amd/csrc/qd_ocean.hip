@@ -794,7 +794,8 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
     // QD_OCN_FUSED=1: the WHOLE sub-step is one launch (k_ocn_fused, qd_ocntail.hip): the momentum + del^4 waves hand their rows to the
     // tail waves of the same strip through LDS rings; uo', vo', eta' never reach memory
     const bool use_fused1 = use_tail && !band && c->ocn_fused && c->ocn_tail == 1 && tail_acc && c->fused_fast == 1 && do_diff &&
-                            p.ocean_k4_nsub == 1 && !do_shap && HP.use_q && HP.K_h > 0.0 && qd_ocn_fused_ok(c);
+                            p.ocean_k4_nsub == 1 && !do_shap && HP.use_q && HP.K_h > 0.0 && qd_ocn_fused_ok(c) &&
+                            !c->k4_ocn_skip[0] && !c->k4_ocn_skip[1] && !c->k4_ocn_skip[2];
     for (int s = 0; s < n_sub; ++s) {
         if (use_fused1) {
             QdOcnArgs O;

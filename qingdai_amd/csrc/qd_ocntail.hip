@@ -815,11 +815,18 @@ k_ocn_fused(QsOcnArgs A, QdTabs T, QdTailArgs P, QfuArgs F) {
     const QdGeom& G = A.G;
     const int n = G.nlat;
     const unsigned w = qd_xcd_chunk(blockIdx.x, gridDim.x);
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // Which wave plays which role rotates with the workgroup's layer on its CU (workgroups b, b + 256, b + 512 share a CU: dispatch is
+    // round-robin over 8 XCDs x 32 CUs; waves w and w + 4 of a workgroup share a SIMD): with fixed roles the SST waves of a CU, the
+    // heaviest, sit on one SIMD (measured: 64.8 -> 61.5 us per launch at R = 26).  QD_FUSED_NOROT=1: fixed roles.
+    const int hwv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lyr = (int)((blockIdx.x >> 8) % 3u);
+    const int rot = (F.mode & 2) ? 0 : (lyr == 0 ? 0 : (lyr == 1 ? 2 : 3));
+    const int wv = (hwv + 5 - rot) % 5;                       // the ROLE of this wave: 0, 1, 2 = uo / vo / eta, 3 = currents, 4 = SST
     const int lane = threadIdx.x & 63;
     const QsOcnArgs QD_CONST* Ak = (const QsOcnArgs QD_CONST*)__builtin_amdgcn_kernarg_segment_ptr();
     const QsRec QD_CONST* fp = &Ak->rec[wv < 3 ? wv : 0];
     double acc = 0.0;
+    QT_STAMP(0);
     if ((int)w < F.ntc) {
         // ---- the two polar tiles of column strip w, sequential form
         const int cs = (int)w;
@@ -858,6 +865,7 @@ k_ocn_fused(QsOcnArgs A, QdTabs T, QdTailArgs P, QfuArgs F) {
                     bad = __builtin_amdgcn_ballot_w64(edge_lane) != 0ull ? qfu_sst<true>(P, W, R) : qfu_sst<false>(P, W, R);
                 }
             }
+            QT_STAMP(2);
             if (__builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) __hip_atomic_store(s_prog + 5, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __syncthreads();
             redo = __hip_atomic_load(s_prog + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
@@ -898,7 +906,7 @@ static bool qfu_shape(const qd_ctx* c, QfuArgs& F) {
     R = std::max(R, 12);
     F.nmid = std::max(1, M / R);
     F.R = (M + F.nmid - 1) / F.nmid;
-    F.mode = c->tune.fused_seq ? 1 : 0;
+    F.mode = (c->tune.fused_seq ? 1 : 0) | (c->tune.fused_norot ? 2 : 0);
     return true;
 }
 bool qd_ocn_fused_ok(const qd_ctx* c) { QfuArgs F; return qfu_shape(c, F); }
@@ -923,7 +931,21 @@ int qd_launch_ocn_fused(qd_ctx* c, const QdOcnArgs& O, QdTailArgs& P) {
     }
     P.tab = c->qt_tab; P.own0 = 0; P.own1 = c->geo.nlat; P.flags = 0; P.R = F.R; P.Rp = QFU_PH; P.ntc = F.ntc; P.nmid = F.nmid;
     QdScope sc(c, "ocean_step", true);
+#ifdef QT_STAMPS
+    static unsigned long long* stamps = nullptr;
+    const size_t stamp_words = (size_t)8 * 5 * 8192;
+    if (!stamps) { hipMalloc(&stamps, stamp_words * 8); hipMemcpyToSymbol(HIP_SYMBOL(qt_stamp_buf), &stamps, sizeof(stamps)); }
+    hipMemsetAsync(stamps, 0, stamp_words * 8, c->stream);
+#endif
     QD_LAUNCH_TIMED(sc, k_ocn_fused, dim3(F.ntc * (1 + F.nmid)), dim3(320), c->stream, A, c->tabs, P, F);
+#ifdef QT_STAMPS
+    if (const char* f = std::getenv("QD_STAMPS_FILE")) {     // developer build (-DQT_STAMPS) only
+        std::vector<unsigned long long> h(stamp_words);
+        hipStreamSynchronize(c->stream);
+        hipMemcpy(h.data(), stamps, stamp_words * 8, hipMemcpyDeviceToHost);
+        if (FILE* fp = std::fopen(f, "wb")) { std::fwrite(h.data(), 8, stamp_words, fp); std::fclose(fp); }
+    }
+#endif
     return 0;
 }
 
