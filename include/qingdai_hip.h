@@ -289,6 +289,7 @@ int qd_plansim_mark(qd_handle h, const int* fields, int n, int margin);
 int qd_plansim_margin(qd_handle h, int field);
 int qd_plansim_segments(qd_handle h, int margin, int* row0_nrows_pairs);                    /* -> number of segments (<= 3) */
 int qd_plansim_pop_exchange(qd_handle h, int* fields_out, int max_fields, int* geom4);      /* geom4 = {H, owned rows, up, dn} */
+int qd_plansim_segments_rows(qd_handle h, int vr0, int cnt, int* row0_nrows_pairs);          /* ring rows [vr0, vr0 + cnt) -> segments (<= 6) */
 int qd_comm_barrier(qd_handle h);
 /* Device-side exchange over the peer mapping (round 4; QD_PEER_EXCHANGE=1): halo rows and global sums are STORED into the
  * neighbours' memory by small kernels on the handle's own stream and polled there -- no collective launch, no host.  Every rank

@@ -36,7 +36,7 @@ SYMBOLS = [
     "qd_comm_unique_id", "qd_comm_init", "qd_comm_init_local", "qd_comm_stats", "qd_comm_allreduce_count", "qd_comm_grouped_sum_count", "qd_comm_init_shm", "qd_comm_host_allreduce_count", "qd_hostring_open", "qd_hostring_allreduce",
     "qd_hostring_close", "qd_comm_barrier", "qd_comm_allreduce_max", "qd_peer_export", "qd_peer_connect", "qd_comm_peer_stats", "qd_tune_reload",
     "qd_plansim_create", "qd_plansim_destroy", "qd_plansim_plan", "qd_plansim_mark", "qd_plansim_margin", "qd_plansim_segments",
-    "qd_plansim_pop_exchange",
+    "qd_plansim_pop_exchange", "qd_plansim_segments_rows",
     "qd_eco_configure", "qd_eco_set_lai_layers", "qd_eco_substep", "qd_eco_banded_alpha", "qd_eco_get_state", "qd_eco_set_state",
     "qd_indiv_configure", "qd_indiv_substep", "qd_indiv_download", "qd_indiv_upload",
     "qd_phyto_configure", "qd_phyto_upload", "qd_phyto_download", "qd_phyto_advect_diffuse",
@@ -148,6 +148,7 @@ def load():
     lib.qd_plansim_margin.argtypes = [vp, i32]
     lib.qd_plansim_segments.argtypes = [vp, i32, ip]
     lib.qd_plansim_pop_exchange.argtypes = [vp, ip, i32, ip]
+    lib.qd_plansim_segments_rows.argtypes = [vp, i32, i32, ip]
     lib.qd_timing_enable.argtypes = [vp, i32]
     lib.qd_timing_select.argtypes = [vp, ctypes.c_char_p]
     lib.qd_timing_get.argtypes = [vp, ctypes.c_char_p, dp, ctypes.POINTER(i64)]

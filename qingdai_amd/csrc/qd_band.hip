@@ -544,6 +544,14 @@ extern "C" int qd_plansim_segments(qd_handle c, int margin, int* out) {
     for (int k = 0; k < S.n; ++k) { out[2 * k] = S.g[k].row0; out[2 * k + 1] = S.g[k].nrows; }
     return S.n;
 }
+// launch segments of an arbitrary run of ring rows [vr0, vr0 + cnt) (vr0 may be negative or beyond n_lat: the ring wraps): what the
+// interior / boundary launches around an overlapped halo exchange use (qd_segments_rows); returns the number of segments (<= 6)
+extern "C" int qd_plansim_segments_rows(qd_handle c, int vr0, int cnt, int* out) {
+    if (!c || !c->plansim || !out) return -1;
+    const QdSegList S = qd_segments_rows(c, vr0, cnt);
+    for (int k = 0; k < S.n; ++k) { out[2 * k] = S.g[k].row0; out[2 * k + 1] = S.g[k].nrows; }
+    return S.n;
+}
 // oldest logged exchange: fields_out[0..n) and geom = {halo rows H, owned rows, rank that receives my top rows (up), rank that
 // receives my bottom rows (dn)}.  Slab layout: local rows [0,H) south halo <- dn's top rows [nown, nown+H) (local numbering);
 // [H, H+nown) owned; [H+nown, 2H+nown) north halo <- up's bottom rows [H, 2H).  Returns n, 0 when the log is empty.

@@ -366,3 +366,50 @@ def test_bench_spawns_its_own_ranks_without_a_launcher():
     out2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--spawn-check"], env=env2, capture_output=True,
                           text=True, timeout=120)
     assert out2.returncode == 0 and json.loads(out2.stdout.strip())["RANK"] == "1"
+
+
+def test_interior_and_boundary_segments_partition_a_launch():
+    """Exchange overlapped with interior compute (qd_plan_begin / qd_plan_end, qd_ocean.hip): a consumer launch of margin m around an
+    exchange is split into its INTERIOR rows [own0 - m_int, own1 + m_int) -- what the old margins allow, launched while the halos
+    travel -- and two BOUNDARY strips.  Whatever the band (polar bands wrap around the ring), the three pieces must cover exactly the
+    rows of the unsplit launch, each once, and no piece may leave the slab."""
+    import ctypes
+    from qingdai_amd import _lib
+    from qingdai_amd.bands import band_ranges
+    lib = _lib.load()
+    I = ctypes.c_int32
+    nlat, nlon, H = 181, 96, 16
+    for world in (2, 3, 8):
+        for rank, (r0, n) in enumerate(band_ranges(nlat, world)):
+            desc = _lib.qd_grid_desc(nlat, nlon, r0, n, H, 0, rank, world)
+            h = ctypes.c_void_p()
+            assert lib.qd_plansim_create(ctypes.byref(desc), ctypes.byref(h)) == 0
+
+            def rows_of(vr0, cnt):
+                seg = (I * 12)()
+                ns = lib.qd_plansim_segments_rows(h, vr0, cnt, seg)
+                assert 0 <= ns <= 6
+                out = []
+                for k in range(ns):
+                    g0, ln = seg[2 * k], seg[2 * k + 1]
+                    assert 0 <= g0 and g0 + ln <= nlat and ln > 0
+                    out += list(range(g0, g0 + ln))
+                return out
+            for m in (0, 3, 9, H - 5):
+                seg = (I * 6)()
+                ns = lib.qd_plansim_segments(h, m, seg)
+                whole = sorted(sum((list(range(seg[2 * k], seg[2 * k] + seg[2 * k + 1])) for k in range(ns)), []))
+                assert whole == sorted((r0 - m + k) % nlat for k in range(n + 2 * m))
+                for m_int in (-12, -1, 0, 2, m):
+                    if m_int > m or n + 2 * m_int < 1:
+                        continue
+                    interior = rows_of(r0 - m_int, n + 2 * m_int)
+                    south = rows_of(r0 - m, m - m_int)
+                    north = rows_of(r0 + n + m_int, m - m_int)
+                    pieces = interior + south + north
+                    assert len(pieces) == len(set(pieces)) == len(whole), (world, rank, m, m_int)
+                    assert sorted(pieces) == whole
+                    # every row is on this band's slab (owned rows + H halo rows either side, ring-periodic)
+                    slab = set((r0 - H + k) % nlat for k in range(n + 2 * H))
+                    assert set(pieces) <= slab
+            assert lib.qd_plansim_destroy(h) == 0
