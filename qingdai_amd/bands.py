@@ -261,6 +261,15 @@ def init_peer(dev: Device, rank, world, tag="peer", timeout_s=180.0):
     _write_atomic(f"{base}.map.{rank}", b"\1" if good else b"\0")
     good = all(r == b"\1" for r in gather("map", 1))
     if good:
+        # third round: does the transport move the RIGHT bytes on this machine?  (ring exchanges of self-describing rows and
+        # all-reduces with known results, both buffer parities: stale data over a mapping nobody has run this on would show here)
+        wrong = ctypes.c_longlong(-1)
+        ok = lib.qd_peer_selftest(dev.h, int(os.environ.get("QD_PEER_SELFTEST", "6")), ctypes.byref(wrong)) == 0 and wrong.value == 0
+        _write_atomic(f"{base}.test.{rank}", b"\1" if ok else b"\0")
+        good = all(r == b"\1" for r in gather("test", 1))
+        if not good:
+            lib.qd_peer_disable(dev.h)
+    if good:
         dev._chk(lib.qd_comm_barrier(dev.h), "qd_comm_barrier")
     _write_atomic(f"{base}.done.{rank}", b"\1")
     if rank == 0:

@@ -422,6 +422,65 @@ extern "C" int qd_peer_connect(qd_handle c, const void* handles, size_t bytes_ea
     return qp_publish_table(c);
 }
 
+// ---- self-test of a freshly connected transport (qingdai_amd.bands.init_peer runs it before anybody relies on the mailboxes)
+// A memory-model surprise on a mapping this code has never run over (xGMI between real GPUs) would show up as STALE data, not as an
+// error: so every rank exchanges rows whose values encode (sender, iteration, position) and checks what arrived, and all-reduces
+// rank-dependent numbers whose sums it knows, `iters` times (both buffer parities, back to back).  Returns the number of wrong values
+// seen by THIS rank (0 = clean), -1 on a launch / deadline failure.
+__global__ void k_peer_test_fill(double* slab, int H, int nown, int nlon, int rank, int it) {
+    const size_t n = (size_t)H * nlon;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        slab[(size_t)nown * nlon + i] = 1.0e6 * (rank + 1) + 1.0e3 * it + (double)(i % 997) + 0.25;        // my top rows -> up's south halo
+        slab[(size_t)H * nlon + i] = -1.0e6 * (rank + 1) - 1.0e3 * it - (double)(i % 991) - 0.5;           // my bottom rows -> dn's north halo
+    }
+}
+__global__ void k_peer_test_check(const double* slab, int H, int nown, int nlon, int up, int dn, int it, unsigned long long* bad) {
+    const size_t n = (size_t)H * nlon;
+    unsigned long long b = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        b += slab[i] != 1.0e6 * (dn + 1) + 1.0e3 * it + (double)(i % 997) + 0.25;                            // south halo <- dn's top rows
+        b += slab[(size_t)(H + nown) * nlon + i] != -1.0e6 * (up + 1) - 1.0e3 * it - (double)(i % 991) - 0.5; // north halo <- up's bottom rows
+    }
+    if (b) atomicAdd(bad, b);
+}
+extern "C" int qd_peer_selftest(qd_handle c, int iters, long long* wrong) {
+    if (!c || !wrong || !qd_peer_on(c) || iters < 1) return -1;
+    QdPeer* P = c->peer;
+    hipSetDevice(c->desc.device);
+    const int H = c->geo.halo, nown = c->own_nrows, nlon = c->geo.nlon;
+    double*& slab = c->scratch[QD_NSCRATCH - 3];              // a scratch slab nobody holds between calls
+    unsigned long long* bad = c->dcount + 24;
+    QD_HIP(c, hipMemsetAsync(bad, 0, sizeof(unsigned long long), c->stream));
+    long long wrong_sums = 0;
+    for (int it = 0; it < iters; ++it) {
+        hipLaunchKernelGGL(k_peer_test_fill, dim3(64), dim3(256), 0, c->stream, slab, H, nown, nlon, P->rank, it);
+        QdUse u{(void**)&slab, 0, 0};
+        if (qd_peer_halo(c, &u, 1)) return -1;
+        hipLaunchKernelGGL(k_peer_test_check, dim3(64), dim3(256), 0, c->stream, slab, H, nown, nlon, P->up, P->dn, it, bad);
+        // sums every rank can predict: sum_r (r + 1) * (it + 1), max_r (r * 7 - it), and a vector long enough for several workgroups
+        double h[4] = {(double)(P->rank + 1) * (it + 1), 0.0, 0.0, 0.0};
+        double* d = c->dscal + QD_S_TMP0;
+        QD_HIP(c, hipMemcpyAsync(d, h, sizeof(double), hipMemcpyHostToDevice, c->stream));
+        if (qd_peer_allreduce(c, d, 1, 0)) return -1;
+        QD_HIP(c, hipMemcpyAsync(h + 1, d, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        h[2] = (double)(P->rank * 7 - it);
+        QD_HIP(c, hipMemcpyAsync(d + 1, h + 2, sizeof(double), hipMemcpyHostToDevice, c->stream));
+        if (qd_peer_allreduce(c, d + 1, 1, 1)) return -1;
+        QD_HIP(c, hipMemcpyAsync(h + 3, d + 1, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        QD_HIP(c, hipStreamSynchronize(c->stream));
+        if (qp_check(c)) return -1;
+        const double want_sum = 0.5 * P->world * (P->world + 1) * (it + 1), want_max = (double)((P->world - 1) * 7 - it);
+        wrong_sums += (h[1] != want_sum) + (h[3] != want_max);
+    }
+    unsigned long long hb = 0;
+    QD_HIP(c, hipMemcpy(&hb, bad, sizeof(hb), hipMemcpyDeviceToHost));
+    *wrong = (long long)hb + wrong_sums;
+    c->vm[slab] = 0;                                          // its halo rows hold test patterns
+    return 0;
+}
+// back to the other transports (the self-test failed somewhere: every rank leaves the mailboxes together)
+extern "C" int qd_peer_disable(qd_handle c) { if (!c) return -1; if (c->peer) c->peer->on = 0; return 0; }
+
 extern "C" int qd_comm_peer_stats(qd_handle c, int* halo_exchanges, int* reductions) {
     if (!c || !halo_exchanges || !reductions) return -1;
     *halo_exchanges = c->peer ? (int)c->peer->n_halo : 0;

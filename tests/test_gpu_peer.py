@@ -78,7 +78,9 @@ def test_peer_self_ring_equals_in_process_transport(gpu, overlap, monkeypatch):
             arr = (ctypes.c_void_p * 1)(dev.h)
             assert dev.lib.qd_comm_init_local(arr, 1) == 0
         else:
-            assert init_peer(dev, 0, 1, tag="selfpeer")
+            assert init_peer(dev, 0, 1, tag="selfpeer")          # includes qd_peer_selftest (self-describing rows, known sums)
+            wrong = ctypes.c_longlong(-1)
+            assert dev.lib.qd_peer_selftest(dev.h, 9, ctypes.byref(wrong)) == 0 and wrong.value == 0
         for k, v in {**static, **st}.items():
             dev.upload_now(k, v)
         dev.step_n(stars, 300.0, with_ocean=True, with_physics=True, pass_albedo=True)
