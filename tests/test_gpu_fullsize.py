@@ -106,6 +106,25 @@ def test_eight_bands_match_the_whole_globe(gpu, transport, monkeypatch):
         assert relerr(got[k], ref[k]) < 1e-13, k                       # band-wise order of the eta sum
 
 
+def test_two_rank_processes_at_the_benchmark_size(gpu):
+    """`bench.py --gpus 2`'s decomposition as two rank PROCESSES on device 0 (IPC-mapped mailboxes, preferred halo, exchange overlapped
+    with the interior rows: scripts/peer_ranks.py) against the whole globe at 721 x 1440, coupled: atmosphere bit for bit, ocean to the
+    band-wise order of the eta sums."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "peer_ranks.py"), "--world", "2", "--nlat", str(NLAT), "--nlon", str(NLON),
+                        "--steps", "2", "--ocean", "--preferred-halo", "--tol", "1e-12"], env=dict(os.environ, QD_PEER_EXCHANGE="1"),
+                       capture_output=True, text=True, timeout=900)
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and line, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    res = json.loads(line[-1])
+    print({k: res[k] for k in ("ok", "atmosphere_bitwise", "max_rel_err")}, [m["halo_exchanges"] for m in res["ranks"]])
+    assert res["ok"] and res["atmosphere_bitwise"] and all(m["transport"] == "peer" for m in res["ranks"])
+
+
 def test_ecology_substep_full_size(gpu, monkeypatch):
     """BASELINE configs[4] at 721 x 1440: 20 species planes, 16 bands, ~6 k sampled cells x 150 individuals inside the resident
     loop.  Properties: E_day is the step-by-step sum of isr dt (same star row every step: exact repeated addition); the alpha map
