@@ -218,10 +218,13 @@ def test_nonfinite_values_fall_back_to_the_exact_path(gpu, monkeypatch):
         assert not bad.any(), (k, np.argwhere(bad)[:5], fast[k][bad][:5], unfused[k][bad][:5])
 
 
-def test_bands_ecology_substep(gpu, monkeypatch):
+@pytest.mark.parametrize("transport", ["host", "peer"])
+def test_bands_ecology_substep(gpu, transport, monkeypatch):
     """The ecology sub-step (qd_step_n bit5) on 3 latitude bands against the whole-globe handle: the LAI-change ratio is a
     band-wise sum (all-reduced), the alpha blend and E_day are pointwise, each sampled individual is advanced by the band
     that owns its cell (no exchange); the per-band energy arrays add up to the whole-globe one."""
+    if transport == "peer":                                  # the lai-delta sums and the halo rows through the mailboxes (qd_peer.hip)
+        monkeypatch.setenv("QD_PEER_EXCHANGE", "1")
     import os
     from qingdai_amd.bands import BandGroup
     from qingdai_amd.device import Device

@@ -99,9 +99,12 @@ def _coupled(world, nlat, nlon, nsteps, S):
     return C, uo, C0
 
 
-def test_transport_inside_the_resident_loop_and_on_bands(gpu):
+@pytest.mark.parametrize("transport", ["host", "peer"])
+def test_transport_inside_the_resident_loop_and_on_bands(gpu, transport, monkeypatch):
     """flags bit6 of qd_step_n: the tracers move with the currents of THIS step's ocean update.  Whole globe against 3 latitude
     bands (halo exchanges of the tracer slabs planned like every other stencil input): bit-identical tracers."""
+    if transport == "peer":                                  # the tracer slabs' halos through the mailboxes (qd_peer.hip)
+        monkeypatch.setenv("QD_PEER_EXCHANGE", "1")
     one, uo1, C0 = _coupled(1, 61, 96, 4, 3)
     assert relerr(one, C0) > 1e-3                      # something moved
     three, uo3, _ = _coupled(3, 61, 96, 4, 3)
