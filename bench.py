@@ -59,11 +59,13 @@ def build_case(nlat, nlon, with_ocean, device=0, band=None, rank=0, world=1):
     return grid, m, oc, forcing, mask, base_albedo, friction
 
 
-def cpu_baseline(nlat, nlon, with_ocean, with_phys=True, budget_s=20.0):
+def cpu_baseline(nlat, nlon, with_ocean, with_phys=True, budget_s=20.0, state=None, t0_s=0.0):
     """The oracle (NumPy restatement, proven equal to the reference in the authoring container, speed ratio to the real reference
     in BASELINE.md) timed on this box's host cores on the SAME loop as the GPU leg -- driver physics (precipitation / cloud /
     albedo diagnostics) -> forcing -> time_step(Teq, dt, albedo) -> ocean coupling: 1 warm-up step, then as many steps as fit in
-    ~budget_s (at least 2)."""
+    ~budget_s (at least 2).  `state`: the prognostic fields the GPU leg ended on (downloaded after its timed region): the oracle
+    continues from THEM, so its ocean runs the same number of sub-steps per step as the GPU leg's did (a cold start runs fewer:
+    the round-3 baseline was a lower bound for that reason)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import qd_oracle as qo
     from qd_oracle.driver import DriverOracle
@@ -76,17 +78,25 @@ def cpu_baseline(nlat, nlon, with_ocean, with_phys=True, budget_s=20.0):
     oc = qo.OceanOracle(g, mask, P, init_Ts=np.full((nlat, nlon), 288.0)) if with_ocean else None
     f = qo.Forcing(g)
     dt = 300.0
+    spun_up = False
+    if state is not None:
+        for k_dev, k_or in (("U", "u"), ("V", "v"), ("H", "h"), ("TS", "T_s"), ("Q", "q"), ("CLOUD", "cloud_cover"), ("HICE", "h_ice")):
+            if k_dev in state:
+                setattr(m, k_or, np.array(state[k_dev], dtype=float))
+        if oc is not None and all(k in state for k in ("UO", "VO", "ETA", "SST")):
+            oc.uo, oc.vo, oc.eta, oc.Ts = (np.array(state[k], dtype=float) for k in ("UO", "VO", "ETA", "SST"))
+        spun_up = True
     if with_phys:
         d = DriverOracle(g, m, oc, f, mask, alb, P)
 
         def one(i):
-            d.step(i * dt, dt, pass_albedo=True, commit=False)
+            d.step(t0_s + i * dt, dt, pass_albedo=True, commit=False)
     else:
         from qd_oracle import column as col
         albedo = np.where(mask == 0, 0.08, alb)
 
         def one(i):
-            t = i * dt
+            t = t0_s + i * dt
             a_, b_ = f.insolation_components(t)
             m.isr_A, m.isr_B, m.isr = a_, b_, a_ + b_
             Teq = f.equilibrium_temp(t, albedo)
@@ -112,9 +122,9 @@ def cpu_baseline(nlat, nlon, with_ocean, with_phys=True, budget_s=20.0):
     per = el / n
     return {"value": dt / per / PLANET_DAY_S, "unit": "planet-days/s", "cores": 1, "kind": "port",
             "sample": f"{n} steps of the same {nlat}x{nlon} loop as the GPU leg (driver physics {'on' if with_phys else 'off'}, "
-                      f"ocean {'on' if with_ocean else 'off'}) from a cold start after 1 warm-up ({per * 1e3:.1f} ms/step; the cold ocean "
-                      f"runs {oc.last_n_sub if oc is not None else 0} sub-steps per step against the spun-up GPU leg's ocean_n_sub, so the "
-                      f"ratio is a lower bound); NumPy is single-threaded, {os.cpu_count()} host cores available"}
+                      f"ocean {'on' if with_ocean else 'off'}) " + ("continuing from the state the GPU leg ended on" if spun_up else "from a cold start") +
+                      f" after 1 warm-up ({per * 1e3:.1f} ms/step, {oc.last_n_sub if oc is not None else 0} ocean sub-steps per step); "
+                      f"NumPy is single-threaded, {os.cpu_count()} host cores available"}
 
 
 def ecology_leg(dev, grid, mask, forcing, dt, W, K):
@@ -375,6 +385,15 @@ def main():
             comm["collective_launches_per_step"] = 0.0
         else:
             comm["collective_launches_per_step"] = comm["halo_exchanges_per_step"] + comm["rccl_allreduces_per_step"] - ng.value / max(1, K + W)
+    end_state = None
+    if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
+        # what the CPU baseline continues from (downloaded AFTER the timed region; the ecology leg below runs on)
+        names = ["U", "V", "H", "TS", "Q", "CLOUD", "HICE"] + (["UO", "VO", "ETA", "SST"] if with_ocean else [])
+        end_state = {}
+        for k in names:
+            dev._host.pop(k, None)
+            end_state[k] = np.array(dev.get(k), dtype=float)
+            dev._host.pop(k, None)
     kern_ms, kern_n = dev.timing_get(args.profile_kernel)
     also_ms, also_n = dev.timing_get(also) if also else (0.0, 0)
     dev.timing(on=False)
@@ -449,7 +468,7 @@ def main():
         except Exception as e:       # noqa: BLE001  (never lose the main line to the supplementary leg)
             out["ecology_config5"] = {"error": str(e)}
     if not args.no_cpu_baseline and rank == 0 and args.gpus == 1:
-        out["cpu_baseline"] = cpu_baseline(args.nlat, args.nlon, with_ocean, with_phys, args.cpu_budget)
+        out["cpu_baseline"] = cpu_baseline(args.nlat, args.nlon, with_ocean, with_phys, args.cpu_budget, state=end_state, t0_s=(W + K) * dt)
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(out))

@@ -9,6 +9,8 @@ attribute read downloads, an attribute write uploads before the next device step
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from .device import Device
@@ -106,6 +108,11 @@ class SpectralModel:
         """dynamics.py:260-667.  `Teq_field` / `albedo` may be arrays (uploaded) or None to use
         the fields already resident on the device (Device.forcing / simple_albedo)."""
         dev = self._dev
+        # The reference re-reads its QD_* variables inside every step (dynamics.py:330-348 and the parameter dataclasses); here
+        # they are parsed once (QdParams) because re-parsing ~100 variables costs more than the GPU step.  QD_ENV_REREAD=1 restores
+        # the reference's behaviour for callers that change the environment between steps.
+        if os.environ.get("QD_ENV_REREAD") == "1":
+            self.reload_env()
         if Teq_field is not None:
             dev.set("TEQ", Teq_field)
         if albedo is not None and albedo is not True:

@@ -612,3 +612,38 @@ def test_driver_loop_configs0_181x360_24_steps(gpu):
         print(upto, "steps:", errs, "ocean sub-steps:", oc.last_n_sub)
         for k, e in errs.items():
             assert e < ocean_tol.get(k, STEP_TOL), (upto, k, e)
+
+
+def test_env_reread_per_step_like_the_reference(gpu, monkeypatch):
+    """The reference reads its QD_* variables inside every step (dynamics.py:330-348: QD_CLOUD_COUPLE, QD_RH0, QD_K_Q, QD_K_P, ...);
+    this implementation parses them once unless QD_ENV_REREAD=1.  With the switch on, a variable changed between two steps must act on
+    the second one exactly as an explicit reload_env() does -- and without the switch it must not."""
+    meta, d = load_golden("ts_19x36_default_alb")
+
+    def run(mode):
+        import qingdai_amd as qa
+        monkeypatch.setenv("QD_ENERGY_W", "1")                # everything that configures the run comes from the environment here
+        monkeypatch.setenv("QD_ENV_REREAD", "1" if mode == "reread" else "0")
+        nlat, nlon = meta["nlat"], meta["nlon"]
+        _, mask, alb, fric = surface(nlat, nlon)
+        grid = qa.SphericalGrid(nlat, nlon)
+        Cs_ocean = 1000.0 * 4200.0 * 50.0
+        m = qa.SpectralModel(grid, fric, H=8000, tau_rad=10 * 24 * 3600, greenhouse_factor=0.40,
+                             C_s_map=np.where(mask == 1, 3e6, Cs_ocean).astype(float), land_mask=mask,
+                             Cs_ocean=Cs_ocean, Cs_land=3e6, Cs_ice=5e6)
+        for k in STATE:
+            setattr(m, k, d["init_" + k].copy())
+        forcing = qa.ThermalForcing(grid, qa.OrbitalSystem())
+        m._dev.set("ALBEDO", np.where(mask == 0, 0.08, alb))
+        for i in range(2):
+            if i == 1:
+                monkeypatch.setenv("QD_ENERGY_W", "0.5")     # the weight of the energy-budget surface temperature: read inside time_step by the reference
+                if mode == "explicit":
+                    m.reload_env()
+            forcing.update_device(i * meta["dt"], with_teq=True)
+            m.time_step(None, meta["dt"], albedo=True)
+        return {k: np.array(getattr(m, k)) for k in STATE}
+    base, explicit, reread = run("off"), run("explicit"), run("reread")
+    for k in STATE:
+        assert np.array_equal(reread[k], explicit[k]), k
+    assert any(not np.array_equal(base[k], explicit[k]) for k in STATE)      # the variable does matter
