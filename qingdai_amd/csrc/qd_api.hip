@@ -607,7 +607,7 @@ extern "C" int qd_step_n(qd_handle c, int n, double dt, int flags, const double*
         // its clock / canopy / alpha part runs before the albedo kernel, its E_day += isr dt rides on this step's forcing launch
         if (with_eco && c->eco.p.albedo_couple) { if ((rc = qd_eco_canopy_impl(c, dt))) return rc; c->eco.eday_dt = c->eco.p.use_lai ? dt : 0.0; }
         // whole-globe handles: the forcing rides on the last launch of the driver physics (k_snow_albedo_forcing)
-        const bool merged = with_phys && c->geo.full && c->merge_pointwise;
+        const bool merged = with_phys && c->merge_pointwise;
         const QdForcingCall fc{st, st + 3, st[6]};
         if (with_phys) {
             const int part = c->precip_done ? 2 : 0;         // the precipitation block may have run inside the previous ocean step

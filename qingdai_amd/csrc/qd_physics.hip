@@ -456,9 +456,11 @@ int qd_driver_physics_impl(qd_ctx* c, double dt, const QdForcingCall* fc, int pa
         if (m < 0) return -1;
         int ms = qd_plan(c, {QD_IN(F[QD_F_U], 1), QD_IN(F[QD_F_V], 1), QD_IN(F[QD_F_TS], 1)});
         if (ms < 0) return -1;
-        if (G0.full && c->merge_pointwise) {
-            hipLaunchKernelGGL(k_cloud_fromp_source, qd_grid2d(G0), blk, 0, c->stream, G0, c->tabs, F[QD_F_PRECIP], c->dscal + QD_S_MED_OUT,
-                               p.cmax, F[QD_F_U], F[QD_F_V], F[QD_F_TS], p.a, c->dlat, c->dlon, cfp, src);
+        if (c->merge_pointwise) {
+            // one launch for both fields (bands: on the rows both can be computed on -- the blur below needs both on the same rows anyway)
+            m = ms = std::min(m, ms);
+            QD_ROWS(c, m, G, hipLaunchKernelGGL(k_cloud_fromp_source, qd_grid2d(G), blk, 0, c->stream, G, c->tabs, F[QD_F_PRECIP],
+                                                c->dscal + QD_S_MED_OUT, p.cmax, F[QD_F_U], F[QD_F_V], F[QD_F_TS], p.a, c->dlat, c->dlon, cfp, src));
         } else {
         QD_ROWS(c, m, G, hipLaunchKernelGGL(k_cloud_from_p, qd_grid2d(G), blk, 0, c->stream, G, F[QD_F_PRECIP],
                                             c->dscal + QD_S_MED_OUT, p.cmax, cfp));
@@ -528,19 +530,22 @@ int qd_driver_physics_impl(qd_ctx* c, double dt, const QdForcingCall* fc, int pa
             S.swe_max = (p.swe_max_mm == p.swe_max_mm && p.swe_max_mm > 0) ? p.swe_max_mm : -1.0;
             S.swe_ref_safe = std::max(1e-6, p.swe_ref_mm); S.gl_frac = p.glacier_frac; S.gl_swe = p.glacier_swe_mm; S.swe = p.swe_enable;
             // the forcing of this step rides on the same launch when the caller (qd_step_n, whole-globe handle) hands it over
-            if (fc && G0.full) {
+            if (fc) {
                 const QdForcingP Fo{QdStar{fc->sa[0], std::sin(fc->sa[1]), std::cos(fc->sa[1]), fc->sa[2]},
                                     QdStar{fc->sb[0], std::sin(fc->sb[1]), std::cos(fc->sb[1]), fc->sb[2]}, fc->theta, 5.670374e-8, 1};
-                hipLaunchKernelGGL(k_snow_albedo_forcing, qd_grid2d(G0), blk, 0, c->stream, G0, c->tabs, S, A, Fo, F[QD_F_PRECIP], F[QD_F_H],
+                // (bands: on the rows every input is valid on -- the margin the three separate launches end up with as well, since
+                //  the albedo needs the snow cover and the forcing the albedo)
+                const int mm = std::min(m, msn);
+                QD_ROWS(c, mm, G, hipLaunchKernelGGL(k_snow_albedo_forcing, qd_grid2d(G), blk, 0, c->stream, G, c->tabs, S, A, Fo, F[QD_F_PRECIP], F[QD_F_H],
                                    F[QD_F_S_SNOW], F[QD_F_ELEVATION], c->land, F[QD_F_P_RAIN], F[QD_F_S_SNOW_NEXT], F[QD_F_MELT],
                                    F[QD_F_C_SNOW], F[QD_F_GLACIER], adv, F[QD_F_CLOUD],
                                    c->cloud_eff_valid ? F[QD_F_CLOUD_EFF] : (const double*)nullptr, F[QD_F_HICE], F[QD_F_BASE_ALBEDO],
                                    F[QD_F_ECO_ALPHA], F[QD_F_ECO_ALPHA_BANDED], F[QD_F_WATER_ALPHA], F[QD_F_ALBEDO], F[QD_F_ISR_A],
                                    F[QD_F_ISR_B], F[QD_F_ISR], F[QD_F_TEQ], c->eco.eday_dt > 0 ? F[QD_F_ECO_EDAY] : (double*)nullptr,
-                                   c->eco.eday_dt);
+                                   c->eco.eday_dt));
                 c->eco.eday_dt = 0;
-                qd_mark(c, {F[QD_F_P_RAIN], F[QD_F_S_SNOW_NEXT], F[QD_F_MELT], F[QD_F_C_SNOW], F[QD_F_GLACIER]}, 0);
-                qd_mark(c, {F[QD_F_CLOUD], F[QD_F_ALBEDO], F[QD_F_ISR_A], F[QD_F_ISR_B], F[QD_F_ISR], F[QD_F_TEQ]}, 0);
+                qd_mark(c, {F[QD_F_P_RAIN], F[QD_F_S_SNOW_NEXT], F[QD_F_MELT], F[QD_F_C_SNOW], F[QD_F_GLACIER]}, mm);
+                qd_mark(c, {F[QD_F_CLOUD], F[QD_F_ALBEDO], F[QD_F_ISR_A], F[QD_F_ISR_B], F[QD_F_ISR], F[QD_F_TEQ]}, mm);
                 return 0;
             }
             QD_ROWS(c, msn, G, hipLaunchKernelGGL(k_snow_provisional, qd_grid2d(G), blk, 0, c->stream, G, c->tabs, S, F[QD_F_PRECIP],
