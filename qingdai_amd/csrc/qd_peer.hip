@@ -23,11 +23,13 @@
 // buffer s % 2 with exchange s + 2 before it has been consumed.  (Every exchange is the symmetric ring exchange, every reduction
 // involves all ranks, and all ranks issue the same sequence of them: they run the same program on the same global scalars.)
 //
-// Memory model: data stores, release (qd_peer_dev.h: qp_release), workgroup barrier, ONE system-scope atomic on the consumer's flag
-// or counter; the consumer polls with system-scope atomic loads, then acquires (qp_acquire) before it reads.  The mailbox is
-// allocated fine-grained (hipDeviceMallocFinegrained: stores write through, loads do not linger in L2), which is what lets release
-// be a wait for the store acknowledgements instead of an L2 write-back.  Every poll loop has a deadline (QP_TIMEOUT_S of s_memrealtime): a
-// rank that never arrives turns into an error word in pinned host memory and a failed qd_* call, never into a hung GPU.
+// Memory model: EVERY access to a mailbox is a system-scope atomic (relaxed) load or store of 8 bytes -- such accesses go to the point of
+// coherence whatever memory type the mapping has (the mailbox is allocated fine-grained, but the mapping hipIpcOpenMemHandle hands to
+// another process behaves like ordinary L2-cached memory: found the hard way, see qp_copy_t).  Producer: data stores, a wait for their
+// acknowledgement (qd_peer_dev.h: qp_release -- not a fence: a release fence writes back the whole L2), workgroup barrier, ONE store
+// or add on the consumer's flag / counter; consumer: polls the flag, then loads.  Every poll loop has a deadline (QP_TIMEOUT_S of
+// s_memrealtime): a rank that never arrives turns into an error word in pinned host memory and a failed qd_* call, never into a hung
+// GPU.  A freshly connected transport is self-tested before anybody relies on it (qd_peer_selftest).
 //
 // In-process groups (N band handles on one device, one host thread each: the test vehicle) run the same kernels in two launches
 // per operation -- deposit, pthread barrier, collect: with all deposits queued before any collect, no kernel ever polls for work
