@@ -204,3 +204,15 @@ def test_coupled_loop_with_tracers_vs_oracle(gpu):
     e = relerr(got, want)
     print(e, relerr(dev.get("UO"), oo.uo))
     assert relerr(want, C0) > 1e-4 and e < 1e-9
+
+
+def test_more_slabs_than_a_mailbox_exchange_holds(gpu, monkeypatch):
+    """20 tracer species on 2 latitude bands over the peer exchange: the tracer stack's halo exchange moves more slabs (20 + the
+    currents) than one push / unpack pair stages (16: QP_MAXSLABS), so qd_peer_halo has to go round twice -- each round its own
+    sequence number and buffer parity.  Bit-identical tracers against the whole globe."""
+    monkeypatch.setenv("QD_PEER_EXCHANGE", "1")
+    one, uo1, C0 = _coupled(1, 61, 96, 3, 20)
+    two, uo2, _ = _coupled(2, 61, 96, 3, 20)
+    assert relerr(one, C0) > 1e-3
+    assert relerr(uo2, uo1) < 1e-12
+    assert relerr(two, one) < 1e-12
