@@ -361,7 +361,7 @@ int  qd_gaussian(qd_ctx* c, const double* in, double* out, double* tmp, double s
                  const double* scale_p = nullptr, double scale_k = 1.0);
 bool qd_gauss_pair_ok(const qd_ctx* c, double sigma);
 int  qd_gaussian_pair(qd_ctx* c, const double* inA, const double* inB, double sigma, int mode_wrap, const double* scA_p, double scA_k,
-                      double scB_k, const double* sc, int op, const double* blend5, double* outA, double* outB, double* out0);
+                      double scB_k, const double* sc, int op, const double* blend5, double* outA, double* outB, double* out0, int m_out = 0);
 int  qd_gaussian_swap(qd_ctx* c, double*& field, double*& tmp, double sigma, int mode_wrap, int m_out, int clip01 = 0,
                       const double* scale_p = nullptr, double scale_k = 1.0);
 bool qd_gauss_can_fuse(const qd_ctx* c, double sigma);

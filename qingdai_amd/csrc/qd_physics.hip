@@ -416,10 +416,12 @@ int qd_driver_physics_impl(qd_ctx* c, double dt, const QdForcingCall* fc, int pa
         }
         // P = gaussian(P_raw * s); P_dyn = gaussian(k_precip * pos): the two scalings ride on the blur's loads
         if (qd_gauss_pair_ok(c, 1.0)) {
-            // whole globe: both blurs and the blend in one launch (the convergence field is not even read while the fallback is off)
+            // both blurs and the blend in one launch (the convergence field is not even read while the fallback is off)
+            const int mg = qd_plan(c, {QD_IN(praw, R1), QD_IN(pos, R1)});
+            if (mg < 0) return -1;
             if (qd_gaussian_pair(c, praw, pos, 1.0, 0, c->dscal + QD_S_RENORM, 1.0, p.k_precip, c->dscal + QD_S_RENORM, 1, nullptr,
-                                 nullptr, nullptr, F[QD_F_PRECIP])) return -1;
-            qd_mark(c, {F[QD_F_PRECIP]}, 0);
+                                 nullptr, nullptr, F[QD_F_PRECIP], mg)) return -1;
+            qd_mark(c, {F[QD_F_PRECIP]}, mg);
         } else if (qd_gauss_can_fuse(c, 1.0)) {
             const int mg = qd_plan(c, {QD_IN(praw, R1), QD_IN(pos, R1)});
             if (mg < 0) return -1;
@@ -476,13 +478,13 @@ int qd_driver_physics_impl(qd_ctx* c, double dt, const QdForcingCall* fc, int pa
         wm /= wsum; wp /= wsum; ws /= wsum;
         QdBlendP B{wm, wp, ws, dt / (6 * 3600), p.cloud_from_p_floor};
         if (qd_gauss_pair_ok(c, 1.0)) {
-            // whole globe: blur + clip of both fields and the blend in one launch; the blurred fields land in two scratch slabs that
-            // then trade places with the inputs (like qd_gaussian_swap)
+            // blur + clip of both fields and the blend in one launch; the blurred fields land in two scratch slabs that then trade
+            // places with the inputs (like qd_gaussian_swap)
             double*& oa = c->scratch[6]; double*& ob = c->scratch[7];
             const double b5[5] = {B.w_mem, B.w_p, B.w_src, B.tend, B.c_floor};
-            if (qd_gaussian_pair(c, cfp, src, 1.0, 0, nullptr, 1.0, 1.0, nullptr, 2, b5, oa, ob, F[QD_F_CLOUD])) return -1;
+            if (qd_gaussian_pair(c, cfp, src, 1.0, 0, nullptr, 1.0, 1.0, nullptr, 2, b5, oa, ob, F[QD_F_CLOUD], mg)) return -1;
             std::swap(cfp, oa); std::swap(src, ob);
-            qd_mark(c, {cfp, src, F[QD_F_CLOUD]}, 0);
+            qd_mark(c, {cfp, src, F[QD_F_CLOUD]}, mg);
         } else {
         if (qd_gaussian_swap(c, cfp, tmp, 1.0, 0, mg, 1)) return -1;      // np.clip(gaussian(...), 0, 1)
         if (qd_gaussian_swap(c, src, tmp, 1.0, 0, mg, 1)) return -1;

@@ -565,23 +565,23 @@ k_gauss_pair(QdGeom G, const double* __restrict__ inA, const double* __restrict_
     }
 }
 
-// whole-globe handles only (the caller checks qd_gauss_pair_ok): returns nonzero on failure
+// the caller checks qd_gauss_pair_ok and (band handles) plans both inputs with the blur's radius; m_out: margin of the outputs
 bool qd_gauss_pair_ok(const qd_ctx* c, double sigma) {
     const int r = qd_gauss_radius(sigma);
-    return c->geo.full && c->use_fused && c->merge_pointwise && sigma > 1e-15 && c->geo.nlon > 2 * r && (r == 1 || r == 2 || r == 4);
+    return c->use_fused && c->merge_pointwise && sigma > 1e-15 && c->geo.nlon > 2 * r && (r == 1 || r == 2 || r == 4);
 }
 int qd_gaussian_pair(qd_ctx* c, const double* inA, const double* inB, double sigma, int mode_wrap, const double* scA_p, double scA_k,
-                     double scB_k, const double* sc, int op, const double* blend5, double* outA, double* outB, double* out0) {
+                     double scB_k, const double* sc, int op, const double* blend5, double* outA, double* outB, double* out0, int m_out) {
     QdGaussW W;
     if (!qd_gauss_weights(sigma, W)) return qd_fail(c, "gaussian radius too large");
     QdGaussPairP P{op, 0, 0, 0, 0, 0};
     if (blend5) { P.w_mem = blend5[0]; P.w_p = blend5[1]; P.w_src = blend5[2]; P.tend = blend5[3]; P.c_floor = blend5[4]; }
-    const QdGeom& G = c->geo;
     const int r = W.r;
-    const dim3 grid((G.nlon + (QD_BLOCK - 2 * r) - 1) / (QD_BLOCK - 2 * r), (G.nrows + QD_GB - 1) / QD_GB);
-    if (r == 1) hipLaunchKernelGGL(k_gauss_pair<1>, grid, dim3(QD_BLOCK), 0, c->stream, G, inA, inB, W, mode_wrap, scA_p, scA_k, scB_k, sc, P, outA, outB, out0);
-    else if (r == 2) hipLaunchKernelGGL(k_gauss_pair<2>, grid, dim3(QD_BLOCK), 0, c->stream, G, inA, inB, W, mode_wrap, scA_p, scA_k, scB_k, sc, P, outA, outB, out0);
-    else hipLaunchKernelGGL(k_gauss_pair<4>, grid, dim3(QD_BLOCK), 0, c->stream, G, inA, inB, W, mode_wrap, scA_p, scA_k, scB_k, sc, P, outA, outB, out0);
+    QD_ROWS(c, m_out, G,
+        const dim3 grid((G.nlon + (QD_BLOCK - 2 * r) - 1) / (QD_BLOCK - 2 * r), (G.nrows + QD_GB - 1) / QD_GB);
+        if (r == 1) hipLaunchKernelGGL(k_gauss_pair<1>, grid, dim3(QD_BLOCK), 0, c->stream, G, inA, inB, W, mode_wrap, scA_p, scA_k, scB_k, sc, P, outA, outB, out0);
+        else if (r == 2) hipLaunchKernelGGL(k_gauss_pair<2>, grid, dim3(QD_BLOCK), 0, c->stream, G, inA, inB, W, mode_wrap, scA_p, scA_k, scB_k, sc, P, outA, outB, out0);
+        else hipLaunchKernelGGL(k_gauss_pair<4>, grid, dim3(QD_BLOCK), 0, c->stream, G, inA, inB, W, mode_wrap, scA_p, scA_k, scB_k, sc, P, outA, outB, out0));
     return 0;
 }
 
