@@ -297,6 +297,11 @@ def main():
         spawn_ranks(args.gpus)                                # never returns
     if args.spawn_check:
         print(json.dumps({k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}), flush=True)
+        # (test hooks of tests/test_bands_cpu.py: one rank dies, another would block for ever -- the spawner has to end both)
+        if os.environ.get("QD_BENCH_TEST_FAIL_RANK") == str(rank):
+            raise SystemExit(3)
+        if os.environ.get("QD_BENCH_TEST_HANG_RANK") == str(rank):
+            time.sleep(300)
         return
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run / torchrun "

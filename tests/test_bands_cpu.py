@@ -413,3 +413,55 @@ def test_interior_and_boundary_segments_partition_a_launch():
                     slab = set((r0 - H + k) % nlat for k in range(n + 2 * H))
                     assert set(pieces) <= slab
             assert lib.qd_plansim_destroy(h) == 0
+
+
+def test_spawner_ends_the_other_ranks_when_one_dies():
+    """bench.py --gpus N without a launcher: when a rank process fails, the ranks that would now block in the rendezvous or in a
+    collective for ever are terminated, and the spawner exits with the failing rank's code -- promptly."""
+    import subprocess
+    import time
+    root = ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(QD_BENCH_TEST_FAIL_RANK="1", QD_BENCH_TEST_HANG_RANK="2")
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--spawn-check"], env=env, capture_output=True,
+                         text=True, timeout=120)
+    assert out.returncode == 3, (out.returncode, out.stderr[-500:])
+    assert time.time() - t0 < 60.0                           # not the hanging rank's 300 s
+
+
+def test_device_code_stamp_reads_the_fatbin_section():
+    """qingdai_amd/_codehash.py: the profile stamp is the hash of the .hip_fatbin section (device code only) of the built library /
+    objects; a hand-made ELF shows the section walk picks the right bytes and that bytes OUTSIDE the section do not matter."""
+    import hashlib
+    import struct
+    from qingdai_amd import _codehash as ch
+
+    def elf(payload, junk):
+        names = b"\0.shstrtab\0.hip_fatbin\0"
+        hdr = 64
+        off_junk, off_pay = hdr, hdr + len(junk)
+        off_str = off_pay + len(payload)
+        shoff = (off_str + len(names) + 7) & ~7
+        e = bytearray(b"\x7fELF" + bytes([2, 1, 1]) + bytes(9))
+        e += struct.pack("<HHIQQQIHHHHHH", 3, 62, 1, 0, 0, shoff, 0, 64, 0, 0, 64, 3, 1)
+        body = bytes(e) + junk + payload + names
+        body += bytes(shoff - len(body))
+        sh0 = bytes(64)
+        sh1 = struct.pack("<IIQQQQIIQQ", 1, 3, 0, 0, off_str, len(names), 0, 0, 1, 0)            # .shstrtab
+        sh2 = struct.pack("<IIQQQQIIQQ", 11, 1, 2, 0, off_pay, len(payload), 0, 0, 4096, 0)      # .hip_fatbin
+        return body + sh0 + sh1 + sh2
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        a, b = os.path.join(d, "a.o"), os.path.join(d, "b.o")
+        open(a, "wb").write(elf(b"DEVICE-CODE" * 50, b"host text 1"))
+        open(b, "wb").write(elf(b"DEVICE-CODE" * 50, b"host text 2, edited"))
+        assert ch.elf_section(a, ".hip_fatbin") == b"DEVICE-CODE" * 50
+        assert ch.fatbin_sha(a) == ch.fatbin_sha(b) == hashlib.sha256(b"DEVICE-CODE" * 50).hexdigest()[:16]
+        open(b, "wb").write(elf(b"DEVICE-CODE" * 49 + b"DEVICE-C0DE", b"host text 1"))
+        assert ch.fatbin_sha(a) != ch.fatbin_sha(b)
+    lib = os.path.join(ROOT, "qingdai_amd", "libqingdai_hip.so")
+    if os.path.exists(lib):
+        st = ch.device_code_stamp()
+        assert "libqingdai_hip.so" in st and not ch.stale_against(st)
+        assert ch.stale_against({k: "0" * 16 for k in st})
