@@ -386,7 +386,9 @@ def main():
             nph, npr = _ct.c_int(0), _ct.c_int(0)
             dev.lib.qd_comm_peer_stats(dev.h, _ct.byref(nph), _ct.byref(npr))
             comm["reductions_per_step"] = comm.pop("rccl_allreduces_per_step")
-            comm["peer_ops_whole_run"] = {"halo_exchanges": nph.value, "reductions": npr.value}
+            comm["peer_ops_whole_run"] = {"halo_exchanges": nph.value, "reductions": npr.value,
+                                          # pushes that were the first workgroups of the interior momentum launch (QD_PEER_OVERLAP=2)
+                                          "pushes_carried_by_a_compute_launch": dev.lib.qd_comm_peer_carried(dev.h)}
             comm["collective_launches_per_step"] = 0.0
         else:
             comm["collective_launches_per_step"] = comm["halo_exchanges_per_step"] + comm["rccl_allreduces_per_step"] - ng.value / max(1, K + W)

@@ -299,6 +299,7 @@ int qd_comm_barrier(qd_handle h);
 int qd_peer_export(qd_handle h, void* handle64, size_t bytes);
 int qd_peer_connect(qd_handle h, const void* handles, size_t bytes_each, int world);
 int qd_comm_peer_stats(qd_handle h, int* halo_exchanges, int* reductions);   /* operations that went through the mailboxes */
+int qd_comm_peer_carried(qd_handle h);   /* of those halo exchanges: pushes that went out INSIDE a compute launch (QD_PEER_OVERLAP=2); < 0: bad handle */
 /* self-test of a freshly connected transport: `iters` ring exchanges of rows whose values encode (sender, iteration, position) and
  * all-reduces of rank-dependent numbers with known results; *wrong = values this rank found wrong (stale data would show here, not as
  * an error).  qd_peer_disable: leave the mailboxes (all ranks together, when any rank's self-test failed) -- the host then calls

@@ -34,7 +34,7 @@ SYMBOLS = [
     "qd_op_laplacian", "qd_op_hyperdiffuse", "qd_op_advect", "qd_op_shapiro", "qd_op_zonal_filter", "qd_op_divergence",
     "qd_op_vorticity", "qd_op_gaussian", "qd_op_median_positive", "qd_median_state", "qd_reduce", "qd_energy_diagnostics", "qd_energy_diagnostics_last", "qd_band_insolation",
     "qd_comm_unique_id", "qd_comm_init", "qd_comm_init_local", "qd_comm_stats", "qd_comm_allreduce_count", "qd_comm_grouped_sum_count", "qd_comm_init_shm", "qd_comm_host_allreduce_count", "qd_hostring_open", "qd_hostring_allreduce",
-    "qd_hostring_close", "qd_comm_barrier", "qd_comm_allreduce_max", "qd_peer_export", "qd_peer_connect", "qd_comm_peer_stats", "qd_peer_selftest", "qd_peer_disable", "qd_tune_reload",
+    "qd_hostring_close", "qd_comm_barrier", "qd_comm_allreduce_max", "qd_peer_export", "qd_peer_connect", "qd_comm_peer_stats", "qd_comm_peer_carried", "qd_peer_selftest", "qd_peer_disable", "qd_tune_reload",
     "qd_plansim_create", "qd_plansim_destroy", "qd_plansim_plan", "qd_plansim_mark", "qd_plansim_margin", "qd_plansim_segments",
     "qd_plansim_pop_exchange", "qd_plansim_segments_rows",
     "qd_eco_configure", "qd_eco_set_lai_layers", "qd_eco_substep", "qd_eco_banded_alpha", "qd_eco_get_state", "qd_eco_set_state",
@@ -142,6 +142,7 @@ def load():
     lib.qd_peer_selftest.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_longlong)]
     lib.qd_peer_disable.argtypes = [vp]
     lib.qd_comm_peer_stats.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    lib.qd_comm_peer_carried.argtypes = [vp]
     ip = ctypes.POINTER(i32)
     lib.qd_plansim_create.argtypes = [ctypes.POINTER(qd_grid_desc), ctypes.POINTER(vp)]
     lib.qd_plansim_destroy.argtypes = [vp]

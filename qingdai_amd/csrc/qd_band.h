@@ -34,10 +34,14 @@ int  qd_peer_halo(qd_ctx* c, const QdUse* slots, int n);                 // the 
 int  qd_peer_allreduce(qd_ctx* c, void* dptr, int n, int kind);          // kind 0: f64 sum in rank order, 1: f64 max, 2: u32 sum
 int  qd_peer_allreduce_publish(qd_ctx* c, double* dptr, int n, int op_max, double* hdst, double hseq);   // ... and straight on to pinned host memory
 int  qd_peer_allgather(qd_ctx* c, double* buf, int n_per_rank);          // buf[world][n_per_rank], own segment filled in
-int  qd_peer_halo_begin(qd_ctx* c, const QdUse* slots, int n);           // push only (n <= qd_peer_max_slabs()) ...
+int  qd_peer_halo_begin(qd_ctx* c, const QdUse* slots, int n, bool defer = false);           // push only (n <= qd_peer_max_slabs()) ...
+struct QdPeerPush;
+struct QsOcnArgs;
+bool qd_launch_ocn_stream_push(qd_ctx* c, const QsOcnArgs& A);           // qd_stream_push.hip: the strips of A behind a waiting push (false: none waiting)
+bool qd_peer_take_job(qd_ctx* c, QdPeerPush* J);                         // a deferred push, for the launch that will carry it
 int  qd_peer_halo_end(qd_ctx* c);                                        // ... wait + unpack
 int  qd_peer_max_slabs();
-bool qd_peer_overlap(const qd_ctx* c);                                   // QD_PEER_OVERLAP: consumers split into interior / boundary rows around an exchange
+int  qd_peer_overlap(const qd_ctx* c);                                   // QD_PEER_OVERLAP: 0 no split; consumers split into interior / boundary rows around an exchange: 1 push as its own kernel, 2 carried by the interior launch
 struct QdPeerFold;
 bool qd_peer_fold_begin(qd_ctx* c, QdPeerFold* F);                       // a one-double sum finished inside its producer's launch (qd_peer_dev.h)
 int  qd_peer_init_group(QdLocalGroup* g);                                // in-process group: one mailbox per handle, pointers shared

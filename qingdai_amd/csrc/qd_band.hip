@@ -213,7 +213,7 @@ static int qd_plan_impl(qd_ctx* c, const QdUse* in_, int n_in, int want, bool* p
         if (pending && qd_peer_overlap(c) && (int)ex.size() <= qd_peer_max_slabs() && c->own_nrows >= H) {
             // only the push: the caller computes what the old margins allow, then qd_plan_end()
             c->exchanges += 1;
-            if (qd_peer_halo_begin(c, ex.data(), (int)ex.size())) return -1;
+            if (qd_peer_halo_begin(c, ex.data(), (int)ex.size(), qd_peer_overlap(c) >= 2)) return -1;
             c->split_pending = ex;
             *pending = true;
             return 0;

@@ -40,18 +40,14 @@
 #include <cstring>
 #include <algorithm>
 
-#define QP_MAXSLABS 16
 #define QP_RV 4104                      // 8-byte units per rank slot of a reduction (median segment: 4096 + 4)
 #define QP_PART_BYTES 16384             // bytes of a halo segment one workgroup copies
 #define QP_MAX_PARTS 32
 
-struct QdPeerHalo {
-    void* slab[QP_MAXSLABS];
-    unsigned char u8[QP_MAXSLABS];
-    int n, H, nown, nlon;
-};
-
 struct QdPeer {
+    QdPeerPush job;                      // a booked push nobody has launched yet (qd_peer_halo_begin(defer) .. qd_peer_take_job / unpack)
+    bool job_waiting = false;
+    int n_carried = 0;                   // pushes that went out inside a compute kernel's launch
     int on = 0, local = 0, world = 1, rank = 0, up = 0, dn = 0;
     char* box = nullptr;                          // my mailbox
     size_t box_bytes = 0, off_rv = 0, rv_stride = 0, off_stage = 0, slab_stride = 0, dir_stride = 0, par_stride = 0;
@@ -64,71 +60,19 @@ struct QdPeer {
     double* herr = nullptr;                       // pinned host word: a poll loop ran into its deadline
     long n_halo = 0, n_reduce = 0;
     int coarse = 0;                               // QD_PEER_COARSE=1: mailbox in ordinary device memory, full fences in the kernels
-    int overlap = 0;                              // QD_PEER_OVERLAP: 1 = consumers of an exchange run their interior rows between push and unpack (default: world > 1)
+    int overlap = 0;                              // QD_PEER_OVERLAP: consumers of an exchange run their interior rows between push and unpack: 2 (default, world > 1) =
+                                                  // the push rides in the interior launch itself, 1 = as a kernel of its own before it, 0 = no split
     int fold = 1;                                 // QD_PEER_FOLD=0: the eta sum of a sub-step as a k_peer_reduce launch of its own
     bool pushed = false;                          // a push is out whose unpack has not been launched yet
     QdPeerHalo pend;                              // its slabs
 };
 
 bool qd_peer_on(const qd_ctx* c) { return c->peer && c->peer->on; }
-bool qd_peer_overlap(const qd_ctx* c) { return c->peer && c->peer->on && c->peer->overlap; }
+int qd_peer_overlap(const qd_ctx* c) { return c->peer && c->peer->on ? c->peer->overlap : 0; }
 int qd_peer_max_slabs() { return QP_MAXSLABS; }
 
 // ------------------------------------------------------------------ device side
-// One (slab, direction) segment of an exchange is H rows; a launch is a 2-D grid: blockIdx.y = 2 k + direction, blockIdx.x = one of
-// nbx contiguous parts of the segment, four accesses in flight per lane.
-// Every access to a MAILBOX is a system-scope atomic (relaxed) load or store of 8 bytes (single bytes for u8 slabs whose rows are
-// not 8-byte aligned): such accesses go to the point of coherence whatever memory type the mapping has.  That matters between
-// processes: a mailbox is allocated fine-grained, but the mapping hipIpcOpenMemHandle hands to ANOTHER process behaves like ordinary
-// (coarse-grained, L2-cached) memory -- with plain stores and a wait for their acknowledgement, rank processes on one GPU read stale
-// halo rows (the in-process groups, which share the owner's own pointer, did not); and a full release fence per workgroup writes back
-// the whole L2, which the kernel before an exchange has just filled with the band (28 us for a push of 2 x 5.9 MB, 7 us like this).
-template <typename T, bool PUT>
-__device__ __forceinline__ void qp_copy_t(char* dst, const char* src, size_t bytes, int part, int nparts) {
-    const size_t n = bytes / sizeof(T);
-    const size_t per = (n + nparts - 1) / nparts;
-    const size_t i0 = (size_t)part * per, i1 = i0 + per < n ? i0 + per : n;
-    T* d = (T*)dst; const T* q = (const T*)src;
-    auto ld = [&](size_t i) -> T { return PUT ? q[i] : __hip_atomic_load(q + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
-    auto st = [&](size_t i, T v) { if (PUT) __hip_atomic_store(d + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); else d[i] = v; };
-    size_t i = i0 + threadIdx.x;
-    for (; i + 3 * blockDim.x < i1; i += 4 * blockDim.x) {
-        const T a = ld(i), b = ld(i + blockDim.x), c = ld(i + 2 * blockDim.x), e = ld(i + 3 * blockDim.x);
-        st(i, a); st(i + blockDim.x, b); st(i + 2 * blockDim.x, c); st(i + 3 * blockDim.x, e);
-    }
-    for (; i < i1; i += blockDim.x) st(i, ld(i));
-}
-// PUT: plain loads from a slab, atomic stores into a mailbox; !PUT: atomic loads from my mailbox, plain stores into a slab
-template <bool PUT>
-__device__ __forceinline__ void qp_copy(char* dst, const char* src, size_t bytes, int part, int nparts) {
-    const unsigned long long al = (unsigned long long)dst | (unsigned long long)src | (unsigned long long)bytes;
-    if ((al & 7ull) == 0) qp_copy_t<unsigned long long, PUT>(dst, src, bytes, part, nparts);
-    else qp_copy_t<unsigned char, PUT>(dst, src, bytes, part, nparts);
-}
-
-// `tick`: a word in this device's ordinary memory; the workgroup that takes the last ticket of the launch knows that every other
-// workgroup's stores are out (each fenced at system scope before it took its ticket) and publishes the exchange's sequence number in
-// both neighbours' mailboxes -- ONE remote store per direction instead of an atomic per workgroup.
-__global__ void __launch_bounds__(256)
-k_halo_push(QdPeerHalo A, char* up_south, char* dn_north, size_t slab_stride, unsigned long long* up_flag, unsigned long long* dn_flag,
-            unsigned long long seq, unsigned int* tick, int coarse) {
-    const int k = blockIdx.y >> 1, dir = blockIdx.y & 1;
-    const size_t esz = A.u8[k] ? 1 : sizeof(double);
-    const size_t bytes = (size_t)A.H * A.nlon * esz;
-    const char* base = (const char*)A.slab[k];
-    if (dir == 0) qp_copy<true>(up_south + k * slab_stride, base + (size_t)A.nown * A.nlon * esz, bytes, blockIdx.x, gridDim.x);   // my top rows -> up's south halo
-    else qp_copy<true>(dn_north + k * slab_stride, base + (size_t)A.H * A.nlon * esz, bytes, blockIdx.x, gridDim.x);               // my bottom rows -> dn's north halo
-    qp_release(coarse);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned int nb = gridDim.x * gridDim.y;
-        if (__hip_atomic_fetch_add(tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nb - 1u) {
-            __hip_atomic_store(tick, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(up_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(dn_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-}
+__global__ void __launch_bounds__(256) k_halo_push(QdPeerPush J) { qp_push_block(J, (int)blockIdx.x, (int)blockIdx.y); }
 
 __global__ void __launch_bounds__(256)
 k_halo_unpack(QdPeerHalo A, const char* my_south, const char* my_north, size_t slab_stride, const unsigned long long* flag,
@@ -243,8 +187,8 @@ static int qp_alloc(qd_ctx* c) {
         hipFree(P->d_pbox); hipFree(P->box); delete P; return qd_fail(c, "peer exchange: ticket allocation", e);
     }
     { const char* ef = std::getenv("QD_PEER_FOLD"); if (ef && ef[0] == '0') P->fold = 0; }
-    P->overlap = world > 1 ? 1 : 0;
-    { const char* ef = std::getenv("QD_PEER_OVERLAP"); if (ef) P->overlap = ef[0] == '0' ? 0 : 1; }
+    P->overlap = world > 1 ? 2 : 0;
+    { const char* ef = std::getenv("QD_PEER_OVERLAP"); if (ef) P->overlap = ef[0] == '0' ? 0 : (ef[0] == '1' ? 1 : 2); }
     P->pbox[P->rank] = P->box;
     P->herr = c->hpin + 60;
     *P->herr = 0.0;
@@ -291,7 +235,9 @@ static dim3 qp_halo_grid(const qd_ctx* c, int n) {
     const int nbx = (int)std::min<size_t>(QP_MAX_PARTS, std::max<size_t>(1, seg / QP_PART_BYTES));
     return dim3(nbx, 2 * n);
 }
-static int qp_halo_push(qd_ctx* c, const QdUse* slots, int n) {
+// books the exchange (sequence number, buffer parity) and describes its push as a job; defer: the job waits in the handle for a kernel
+// that carries it in its own launch (qd_peer_take_job) -- qp_halo_unpack launches whatever nobody took
+static int qp_halo_push(qd_ctx* c, const QdUse* slots, int n, bool defer) {
     QdPeer* P = c->peer;
     if (P->pushed) return qp_fail(c, "peer exchange: a halo push is still waiting for its unpack");
     if (n < 1 || n > QP_MAXSLABS) return qp_fail(c, "peer exchange: bad slab count");
@@ -300,11 +246,17 @@ static int qp_halo_push(qd_ctx* c, const QdUse* slots, int n) {
     for (int k = 0; k < n; ++k) { A.slab[k] = *slots[k].slot; A.u8[k] = slots[k].u8 ? 1 : 0; }
     const int par = (int)(P->hseq & 1ull);
     P->hseq += 1; P->n_halo += 1;
-    char* up_south = P->pbox[P->up] + P->off_stage + par * P->par_stride;                      // dir 0: "from the south"
-    char* dn_north = P->pbox[P->dn] + P->off_stage + par * P->par_stride + P->dir_stride;      // dir 1: "from the north"
-    hipLaunchKernelGGL(k_halo_push, qp_halo_grid(c, n), dim3(256), 0, c->stream, A, up_south, dn_north, P->slab_stride,
-                       (unsigned long long*)(P->pbox[P->up] + QP_OFF_HCNT), (unsigned long long*)(P->pbox[P->dn] + QP_OFF_HCNT) + 1,
-                       P->hseq, P->tick, P->coarse);
+    const dim3 g = qp_halo_grid(c, n);
+    QdPeerPush J;
+    J.A = A;
+    J.up_south = P->pbox[P->up] + P->off_stage + par * P->par_stride;                      // dir 0: "from the south"
+    J.dn_north = P->pbox[P->dn] + P->off_stage + par * P->par_stride + P->dir_stride;      // dir 1: "from the north"
+    J.slab_stride = P->slab_stride;
+    J.up_flag = (unsigned long long*)(P->pbox[P->up] + QP_OFF_HCNT);
+    J.dn_flag = (unsigned long long*)(P->pbox[P->dn] + QP_OFF_HCNT) + 1;
+    J.seq = P->hseq; J.tick = P->tick; J.coarse = P->coarse; J.nbx = (int)g.x; J.nby = (int)g.y;
+    if (defer) { P->job = J; P->job_waiting = true; }
+    else hipLaunchKernelGGL(k_halo_push, g, dim3(256), 0, c->stream, J);
     P->pushed = true;
     return 0;
 }
@@ -312,6 +264,10 @@ static int qp_halo_push(qd_ctx* c, const QdUse* slots, int n) {
 static int qp_halo_unpack(qd_ctx* c) {
     QdPeer* P = c->peer;
     if (!P->pushed) return 0;
+    if (P->job_waiting) {
+        hipLaunchKernelGGL(k_halo_push, dim3(P->job.nbx, P->job.nby), dim3(256), 0, c->stream, P->job);
+        P->job_waiting = false;
+    }
     if (P->local) pthread_barrier_wait(&c->lgroup->bar);          // every push of the group is queued before any unpack polls
     const int par = (int)((P->hseq - 1) & 1ull);
     const char* my_south = P->box + P->off_stage + par * P->par_stride;
@@ -325,12 +281,19 @@ static int qp_halo_unpack(qd_ctx* c) {
 int qd_peer_halo(qd_ctx* c, const QdUse* slots, int n) {
     for (int k0 = 0; k0 < n; k0 += QP_MAXSLABS) {
         const int m = std::min(QP_MAXSLABS, n - k0);
-        if (qp_halo_push(c, slots + k0, m) || qp_halo_unpack(c)) return -1;
+        if (qp_halo_push(c, slots + k0, m, false) || qp_halo_unpack(c)) return -1;
     }
     return 0;
 }
-int qd_peer_halo_begin(qd_ctx* c, const QdUse* slots, int n) {      // n <= QP_MAXSLABS; qd_peer_halo_end() must follow
-    return qp_halo_push(c, slots, n);
+// n <= QP_MAXSLABS; qd_peer_halo_end() must follow.  defer: the push is not launched but left for a compute kernel to carry in its
+// own launch (qd_peer_take_job; k_ocn_stream_push) -- a push kernel of its own ends only when everything it sent has been
+// acknowledged over the links, and the stream starts nothing before that: the interior rows would not overlap the transfer at all
+int qd_peer_halo_begin(qd_ctx* c, const QdUse* slots, int n, bool defer) { return qp_halo_push(c, slots, n, defer); }
+bool qd_peer_take_job(qd_ctx* c, QdPeerPush* J) {
+    QdPeer* P = c->peer;
+    if (!P || !P->job_waiting) return false;
+    *J = P->job; P->job_waiting = false; P->n_carried += 1;
+    return true;
 }
 int qd_peer_halo_end(qd_ctx* c) { return qp_halo_unpack(c); }
 
@@ -483,6 +446,7 @@ extern "C" int qd_peer_selftest(qd_handle c, int iters, long long* wrong) {
 // back to the other transports (the self-test failed somewhere: every rank leaves the mailboxes together)
 extern "C" int qd_peer_disable(qd_handle c) { if (!c) return -1; if (c->peer) c->peer->on = 0; return 0; }
 
+extern "C" int qd_comm_peer_carried(qd_handle c) { return !c ? -1 : (c->peer ? c->peer->n_carried : 0); }
 extern "C" int qd_comm_peer_stats(qd_handle c, int* halo_exchanges, int* reductions) {
     if (!c || !halo_exchanges || !reductions) return -1;
     *halo_exchanges = c->peer ? (int)c->peer->n_halo : 0;

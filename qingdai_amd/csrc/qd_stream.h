@@ -516,8 +516,9 @@ __device__ __forceinline__ bool qs_del4_stream(SRC& S, const QdGeom& G, const Qs
 __host__ __device__ __forceinline__ int qs_cut(int nrows, int nrs, int vb, int rs) {
     return rs >= nrs ? nrows : (int)(((long long)rs * (nrows + vb)) / nrs);
 }
-__device__ __forceinline__ void qs_strip(const QdGeom& G, int vb, int ntc, int nrs, QsW& W) {
-    const unsigned w = qd_xcd_chunk(blockIdx.x, gridDim.x);
+// (bid of nb: the workgroup's index among the launch's strip workgroups -- k_ocn_stream_push has others in front of them)
+__device__ __forceinline__ void qs_strip(const QdGeom& G, int vb, int ntc, int nrs, QsW& W, unsigned bid, unsigned nb) {
+    const unsigned w = qd_xcd_chunk(bid, nb);
     const int rs = (int)(w / (unsigned)ntc), cs = (int)(w % (unsigned)ntc);
     W.n = G.nlat; W.nlon = G.nlon;
     W.lane = threadIdx.x & 63;
@@ -533,6 +534,7 @@ __device__ __forceinline__ void qs_strip(const QdGeom& G, int vb, int ntc, int n
     W.o0 = G.row0 + qs_cut(G.nrows, nrs, vb, rs);
     W.o1 = G.row0 + qs_cut(G.nrows, nrs, vb, rs + 1);
 }
+__device__ __forceinline__ void qs_strip(const QdGeom& G, int vb, int ntc, int nrs, QsW& W) { qs_strip(G, vb, ntc, nrs, W, blockIdx.x, gridDim.x); }
 
 template <bool PRIM, int V>
 __device__ __forceinline__ bool qs_dyn_wave(const QsDynArgs& A, const QsW& W, int wv) {

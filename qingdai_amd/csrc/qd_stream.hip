@@ -50,6 +50,7 @@ __device__ __forceinline__ void qs_stamp(int slot) {
 #endif
 
 #include "qd_stream.h"
+#include "qd_band.h"
 
 // FAST pass; a wave that met a non-finite value repeats its strip with the EXACT arithmetic
 template <bool PRIM>
@@ -266,7 +267,8 @@ int qd_launch_ocn_stream_list(qd_ctx* c, const QdOcnArgs& P, const QdSegList& S)
         const QdGeom& G = S.g[k];
         const QsShape sh = qs_shape(c, G.nrows, G.nlon, 2, G.row0 + G.nrows == G.nlat);
         A.G = G; A.vb = sh.vb; A.nrs = sh.nrs; A.ntc = (G.nlon + QS_TC - 1) / QS_TC;
-        hipLaunchKernelGGL(k_ocn_stream, dim3(A.nrs * A.ntc), dim3(192), 0, c->stream, A);
+        // a halo push waits for a launch to carry it (qd_plan_begin): k_ocn_stream_push, its workgroups go first (qd_stream_push.hip)
+        if (!qd_launch_ocn_stream_push(c, A)) hipLaunchKernelGGL(k_ocn_stream, dim3(A.nrs * A.ntc), dim3(192), 0, c->stream, A);
     }
     return 0;
 }

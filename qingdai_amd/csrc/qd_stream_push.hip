@@ -1,0 +1,42 @@
+// qd_stream_push.hip -- the ocean momentum kernel of a latitude band with a halo push in front (peer exchange, QD_PEER_OVERLAP=2).
+//
+// A sub-step whose halos are due splits its momentum launch into the interior rows (computable from the margins the slabs still
+// have) and two boundary strips (after the unpack; qd_ocean.hip).  For the interior to overlap the transfer, the transfer must be
+// IN FLIGHT while it runs: a push kernel of its own ends only when every store it sent over the links has been acknowledged
+// (s_waitcnt vmcnt(0) before the ticket), and the stream starts the next kernel after that -- on one device that is 7 us, over
+// xGMI it is the whole transfer (2 x 0.2-0.9 MB per neighbour at 1/8 of 1441 x 2880 against ~50 GB/s per direction and link).
+// So the push is not a kernel: it is the first J.nbx * J.nby workgroups of the interior launch.  They are dispatched first, issue
+// their stores and sit in s_waitcnt while the ~900 strip workgroups behind them fill the other wave slots.
+// Same strip code as k_ocn_stream (qd_stream.h); a translation unit of its own so that the whole-globe kernels are not rebuilt
+// around an argument block and a branch they do not use.
+#include "qd_internal.h"
+#include "qd_stream.h"
+#include "qd_band.h"
+#include "qd_peer_dev.h"
+
+__global__ void __launch_bounds__(192)
+k_ocn_stream_push(QsOcnArgs A, QdPeerPush J) {
+    const unsigned npush = (unsigned)(J.nbx * J.nby);
+    if (blockIdx.x < npush) { qp_push_block(J, (int)(blockIdx.x % (unsigned)J.nbx), (int)(blockIdx.x / (unsigned)J.nbx)); return; }
+    QsW W;
+    qs_strip(A.G, A.vb, A.ntc, A.nrs, W, blockIdx.x - npush, gridDim.x - npush);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wv <= 1) __builtin_amdgcn_s_setprio(2);
+    const QsOcnArgs QD_CONST* Ak = (const QsOcnArgs QD_CONST*)__builtin_amdgcn_kernarg_segment_ptr();      // A is the FIRST argument
+    const QsRec QD_CONST* fp = &Ak->rec[wv];
+    if (!A.exact) {
+        QsOutGlobal out{qs_make_rsrc(fp->out, W.slab_bytes), qs_off(A.G, W.o0), W.vs, (unsigned)W.nlon};
+        const bool bad = qs_ocn_wave<QS_FAST>(A, W, wv, fp, out);
+        if (__builtin_amdgcn_ballot_w64(bad) == 0ull) return;
+    }
+    QsOutGlobal out{qs_make_rsrc(fp->out, W.slab_bytes), qs_off(A.G, W.o0), W.vs, (unsigned)W.nlon};
+    qs_ocn_wave<QS_EXACT>(A, W, wv, fp, out);
+}
+
+// true: a deferred push was waiting and has gone out in front of the strips of A (A.nrs x A.ntc of them)
+bool qd_launch_ocn_stream_push(qd_ctx* c, const QsOcnArgs& A) {
+    QdPeerPush J;
+    if (!qd_peer_take_job(c, &J)) return false;
+    hipLaunchKernelGGL(k_ocn_stream_push, dim3(J.nbx * J.nby + A.nrs * A.ntc), dim3(192), 0, c->stream, A, J);
+    return true;
+}

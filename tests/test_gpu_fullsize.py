@@ -96,7 +96,7 @@ def test_eight_bands_match_the_whole_globe(gpu, transport, monkeypatch):
     momentum kernel split into interior / boundary rows around every exchange) -- the transport a multi-GPU run takes."""
     if transport == "peer":
         monkeypatch.setenv("QD_PEER_EXCHANGE", "1")
-        monkeypatch.setenv("QD_PEER_OVERLAP", "1")
+        monkeypatch.setenv("QD_PEER_OVERLAP", "2")
     ref, _ = _run(1, NLAT, NLON, 2, dict(energy_w=1.0), True, True)
     got, ex = _run(8, NLAT, NLON, 2, dict(energy_w=1.0), True, True)
     print("halo exchanges per band:", ex)

@@ -36,7 +36,7 @@ def test_peer_bands_atmosphere_bit_identical(gpu, world, monkeypatch):
         assert np.array_equal(got[k], ref[k]), (k, relerr(got[k], ref[k]))
 
 
-@pytest.mark.parametrize("overlap", ["1", "0"])
+@pytest.mark.parametrize("overlap", ["2", "1", "0"])
 @pytest.mark.parametrize("world", [2, 4])
 def test_peer_bands_full_step_with_ocean_and_physics(gpu, world, overlap, monkeypatch):
     """The coupled step: eta sums, CFL maxima, precipitation sums, both median paths (histogram all-reduce + gathered candidate
@@ -51,7 +51,7 @@ def test_peer_bands_full_step_with_ocean_and_physics(gpu, world, overlap, monkey
         assert e < 1e-12, (k, e)          # only the band-wise order of the global sums differs
 
 
-@pytest.mark.parametrize("overlap", ["0", "1"])
+@pytest.mark.parametrize("overlap", ["0", "1", "2"])
 def test_peer_self_ring_equals_in_process_transport(gpu, overlap, monkeypatch):
     """One rank whose ring neighbours are the rank itself: every operation in its fused one-launch form (push + poll + unpack,
     deposit + poll + reduce in one kernel), mailboxes mapped through qd_peer_export / qd_peer_connect.  Must move exactly the
@@ -60,8 +60,9 @@ def test_peer_self_ring_equals_in_process_transport(gpu, overlap, monkeypatch):
     from qingdai_amd.device import Device
     monkeypatch.setenv("MASTER_PORT", "29741")
     monkeypatch.setenv("QD_NO_HOST_RING", "1")
-    # overlap = 1: the ocean momentum kernel of a sub-step that exchanges runs its interior rows between push and unpack, the two
-    # boundary strips after the unpack (the default of a multi-rank run; a one-rank ring has to ask for it)
+    # overlap >= 1: the ocean momentum kernel of a sub-step that exchanges runs its interior rows between push and unpack, the two
+    # boundary strips after the unpack; 2 (the default of a multi-rank run; a one-rank ring has to ask for it): the push is the
+    # first workgroups of the interior launch itself (k_ocn_stream_push), so that the rows are in flight WHILE it computes
     monkeypatch.setenv("QD_PEER_OVERLAP", overlap)
     nlat, nlon, nsteps = 91, 144, 5
     qa, grid, mask, alb, fric, p = _setup(nlat, nlon, dict(energy_w=1.0))
@@ -91,6 +92,8 @@ def test_peer_self_ring_equals_in_process_transport(gpu, overlap, monkeypatch):
         ne, nh, nr = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
         dev.lib.qd_comm_stats(dev.h, ctypes.byref(ne)); dev.lib.qd_comm_peer_stats(dev.h, ctypes.byref(nh), ctypes.byref(nr))
         counts[transport] = (ne.value, nh.value, nr.value)
+        carried = dev.lib.qd_comm_peer_carried(dev.h)
+        assert (carried > 0) == (transport == "peer" and overlap == "2"), carried
         dev.close()
     print("halo exchanges, of them through mailboxes, reductions through mailboxes:", counts)
     assert counts["local"][0] == counts["peer"][0] and counts["local"][1:] == (0, 0)
