@@ -11,8 +11,10 @@
 //   halo exchange   k_halo_push copies my H top rows of every slab of the exchange into `up`'s mailbox (staging area "from the
 //                   south") and my H bottom rows into `dn`'s ("from the north"), then publishes the exchange's number there;
 //                   k_halo_unpack waits until both of MY flags carry the exchange's number and copies the staged rows
-//                   into my slabs' halo rows.  Whatever the stream runs between the two launches overlaps the transfer
-//                   (qd_band.hip launches the consumer's INTERIOR rows there).
+//                   into my slabs' halo rows.  What the stream runs between the two launches overlaps the NEIGHBOURS' transfers;
+//                   to overlap MY OWN too, the push must not be a kernel of its own (it ends when its stores are acknowledged,
+//                   and the stream starts nothing before that): qd_band.hip books the push as a job and the consumer's INTERIOR
+//                   rows carry it as the first workgroups of their own launch (qd_peer_dev.h qp_push_block, qd_stream_push.hip).
 //   scalar / histogram all-reduce, all-gather   k_peer_reduce: every rank deposits its n values in slot [rank] of EVERY mailbox,
 //                   bumps the counter [rank] there, waits until all `world` counters of its own mailbox have arrived and reduces
 //                   the slots in rank order -- the same bits on every rank, no host, no collective.
