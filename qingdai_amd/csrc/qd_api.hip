@@ -376,6 +376,13 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
         { const char* ef = std::getenv("QD_MEDIAN_PREDICT"); if (ef && ef[0] == '0') c->med_predict = 0; }
         { const char* ef = std::getenv("QD_MERGE_POINTWISE"); if (ef) c->merge_pointwise = ef[0] == '0' ? 0 : 1; }
         { const char* ef = std::getenv("QD_HOIST_PRECIP"); if (ef) c->hoist_precip = ef[0] == '0' ? 0 : 1; }
+        { const char* ef = std::getenv("QD_SIDE_STREAM"); if (ef) c->side_stream_on = ef[0] == '0' ? 0 : 1; }
+        if (c->side_stream_on) {
+            if ((e = hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+            if ((e = hipEventCreateWithFlags(&c->side_fork, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+            if ((e = hipEventCreateWithFlags(&c->side_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+            if ((e = hipMalloc(&c->red_partial_b, (size_t)c->red_blocks * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
+        }
     }
     if ((e = hipHostMalloc((void**)&c->hpin, 64 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return bail("hipHostMalloc", e);
     if ((e = hipHostMalloc((void**)&c->hpin_rows, (size_t)3 * c->geo.lrows() * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return bail("hipHostMalloc", e);
@@ -414,6 +421,9 @@ extern "C" int qd_destroy(qd_handle c) {
     if (c->land) hipFree(c->land); if (c->icemask) hipFree(c->icemask);
     if (c->k4_atm) hipFree(c->k4_atm); if (c->k4_ocn) hipFree(c->k4_ocn); for (int k = 0; k < 2; ++k) if (c->qs_tab[k]) hipFree(c->qs_tab[k]);
     if (c->red_partial) hipFree(c->red_partial); if (c->dscal) hipFree(c->dscal);
+    if (c->red_partial_b) hipFree(c->red_partial_b);
+    if (c->side_stream) { hipStreamSynchronize(c->side_stream); hipStreamDestroy(c->side_stream); }
+    if (c->side_fork) hipEventDestroy(c->side_fork); if (c->side_done) hipEventDestroy(c->side_done);
     if (c->eta_acc) hipFree(c->eta_acc);
     if (c->dcount) hipFree(c->dcount); if (c->hist) hipFree(c->hist); if (c->sel_state) hipFree(c->sel_state);
     if (c->zonal_tw) hipFree(c->zonal_tw);
@@ -588,6 +598,13 @@ extern "C" int qd_hydrology_commit(qd_handle c, double dt) {
     if (rc) return rc;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return qd_fail(c, "qd_hydrology_commit: launch", e);
+    return 0;
+}
+
+int qd_side_join(qd_ctx* c) {
+    if (!c->side_pending) return 0;
+    c->side_pending = false;
+    QD_HIP(c, hipStreamWaitEvent(c->stream, c->side_done, 0));
     return 0;
 }
 

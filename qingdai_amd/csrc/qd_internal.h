@@ -216,6 +216,13 @@ struct qd_ctx {
     double qt_tab_a = 0.0;
     int hoist_precip = 1;            // QD_HOIST_PRECIP=0: qd_step_n keeps the next step's precipitation block behind the ocean step
     int precip_done = 0;             // the precipitation block of the next driver-physics call has already run (qd_step_n)
+    // QD_SIDE_STREAM=1 (whole-globe handles): that hoisted block runs on a SECOND stream, concurrently with the ocean sub-steps, instead
+    // of in front of them (qd_ocean.hip: fork after the stress kernel; qd_side_join: before its first consumer)
+    int side_stream_on = 0;
+    hipStream_t side_stream = nullptr;
+    hipEvent_t side_fork = nullptr, side_done = nullptr;
+    bool side_pending = false;       // the side stream holds work the main stream has not waited for yet
+    double* red_partial_b = nullptr; // the block's own row partials while it runs beside the ocean step (which owns red_partial)
     std::function<int()> before_cfl_wait;   // whole-globe ocean step: queued after the stress kernel, before the host waits for the CFL maxima
     int merge_pointwise = 1;         // QD_MERGE_POINTWISE=0: every pointwise stage of qd_step_n as a launch of its own
     double* med_gather = nullptr;    // band handles: [world][4 + 4092] gathered candidate segments of the windowed median
@@ -317,6 +324,7 @@ int qd_exchange(qd_ctx* c, const QdUse* slots, int n);
 // (qd_plan_peek), calls qd_plan_end (wait + unpack, margins back to the halo width) and launches the remaining boundary rows
 struct QdSegList { QdGeom g[6]; int n; };
 QdSegList qd_segments_rows(qd_ctx* c, int vr0, int cnt, QdSegList S = QdSegList{{}, 0});   // rows [vr0, vr0 + cnt) of the ring (period n_lat), appended to S
+int qd_side_join(qd_ctx* c);         // the main stream waits for what the side stream holds (no-op when nothing is pending)
 int qd_plan_begin(qd_ctx* c, const QdUse* in, int n, bool* pending);
 int qd_plan_end(qd_ctx* c);
 int qd_plan_peek(qd_ctx* c, const QdUse* in, int n);

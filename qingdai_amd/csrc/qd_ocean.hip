@@ -715,7 +715,18 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
             if (c->before_cfl_wait) {
                 std::function<int()> fn = std::move(c->before_cfl_wait);
                 c->before_cfl_wait = nullptr;
-                if (fn()) return -1;
+                if (c->side_stream_on && c->timing != 1 && !c->ocn_fused) {
+                    // QD_SIDE_STREAM: the block goes BESIDE the sub-steps, not in front of them.  It reads what time_step left (fork:
+                    // everything queued so far) and writes only its own slabs and scalars; its first consumer joins (qd_side_join)
+                    QD_HIP(c, hipEventRecord(c->side_fork, c->stream));
+                    QD_HIP(c, hipStreamWaitEvent(c->side_stream, c->side_fork, 0));
+                    std::swap(c->stream, c->side_stream);
+                    const int r = fn();
+                    std::swap(c->stream, c->side_stream);
+                    if (r) return -1;
+                    QD_HIP(c, hipEventRecord(c->side_done, c->side_stream));
+                    c->side_pending = true;
+                } else if (fn()) return -1;
             }
             for (int k = 0; k < G.nrows; ++k)
                 if (qd_wait_host_flag(c, c->hpin_rows + (size_t)2 * G0.lrows() + k, c->eta_seq, "ocean step: the CFL maxima never arrived")) return -1;

@@ -360,6 +360,9 @@ int qd_driver_physics_impl(qd_ctx* c, double dt, const QdForcingCall* fc, int pa
     double*& pdyn = c->scratch[7];
     const int R1 = qd_gauss_radius(1.0);
     const int Rc = qd_adv_reach(c, dt, 250.0);
+    // the block's row partials: its own buffer when it may run beside the ocean step, which owns red_partial (QD_SIDE_STREAM)
+    double* const rp = (c->side_stream_on && c->red_partial_b) ? c->red_partial_b : c->red_partial;
+    if (part == 2 && qd_side_join(c)) return -1;              // the block ran on the side stream: its products are read from here on
     if (part != 2) {
         QdScope sc(c, "phys_precip");
         // median of pos = max(0, -(div - D_crit)) over pos > 0, straight from the divergence field
@@ -394,7 +397,7 @@ int qd_driver_physics_impl(qd_ctx* c, double dt, const QdForcingCall* fc, int pa
                     QdGeom g2 = G; g2.row0 = r0; g2.nrows = r1 - r0;
                     hipLaunchKernelGGL(k_precip_raw, dim3(1, g2.nrows), blk, 0, c->stream, g2, c->tabs, F[QD_F_U], F[QD_F_V],
                                        F[QD_F_PCOND], p.a, c->dlat, c->dlon, p.D_crit, p.p_betadiv, c->dscal + QD_S_PSCALE,
-                                       c->dcount, praw, pos, c->red_partial + (size_t)2 * G0.lrows(), orog);
+                                       c->dcount, praw, pos, rp + (size_t)2 * G0.lrows(), orog);
                 };
                 const int a0 = G.row0, a1 = G.row0 + G.nrows;
                 if (a1 <= own0 || a0 >= own1) run(a0, a1);
@@ -403,15 +406,15 @@ int qd_driver_physics_impl(qd_ctx* c, double dt, const QdForcingCall* fc, int pa
         }
         hipLaunchKernelGGL(k_precip_raw, dim3(1, Gown.nrows), blk, 0, c->stream, Gown, c->tabs, F[QD_F_U], F[QD_F_V],
                            F[QD_F_PCOND], p.a, c->dlat, c->dlon, p.D_crit, p.p_betadiv, c->dscal + QD_S_PSCALE, c->dcount, praw,
-                           pos, c->red_partial, orog);
+                           pos, rp, orog);
         qd_mark(c, {praw, pos}, m);
         if (band) {
-            hipLaunchKernelGGL(k_precip_rawsums, dim3(1), blk, 0, c->stream, c->red_partial, Gown.nrows, c->dscal + QD_S_TMP0);
+            hipLaunchKernelGGL(k_precip_rawsums, dim3(1), blk, 0, c->stream, rp, Gown.nrows, c->dscal + QD_S_TMP0);
             if (qd_allreduce_f64(c, c->dscal + QD_S_TMP0, 2, 0)) return -1;
             hipLaunchKernelGGL(k_precip_scalars_post, dim3(1), dim3(64), 0, c->stream, c->dscal + QD_S_TMP0, c->wsum_all, p.pq_min,
                                p.p_blend, p.p_hybrid_fallback, c->dscal + QD_S_RENORM);
         } else {
-            hipLaunchKernelGGL(k_precip_scalars, dim3(1), blk, 0, c->stream, c->red_partial, Gown.nrows, c->wsum_all, p.pq_min,
+            hipLaunchKernelGGL(k_precip_scalars, dim3(1), blk, 0, c->stream, rp, Gown.nrows, c->wsum_all, p.pq_min,
                                p.p_blend, p.p_hybrid_fallback, c->dscal + QD_S_RENORM);
         }
         // P = gaussian(P_raw * s); P_dyn = gaussian(k_precip * pos): the two scalings ride on the blur's loads

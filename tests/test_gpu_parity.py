@@ -528,8 +528,9 @@ def test_step_n_precipitation_block_inside_the_ocean_step_changes_nothing(gpu, m
     from qingdai_amd.driver import Simulation
     import qingdai_amd as qa
 
-    def run(hoist):
+    def run(hoist, side="0"):
         monkeypatch.setenv("QD_HOIST_PRECIP", hoist)
+        monkeypatch.setenv("QD_SIDE_STREAM", side)
         sim = Simulation(91, 180, params=qa.QdParams(), use_ocean=True, quiet=True, ecology=False)
         lat = np.deg2rad(sim.grid.lat_mesh)
         sim.gcm.h = 8000.0 - 9000.0 * np.sin(lat) ** 2
@@ -544,6 +545,11 @@ def test_step_n_precipitation_block_inside_the_ocean_step_changes_nothing(gpu, m
     a, b = run("1"), run("0")
     for k in a:
         assert np.array_equal(a[k], b[k], equal_nan=True), k
+    # QD_SIDE_STREAM=1: the hoisted block on a second stream, BESIDE the ocean sub-steps (fork after the stress kernel, join in front of
+    # the block's first consumer): still the same kernels on the same inputs
+    s2 = run("1", side="1")
+    for k in a:
+        assert np.array_equal(s2[k], b[k], equal_nan=True), k
 
 
 def test_cloud_source_propagates_nan_like_the_reference(gpu):
