@@ -253,6 +253,26 @@ int qd_wait_host_flag(qd_ctx* c, volatile double* flag, double seq, const char* 
 }
 
 
+// a self-validating slot in pinned host memory: the host keeps it at -1, the device stores a value >= 0 into it exactly once (one
+// uncached 8-byte store, no stamp and nothing to wait for on the device).  Takes the value and puts the slot back to -1.
+int qd_wait_host_nonneg(qd_ctx* c, volatile double* slot, double* out, const char* what) {
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    double v;
+    while (!((v = *slot) >= 0.0)) {
+        __builtin_ia32_pause();
+        if ((++spins & 0x3FFFu) == 0) {
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q != hipErrorNotReady && !(*slot >= 0.0)) return qd_fail(c, what, q);
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 60.0) return qd_fail(c, what);
+        }
+    }
+    *slot = -1.0;
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    *out = v;
+    return 0;
+}
+
 // n <= 32 device doubles into pinned host memory behind a stamp (system-scope stores; the stamp leaves after the values have been
 // acknowledged): what the host needs to decide its next launches (CFL maxima -> n_sub, the miss flag of a band's median).
 __global__ void k_publish_host(const double* __restrict__ src, int n, double* dst, double* stamp, double seq) {
@@ -377,6 +397,10 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
         { const char* ef = std::getenv("QD_MERGE_POINTWISE"); if (ef) c->merge_pointwise = ef[0] == '0' ? 0 : 1; }
         { const char* ef = std::getenv("QD_HOIST_PRECIP"); if (ef) c->hoist_precip = ef[0] == '0' ? 0 : 1; }
         { const char* ef = std::getenv("QD_SIDE_STREAM"); if (ef) c->side_stream_on = ef[0] == '0' ? 0 : 1; }
+        { const char* ef = std::getenv("QD_MERGE_FINAL"); if (ef) c->merge_final = ef[0] == '0' ? 0 : 1; }
+        // per-workgroup CFL maxima of k_final_qnet_stress: 2 x (segments x rows) doubles
+        c->n_wgmax = (int)(qd_grid2d(c->geo).x * (unsigned)c->geo.nrows);
+        if ((e = hipMalloc(&c->wgmax, (size_t)2 * c->n_wgmax * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
         if (c->side_stream_on) {
             if ((e = hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
             if ((e = hipEventCreateWithFlags(&c->side_fork, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
@@ -387,6 +411,7 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
     if ((e = hipHostMalloc((void**)&c->hpin, 64 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return bail("hipHostMalloc", e);
     if ((e = hipHostMalloc((void**)&c->hpin_rows, (size_t)3 * c->geo.lrows() * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return bail("hipHostMalloc", e);
     std::memset(c->hpin, 0, 64 * sizeof(double));
+    c->hpin[58] = -1.0; c->hpin[59] = -1.0;                  // self-validating slots of k_max2_publish (qd_wait_host_nonneg)
     std::memset(c->hpin_rows, 0, (size_t)3 * c->geo.lrows() * sizeof(double));      // [2 n .. 3 n): per-row arrival stamps of k_stress_max
     // reference initial state
     const double q0 = std::min(std::max(q_init_rh, 0.0), 1.0) * host_qsat(288.0, params->p0);
@@ -422,6 +447,7 @@ extern "C" int qd_destroy(qd_handle c) {
     if (c->k4_atm) hipFree(c->k4_atm); if (c->k4_ocn) hipFree(c->k4_ocn); for (int k = 0; k < 2; ++k) if (c->qs_tab[k]) hipFree(c->qs_tab[k]);
     if (c->red_partial) hipFree(c->red_partial); if (c->dscal) hipFree(c->dscal);
     if (c->red_partial_b) hipFree(c->red_partial_b);
+    if (c->wgmax) hipFree(c->wgmax);
     if (c->side_stream) { hipStreamSynchronize(c->side_stream); hipStreamDestroy(c->side_stream); }
     if (c->side_fork) hipEventDestroy(c->side_fork); if (c->side_done) hipEventDestroy(c->side_done);
     if (c->eta_acc) hipFree(c->eta_acc);
@@ -633,7 +659,11 @@ extern "C" int qd_step_n(qd_handle c, int n, double dt, int flags, const double*
         }
         else if ((rc = qd_simple_albedo_impl(c, 0.08))) return rc;
         if (!merged && (rc = qd_forcing_impl(c, st, st + 3, st[6], 1))) return rc;
-        if ((rc = qd_atmos_step_impl(c, dt, pass_alb ? 1 : 0))) return rc;
+        // the ocean step follows at once and nothing in between reads the post-final fields: k_final rides on its first launch
+        c->defer_final = (with_ocean && c->geo.full && c->merge_final && c->wgmax && !(want_diag && s == 0)) ? 1 : 0;
+        rc = qd_atmos_step_impl(c, dt, pass_alb ? 1 : 0);
+        c->defer_final = 0;
+        if (rc) return rc;
         // bit4: energy-budget means of the FIRST step, taken where the reference driver takes them -- after time_step, on the
         // fluxes of the coupling block (run_simulation.py:2199-2246) -- and kept for qd_energy_diagnostics_last
         if (with_ocean && want_diag && s == 0 && (rc = qd_energy_diag_impl(c, c->last_diag))) return rc;

@@ -438,8 +438,12 @@ int qd_atmos_step_impl(qd_ctx* c, double dt, int has_albedo) {
         const int m = qd_plan(c, {QD_IN(F[QD_F_CLOUD], R), QD_IN(F[QD_F_U], 0), QD_IN(F[QD_F_V], 0), QD_IN(F[QD_F_H], 0),
                                   QD_IN(F[QD_F_TS], 0), QD_IN(F[QD_F_Q], 0)});
         if (m < 0) return -1;
-        double* oc = qd_scratch(c, 0);
         const double decay = 1 - dt / (2.0 * 24 * 3600);
+        if (c->defer_final && c->geo.full) {                  // qd_step_n: the ocean step's first launch does this (k_final_qnet_stress)
+            c->final_pending.on = 1; c->final_pending.dt = dt; c->final_pending.decay = decay; c->final_pending.dfac = p.diff_factor;
+            return 0;
+        }
+        double* oc = qd_scratch(c, 0);
         QD_ROWS(c, m, G, hipLaunchKernelGGL(k_final, qd_grid2d(G), blk, 0, c->stream, G, c->tabs.cos6, dt, p.a, c->dlat, c->dlon,
                                             F[QD_F_U], F[QD_F_V], F[QD_F_H], F[QD_F_TS], F[QD_F_Q], F[QD_F_CLOUD], oc, decay,
                                             p.diff_factor));

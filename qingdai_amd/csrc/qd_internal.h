@@ -218,6 +218,14 @@ struct qd_ctx {
     int precip_done = 0;             // the precipitation block of the next driver-physics call has already run (qd_step_n)
     // QD_SIDE_STREAM=1 (whole-globe handles): that hoisted block runs on a SECOND stream, concurrently with the ocean sub-steps, instead
     // of in front of them (qd_ocean.hip: fork after the stress kernel; qd_side_join: before its first consumer)
+    // whole-globe qd_step_n: time_step's last kernel (k_final: cloud gather + damp + scrub) is not launched by qd_atmos_step_impl but
+    // left here for the ocean step, whose first launch does it together with the wind stress, the CFL row maxima and Q_net
+    // (k_final_qnet_stress: the three were 17 + 12 + 15 us and read each other's u, v, T_s, h again)
+    int defer_final = 0;             // set by qd_step_n around qd_atmos_step_impl
+    int merge_final = 1;             // QD_MERGE_FINAL=0: keep the three launches
+    struct { int on = 0; double dt = 0, decay = 0, dfac = 0; } final_pending;
+    double* wgmax = nullptr;         // [2][n_wgmax]: per-workgroup CFL maxima of k_final_qnet_stress (k_max2_publish reduces them)
+    int n_wgmax = 0;
     int side_stream_on = 0;
     hipStream_t side_stream = nullptr;
     hipEvent_t side_fork = nullptr, side_done = nullptr;
@@ -411,6 +419,7 @@ int qd_driver_physics_impl(qd_ctx* c, double dt, const QdForcingCall* fc = nullp
 int qd_hydrology_commit_impl(qd_ctx* c, double dt);
 
 // qd_api.hip
+int qd_wait_host_nonneg(qd_ctx* c, volatile double* slot, double* out, const char* what);
 int qd_wait_host_flag(qd_ctx* c, volatile double* flag, double seq, const char* what);   // spin on a stamp in pinned host memory
 int qd_fetch_scalars(qd_ctx* c, const double* dsrc, int n, double* hdst);                // n <= 32 device doubles -> pinned host memory, no stream sync
 int qd_build_k4_tables(qd_ctx* c, double dt, bool ocean, double sub_dt);

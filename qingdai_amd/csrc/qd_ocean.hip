@@ -170,6 +170,85 @@ k_stress_max(QdGeom G, const double* __restrict__ ua, const double* __restrict__
     }
 }
 
+// ------------------------------------------------------------------ k_final + k_stress_max + k_qnet in one launch (whole globe, qd_step_n)
+// time_step's last kernel (dynamics.py:642-667: cloud gather with the new winds, decay, damp, scrub) is pointwise apart from the
+// gather from the OLD cloud slab, and so are the two kernels the coupling block starts with (run_simulation.py:2199-2239, ocean.py:
+// 283-303): they read the u, v, T_s, h it has just written.  One 2-D launch does all three from registers: 183 MB instead of 233 MB
+// moved.  The CFL maxima: every workgroup stores its two maxima (>= 0; NaN never wins: the running maximum is only replaced by
+// something GREATER) into its own two slots of device memory and ends; one small workgroup behind it (k_max2_publish) reduces
+// the 2 x 4 326 values and hands the two maxima to the host behind a stamp.  What was tried for the hand-over instead
+// (profiles/README.md): one workgroup per row like k_stress_max (round 3: 51 us); an integer atomicMax per row + a ticket + the
+// row's stamp from its last workgroup (42 us: 4 326 workgroups that each end in two dependent L2 round trips of one thread);
+// two uncached stores per workgroup straight into self-validating host slots (64 us: 8 652 small writes over PCIe).
+struct QdFqsArgs {
+    const double* cosl; double dt, a, dlat, dlon, decay, dfac;
+    double *u, *v, *h, *Ts, *q; const double* cloud_in; double* cloud_out;
+    const double *isr, *albedo, *cloud_eff, *hice, *LH; const uint8_t* land; double* qnet; uint8_t* icemask;
+    const double *uo, *vo; double vcap, rhoCD, tau_scale; double *taux, *tauy;
+    double* dev_wg; int n_wg;
+};
+__global__ void __launch_bounds__(QD_BLOCK)
+k_final_qnet_stress(QdGeom G, QdColP P, QdFqsArgs A) {
+    __shared__ double sm[2][QD_BLOCK / 64];
+    const QdTile tl = qd_tile();
+    const int j = tl.seg * QD_BLOCK + threadIdx.x;
+    const int i = G.row0 + tl.row;
+    double Va = 0.0, so = 0.0;
+    if (j < G.nlon) {
+        const size_t o = (size_t)qd_lrow(G, i) * G.nlon + j;
+        // ---- k_final
+        const double uu = A.u[o], vv = A.v[o];
+        const QdBilin b = qd_departure(G, i, j, uu, vv, A.dt, A.a, A.cosl[i], A.dlat, A.dlon);
+        double c = qd_gather(A.cloud_in, G, b);
+        c = c * A.decay;
+        const double cn = qd_nn(c * A.dfac), un = qd_nn(uu * A.dfac), vn = qd_nn(vv * A.dfac);
+        const double hn = qd_nn(A.h[o] * A.dfac), tn = qd_nn(A.Ts[o]);
+        A.cloud_out[o] = cn; A.u[o] = un; A.v[o] = vn; A.h[o] = hn; A.q[o] = qd_nn(A.q[o] * A.dfac); A.Ts[o] = tn;
+        // ---- k_stress_max
+        const double u_o = A.uo[o], v_o = A.vo[o];
+        const double u_rel = un - u_o, v_rel = vn - v_o;
+        Va = sqrt(u_rel * u_rel + v_rel * v_rel);
+        const double Va_eff = qd_min(Va, A.vcap);
+        A.taux[o] = A.tau_scale * (A.rhoCD * Va_eff * u_rel);
+        A.tauy[o] = A.tau_scale * (A.rhoCD * Va_eff * v_rel);
+        so = sqrt(u_o * u_o + v_o * v_o);
+        // ---- k_qnet (cloud optical field: cloud_eff_last when time_step produced one, else the cloud cover just written)
+        const double T_a = 288.0 + P.ga * hn;
+        const double hi = A.hice[o];
+        const QdFlux F = qd_surface_fluxes(P, A.isr[o], A.albedo[o], A.cloud_eff ? A.cloud_eff[o] : cn, tn, T_a, un, vn, A.land[o] == 1, hi);
+        A.qnet[o] = F.SW_sfc - F.LW_sfc - F.SH - A.LH[o];
+        A.icemask[o] = (hi > 0.0) ? 1 : 0;
+    }
+    double mVa = Va > 0.0 ? Va : 0.0, mUo = so > 0.0 ? so : 0.0;           // NaN never wins (k_stress_max: replaced only by something greater than 0)
+    mVa = qd_wave_max_d(mVa); mUo = qd_wave_max_d(mUo);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { sm[0][w] = mVa; sm[1][w] = mUo; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < QD_BLOCK / 64; ++k) { mVa = sm[0][k] > mVa ? sm[0][k] : mVa; mUo = sm[1][k] > mUo ? sm[1][k] : mUo; }
+        const unsigned wg = (unsigned)tl.row * gridDim.x + (unsigned)tl.seg;
+        A.dev_wg[wg] = mVa; A.dev_wg[A.n_wg + wg] = mUo;                 // device memory, nothing to wait for: k_max2_publish follows
+    }
+}
+
+// the two maxima over the per-workgroup maxima of k_final_qnet_stress -> two self-validating slots in pinned host memory (the host
+// keeps them at -1 and polls for >= 0: qd_wait_host_nonneg; no stamp, so nothing to wait for here).  One workgroup.
+__global__ void __launch_bounds__(1024)
+k_max2_publish(const double* __restrict__ wgmax, int n, double* host2) {
+    __shared__ double sm[2][16];
+    double a = 0.0, b = 0.0;
+    for (int k = threadIdx.x; k < n; k += 1024) { const double x = wgmax[k], y = wgmax[n + k]; a = x > a ? x : a; b = y > b ? y : b; }
+    a = qd_wave_max_d(a); b = qd_wave_max_d(b);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { sm[0][w] = a; sm[1][w] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 16; ++k) { a = sm[0][k] > a ? sm[0][k] : a; b = sm[1][k] > b ? sm[1][k] : b; }
+        __hip_atomic_store((unsigned long long*)host2, (unsigned long long)__double_as_longlong(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store((unsigned long long*)host2 + 1, (unsigned long long)__double_as_longlong(b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 __global__ void __launch_bounds__(QD_BLOCK)
 k_max2_finish(const double* __restrict__ partial, int n, double* __restrict__ out, int nzero) {
     __shared__ double sm[2][QD_BLOCK / 64];
@@ -705,11 +784,33 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
             // coherent), so the wait the host needs anyway is the only cost -- no copy kernel (measured: 16 us per step)
             const QdGeom& G = S.g[0];
             c->eta_seq += 1.0;
+            bool merged_final = false;
+            if (c->final_pending.on) {
+                // qd_step_n left time_step's last kernel for this launch: final + stress + row maxima + Q_net in one (k_final_qnet_stress)
+                if (!compute_qnet) return qd_fail(c, "ocean step: a deferred k_final needs compute_qnet");
+                c->final_pending.on = 0;
+                QdFqsArgs A;
+                A.cosl = c->tabs.cos6; A.dt = c->final_pending.dt; A.a = p.a; A.dlat = c->dlat; A.dlon = c->dlon;
+                A.decay = c->final_pending.decay; A.dfac = c->final_pending.dfac;
+                A.u = F[QD_F_U]; A.v = F[QD_F_V]; A.h = F[QD_F_H]; A.Ts = F[QD_F_TS]; A.q = F[QD_F_Q];
+                A.cloud_in = F[QD_F_CLOUD]; A.cloud_out = qd_scratch(c, 0);
+                A.isr = F[QD_F_ISR]; A.albedo = F[QD_F_ALBEDO]; A.cloud_eff = c->cloud_eff_valid ? F[QD_F_CLOUD_EFF] : nullptr;
+                A.hice = F[QD_F_HICE]; A.LH = F[QD_F_LH]; A.land = c->land; A.qnet = F[QD_F_QNET]; A.icemask = c->icemask;
+                A.uo = F[QD_F_UO]; A.vo = F[QD_F_VO]; A.vcap = p.vcap; A.rhoCD = p.rho_a_ocean * p.CD; A.tau_scale = p.tau_scale;
+                A.taux = taux; A.tauy = tauy;
+                A.dev_wg = c->wgmax; A.n_wg = c->n_wgmax;
+                merged_final = true;
+                hipLaunchKernelGGL(k_final_qnet_stress, qd_grid2d(G), blk, 0, c->stream, G, qd_make_colp_driver(c, dt), A);
+                hipLaunchKernelGGL(k_max2_publish, dim3(1), dim3(1024), 0, c->stream, c->wgmax, c->n_wgmax, c->hpin + 58);
+                qd_swap(c, QD_F_CLOUD, 0);
+                use_ice_mask = 1;
+            } else {
             hipLaunchKernelGGL(k_stress_max, dim3(1, G.nrows), blk, 0, c->stream, G, F[QD_F_U], F[QD_F_V], F[QD_F_UO],
                                F[QD_F_VO], p.vcap, p.rho_a_ocean * p.CD, p.tau_scale, taux, tauy, c->hpin_rows,
                                c->hpin_rows + (size_t)2 * G0.lrows(), c->eta_seq);
             qd_mark(c, {taux, tauy}, m);
             if (compute_qnet && launch_qnet()) return -1;
+            }
             // qd_step_n: work of the NEXT step that depends on neither the ocean nor the sub-step count (the precipitation block:
             // ~65 us of launches) goes in here, so the device has something to do while the host waits (the gap was 24 us a step)
             if (c->before_cfl_wait) {
@@ -728,9 +829,14 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
                     c->side_pending = true;
                 } else if (fn()) return -1;
             }
+            if (merged_final) {
+                if (qd_wait_host_nonneg(c, c->hpin + 58, &maxVa, "ocean step: the CFL maxima never arrived") ||
+                    qd_wait_host_nonneg(c, c->hpin + 59, &maxUo, "ocean step: the CFL maxima never arrived")) return -1;
+            } else {
             for (int k = 0; k < G.nrows; ++k)
                 if (qd_wait_host_flag(c, c->hpin_rows + (size_t)2 * G0.lrows() + k, c->eta_seq, "ocean step: the CFL maxima never arrived")) return -1;
             for (int k = 0; k < G.nrows; ++k) { maxVa = std::max(maxVa, c->hpin_rows[k]); maxUo = std::max(maxUo, c->hpin_rows[G.nrows + k]); }
+            }
         } else {
         for (int k = 0; k < S.n; ++k) {
             const QdGeom& G = S.g[k];

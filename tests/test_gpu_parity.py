@@ -528,9 +528,10 @@ def test_step_n_precipitation_block_inside_the_ocean_step_changes_nothing(gpu, m
     from qingdai_amd.driver import Simulation
     import qingdai_amd as qa
 
-    def run(hoist, side="0"):
+    def run(hoist, side="0", merge_final="1"):
         monkeypatch.setenv("QD_HOIST_PRECIP", hoist)
         monkeypatch.setenv("QD_SIDE_STREAM", side)
+        monkeypatch.setenv("QD_MERGE_FINAL", merge_final)
         sim = Simulation(91, 180, params=qa.QdParams(), use_ocean=True, quiet=True, ecology=False)
         lat = np.deg2rad(sim.grid.lat_mesh)
         sim.gcm.h = 8000.0 - 9000.0 * np.sin(lat) ** 2
@@ -550,6 +551,11 @@ def test_step_n_precipitation_block_inside_the_ocean_step_changes_nothing(gpu, m
     s2 = run("1", side="1")
     for k in a:
         assert np.array_equal(s2[k], b[k], equal_nan=True), k
+    # QD_MERGE_FINAL=0: time_step's last kernel, the wind stress + CFL row maxima and Q_net as three launches instead of one
+    # (k_final_qnet_stress): the same arithmetic per cell, the same maxima
+    s3 = run("1", merge_final="0")
+    for k in a:
+        assert np.array_equal(s3[k], b[k], equal_nan=True), k
 
 
 def test_cloud_source_propagates_nan_like_the_reference(gpu):
