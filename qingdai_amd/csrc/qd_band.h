@@ -34,6 +34,20 @@ int  qd_peer_halo(qd_ctx* c, const QdUse* slots, int n);                 // the 
 int  qd_peer_allreduce(qd_ctx* c, void* dptr, int n, int kind);          // kind 0: f64 sum in rank order, 1: f64 max, 2: u32 sum
 int  qd_peer_allreduce_publish(qd_ctx* c, double* dptr, int n, int op_max, double* hdst, double hseq);   // ... and straight on to pinned host memory
 int  qd_peer_allgather(qd_ctx* c, double* buf, int n_per_rank);          // buf[world][n_per_rank], own segment filled in
+// What a band launches right in front of / behind a small reduction, done by the reduction's own workgroup 0 instead (one launch of
+// ~4.7 us each on a 1/8 band): the producer of the vector (pre) and the consumer of the result (post).
+struct QdPeerHook {
+    int pre = 0;               // 1: k_med_pack (header of my gathered median segment from the select state; OP gather)
+                               // 2: k_precip_rawsums (data[0], data[1] = the two row sums of partial[0..n) and partial[n..2n))
+                               // 3: k_max2_finish per row segment (data[2k], data[2k+1] = maxima of partial[k * pstride ..], k < nseg; the rest of data[0..6) = 0)
+    const double* partial = nullptr; int n = 0, nseg = 0, nsegrows[3] = {0, 0, 0}; size_t pstride = 0;
+    unsigned long long* st = nullptr; unsigned int* cc = nullptr;
+    int post = 0;              // 1: k_precip_scalars_post on the reduced (num, den)
+    double wsum = 0, pq_min = 0, p_blend = 0; int use_fb = 0; double* out = nullptr;
+};
+int  qd_peer_allreduce_hooked(qd_ctx* c, double* dptr, int n, int op_max, const QdPeerHook& H, double* hdst = nullptr, double hseq = 0.0);
+int  qd_peer_allgather_hooked(qd_ctx* c, double* buf, int n_per_rank, const QdPeerHook& H);
+bool qd_peer_hooks(const qd_ctx* c);                                     // the hooked forms are available (peer exchange on, QD_PEER_HOOKS != 0)
 int  qd_peer_halo_begin(qd_ctx* c, const QdUse* slots, int n, bool defer = false);           // push only (n <= qd_peer_max_slabs()) ...
 struct QdPeerPush;
 struct QsOcnArgs;

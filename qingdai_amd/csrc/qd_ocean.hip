@@ -838,17 +838,29 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
             for (int k = 0; k < G.nrows; ++k) { maxVa = std::max(maxVa, c->hpin_rows[k]); maxUo = std::max(maxUo, c->hpin_rows[G.nrows + k]); }
             }
         } else {
+        const bool hooked = qd_peer_hooks(c) && !qd_has_host_ring(c) && S.n <= 3;
         for (int k = 0; k < S.n; ++k) {
             const QdGeom& G = S.g[k];
             // partial maxima of halo segments are harmless (a max over more valid rows of the globe)
             hipLaunchKernelGGL(k_stress_max, dim3(1, G.nrows), blk, 0, c->stream, G, F[QD_F_U], F[QD_F_V], F[QD_F_UO],
                                F[QD_F_VO], p.vcap, p.rho_a_ocean * p.CD, p.tau_scale, taux, tauy,
                                c->red_partial + (size_t)k * 2 * G0.lrows(), (double*)nullptr, 0.0);
+            if (!hooked)
             hipLaunchKernelGGL(k_max2_finish, dim3(1), blk, 0, c->stream, c->red_partial + (size_t)k * 2 * G0.lrows(), G.nrows,
                                c->dscal + QD_S_TMP0 + 2 * k, k == S.n - 1 ? 2 * (3 - S.n) : 0);
         }
         qd_mark(c, {taux, tauy}, m);
-        if (qd_has_host_ring(c)) {
+        if (hooked) {
+            // the reducing kernel finishes the row maxima of every segment itself (QdPeerHook::pre 3 = k_max2_finish), all-reduces the
+            // six maxima and hands them to the host: one launch
+            QdPeerHook H; H.pre = 3; H.partial = c->red_partial; H.pstride = (size_t)2 * G0.lrows(); H.nseg = S.n;
+            for (int k = 0; k < S.n; ++k) H.nsegrows[k] = S.g[k].nrows;
+            c->allreduces++;
+            c->pub_seq += 1.0;
+            if (qd_peer_allreduce_hooked(c, c->dscal + QD_S_TMP0, 6, 1, H, c->hpin, c->pub_seq)) return -1;
+            if (qd_wait_host_flag(c, c->hpin + 61, c->pub_seq, "reduced scalars never reached the host")) return -1;
+            if (c->hpin[60] != 0.0) return qd_fail(c, "peer exchange: a rank did not arrive within the deadline");
+        } else if (qd_has_host_ring(c)) {
             // the host waits for these six maxima anyway: reduce them across the ranks in the host ring, no RCCL launch
             QD_HIP(c, hipMemcpyAsync(c->hpin, c->dscal + QD_S_TMP0, 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
             QD_HIP(c, hipStreamSynchronize(c->stream));

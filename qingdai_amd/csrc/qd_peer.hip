@@ -64,6 +64,7 @@ struct QdPeer {
     int coarse = 0;                               // QD_PEER_COARSE=1: mailbox in ordinary device memory, full fences in the kernels
     int overlap = 0;                              // QD_PEER_OVERLAP: consumers of an exchange run their interior rows between push and unpack: 2 (default, world > 1) =
                                                   // the push rides in the interior launch itself, 1 = as a kernel of its own before it, 0 = no split
+    int hooks = 1;                                // QD_PEER_HOOKS=0: the small kernels around a reduction (k_med_pack, k_precip_rawsums, k_precip_scalars_post, k_max2_finish) stay launches of their own
     int fold = 1;                                 // QD_PEER_FOLD=0: the eta sum of a sub-step as a k_peer_reduce launch of its own
     bool pushed = false;                          // a push is out whose unpack has not been launched yet
     QdPeerHalo pend;                              // its slabs
@@ -93,11 +94,57 @@ k_halo_unpack(QdPeerHalo A, const char* my_south, const char* my_north, size_t s
 // OP 0: f64 sum in rank order, 1: f64 max, 2: u32 sum (two per 8-byte unit), 3: gather (data[q][n8] <- slot q).
 // phase bit 0: deposit my chunk in every mailbox; bit 1: wait for every rank's deposit in mine, reduce my chunk into `data`.
 // Block b owns units [b * per, (b + 1) * per) of the vector in both phases, so the in-place result never races with a deposit.
+// the producer of a small vector, run by workgroup 0 in front of its deposit (QdPeerHook::pre; same arithmetic in the same order as
+// the kernels it stands for: k_med_pack qd_reduce.hip, k_precip_rawsums qd_physics.hip, k_max2_finish qd_ocean.hip)
+__device__ __forceinline__ void qp_hook_pre(const QdPeerHook& H, unsigned long long* data, int rank, int n8) {
+    __shared__ double sm[2][4];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (H.pre == 1) {
+        if (t == 0) {
+            double* seg = (double*)(data + (size_t)rank * n8);
+            seg[0] = (double)H.st[0]; seg[1] = (double)H.st[1]; seg[2] = (double)H.cc[0]; seg[3] = 0.0;
+            H.st[0] = 0ull; H.st[1] = 0ull; H.cc[0] = 0u;
+        }
+    } else if (H.pre == 2) {
+        double a = 0.0, b = 0.0;
+        for (int k = t; k < H.n; k += 256) { a += H.partial[k]; b += H.partial[H.n + k]; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); b += __shfl_down(b, o, 64); }
+        if (lane == 0) { sm[0][wv] = a; sm[1][wv] = b; }
+        __syncthreads();
+        if (t == 0) {
+            for (int k = 1; k < 4; ++k) { a += sm[0][k]; b += sm[1][k]; }
+            ((double*)data)[0] = a; ((double*)data)[1] = b;
+        }
+    } else if (H.pre == 3) {
+        for (int s = 0; s < 3; ++s) {
+            double a = 0.0, b = 0.0;
+            if (s < H.nseg) {
+                const double* p = H.partial + (size_t)s * H.pstride;
+                const int n = H.nsegrows[s];
+                for (int k = t; k < n; k += 256) { a = p[k] > a ? p[k] : a; b = p[n + k] > b ? p[n + k] : b; }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { const double y = __shfl_down(a, o, 64), z = __shfl_down(b, o, 64); a = y > a ? y : a; b = z > b ? z : b; }
+            }
+            __syncthreads();                                      // sm is reused per segment
+            if (lane == 0) { sm[0][wv] = a; sm[1][wv] = b; }
+            __syncthreads();
+            if (t == 0) {
+                for (int k = 1; k < 4; ++k) { a = sm[0][k] > a ? sm[0][k] : a; b = sm[1][k] > b ? sm[1][k] : b; }
+                ((double*)data)[2 * s] = a; ((double*)data)[2 * s + 1] = b;
+            }
+        }
+    }
+    __syncthreads();                                              // workgroup 0 deposits what thread 0 has just written
+}
+
 template <int OP>
 __global__ void __launch_bounds__(256)
 k_peer_reduce(char* const* __restrict__ pbox, int world, int rank, size_t off_rv, size_t rv_stride, int parity, unsigned long long* data,
-              int n8, int per, unsigned long long expect, int phase, double* herr, int coarse, double* hdst, double* hstamp, double hseq) {
+              int n8, int per, unsigned long long expect, int phase, double* herr, int coarse, double* hdst, double* hstamp, double hseq,
+              QdPeerHook H) {
     const int i0 = blockIdx.x * per, i1 = min(n8, i0 + per);
+    if ((phase & 1) && H.pre && blockIdx.x == 0) qp_hook_pre(H, data, rank, n8);
     if (phase & 1) {
         const unsigned long long* src = OP == 3 ? data + (size_t)rank * n8 : data;
         for (int q = 0; q < world; ++q) {
@@ -141,6 +188,16 @@ k_peer_reduce(char* const* __restrict__ pbox, int world, int rank, size_t off_rv
             __syncthreads();
             if (threadIdx.x == 0)
                 __hip_atomic_store((unsigned long long*)hstamp, (unsigned long long)__double_as_longlong(hseq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (H.post == 1 && blockIdx.x == 0) {                     // k_precip_scalars_post (qd_physics.hip) on the reduced (num, den)
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const double a = ((const double*)data)[0], b = ((const double*)data)[1];
+                const double den = b + 1e-20;
+                H.out[0] = den > 0 ? a / den : 1.0;
+                const double pq_mean = a / (H.wsum + 1e-15);
+                H.out[1] = (H.use_fb && pq_mean < H.pq_min) ? H.p_blend : 0.0;
+            }
         }
     }
 }
@@ -189,6 +246,7 @@ static int qp_alloc(qd_ctx* c) {
         hipFree(P->d_pbox); hipFree(P->box); delete P; return qd_fail(c, "peer exchange: ticket allocation", e);
     }
     { const char* ef = std::getenv("QD_PEER_FOLD"); if (ef && ef[0] == '0') P->fold = 0; }
+    { const char* ef = std::getenv("QD_PEER_HOOKS"); if (ef && ef[0] == '0') P->hooks = 0; }
     P->overlap = world > 1 ? 2 : 0;
     { const char* ef = std::getenv("QD_PEER_OVERLAP"); if (ef) P->overlap = ef[0] == '0' ? 0 : (ef[0] == '1' ? 1 : 2); }
     P->pbox[P->rank] = P->box;
@@ -301,13 +359,15 @@ int qd_peer_halo_end(qd_ctx* c) { return qp_halo_unpack(c); }
 
 // ---- reductions
 template <int OP>
-static void qp_launch_reduce(qd_ctx* c, unsigned long long* data, int n8, int nb, int per, int par, int phase, double* hdst, double hseq) {
+static void qp_launch_reduce(qd_ctx* c, unsigned long long* data, int n8, int nb, int per, int par, int phase, double* hdst, double hseq,
+                             const QdPeerHook& H) {
     QdPeer* P = c->peer;
     hipLaunchKernelGGL(k_peer_reduce<OP>, dim3(nb), dim3(256), 0, c->stream, (char* const*)P->d_pbox, P->world, P->rank, P->off_rv,
-                       P->rv_stride, par, data, n8, per, P->rexp, phase, P->herr, P->coarse, hdst, c->hpin + 61, hseq);
+                       P->rv_stride, par, data, n8, per, P->rexp, phase, P->herr, P->coarse, hdst, c->hpin + 61, hseq, H);
 }
 
-static int qp_reduce(qd_ctx* c, unsigned long long* data, int n8, int op, double* hdst = nullptr, double hseq = 0.0) {
+static int qp_reduce(qd_ctx* c, unsigned long long* data, int n8, int op, double* hdst = nullptr, double hseq = 0.0,
+                     const QdPeerHook& H = QdPeerHook()) {
     QdPeer* P = c->peer;
     if (n8 < 1 || n8 > QP_RV) return qp_fail(c, "peer exchange: reduction longer than a mailbox slot");
     const int per = 512;                                          // 8-byte units per workgroup
@@ -316,10 +376,10 @@ static int qp_reduce(qd_ctx* c, unsigned long long* data, int n8, int op, double
     P->rseq += 1; P->rexp += (unsigned long long)nb; P->n_reduce += 1;
     auto launch = [&](int phase) {
         switch (op) {
-            case 0: qp_launch_reduce<0>(c, data, n8, nb, per, par, phase, (phase & 2) ? hdst : nullptr, hseq); break;
-            case 1: qp_launch_reduce<1>(c, data, n8, nb, per, par, phase, (phase & 2) ? hdst : nullptr, hseq); break;
-            case 2: qp_launch_reduce<2>(c, data, n8, nb, per, par, phase, nullptr, 0.0); break;
-            default: qp_launch_reduce<3>(c, data, n8, nb, per, par, phase, nullptr, 0.0); break;
+            case 0: qp_launch_reduce<0>(c, data, n8, nb, per, par, phase, (phase & 2) ? hdst : nullptr, hseq, H); break;
+            case 1: qp_launch_reduce<1>(c, data, n8, nb, per, par, phase, (phase & 2) ? hdst : nullptr, hseq, H); break;
+            case 2: qp_launch_reduce<2>(c, data, n8, nb, per, par, phase, nullptr, 0.0, H); break;
+            default: qp_launch_reduce<3>(c, data, n8, nb, per, par, phase, nullptr, 0.0, H); break;
         }
     };
     if (P->local) { launch(1); pthread_barrier_wait(&c->lgroup->bar); launch(2); }
@@ -360,6 +420,14 @@ int qd_peer_allreduce_publish(qd_ctx* c, double* dptr, int n, int op_max, double
 
 int qd_peer_allgather(qd_ctx* c, double* buf, int n_per_rank) {
     return qp_reduce(c, (unsigned long long*)buf, n_per_rank, 3);
+}
+bool qd_peer_hooks(const qd_ctx* c) { return c->peer && c->peer->on && c->peer->hooks; }
+int qd_peer_allreduce_hooked(qd_ctx* c, double* dptr, int n, int op_max, const QdPeerHook& H, double* hdst, double hseq) {
+    if (n > 256) return qp_fail(c, "peer exchange: hooked reduction longer than 256 values");
+    return qp_reduce(c, (unsigned long long*)dptr, n, op_max ? 1 : 0, hdst, hseq, H);
+}
+int qd_peer_allgather_hooked(qd_ctx* c, double* buf, int n_per_rank, const QdPeerHook& H) {
+    return qp_reduce(c, (unsigned long long*)buf, n_per_rank, 3, nullptr, 0.0, H);
 }
 
 // ---- C-ABI: one process per GPU.  Every rank exports the IPC handle of its mailbox, the host side (qingdai_amd/bands.py) hands

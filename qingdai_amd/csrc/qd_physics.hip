@@ -13,6 +13,7 @@
 //   k_advect + blur   cloud tracer advection, cos floor 0.5, sigma = 0.2 wrap (run_simulation.py:1916-1934)
 //   k_cloud_albedo    alpha-blend + ice fraction + dynamic albedo       (physics.py:164-250)
 #include "qd_internal.h"
+#include "qd_band.h"
 #include "qd_pointwise.h"
 #include "qd_device.h"
 
@@ -408,7 +409,13 @@ int qd_driver_physics_impl(qd_ctx* c, double dt, const QdForcingCall* fc, int pa
                            F[QD_F_PCOND], p.a, c->dlat, c->dlon, p.D_crit, p.p_betadiv, c->dscal + QD_S_PSCALE, c->dcount, praw,
                            pos, rp, orog);
         qd_mark(c, {praw, pos}, m);
-        if (band) {
+        if (band && qd_peer_hooks(c)) {
+            // row sums -> all-reduce -> the two scalars in ONE launch (QdPeerHook: pre 2 = k_precip_rawsums, post 1 = k_precip_scalars_post)
+            QdPeerHook H; H.pre = 2; H.partial = rp; H.n = Gown.nrows;
+            H.post = 1; H.wsum = c->wsum_all; H.pq_min = p.pq_min; H.p_blend = p.p_blend; H.use_fb = p.p_hybrid_fallback; H.out = c->dscal + QD_S_RENORM;
+            c->allreduces++;
+            if (qd_peer_allreduce_hooked(c, c->dscal + QD_S_TMP0, 2, 0, H)) return -1;
+        } else if (band) {
             hipLaunchKernelGGL(k_precip_rawsums, dim3(1), blk, 0, c->stream, rp, Gown.nrows, c->dscal + QD_S_TMP0);
             if (qd_allreduce_f64(c, c->dscal + QD_S_TMP0, 2, 0)) return -1;
             hipLaunchKernelGGL(k_precip_scalars_post, dim3(1), dim3(64), 0, c->stream, c->dscal + QD_S_TMP0, c->wsum_all, p.pq_min,

@@ -10,6 +10,7 @@
 // of the positive entries (order-isomorphic to their values), 11 bits per pass, tracking the
 // two middle ranks at once for even counts.
 #include "qd_internal.h"
+#include "qd_band.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -730,7 +731,11 @@ __device__ __forceinline__ void qd_med_final_body(unsigned long long* st, const 
     const unsigned long long k1 = (m - 1ull) / 2ull, k2 = m / 2ull;
     const bool hit = valid && !overflow && c_lo <= k1 && k2 < c_lo + (unsigned long long)M;
     if (world > 0 && !hit) { if (t == 0) *miss_flag = 1.0; return; }
-    const int src = (world > 0) ? 2 : (hit ? 0 : 1);
+    // latitude bands: the gathered segments hold M candidates in world x cap slots; when they fit, they are compacted into the LDS
+    // list first and the passes below run as on a whole-globe handle (six passes over world x cap slots of L2, a division per
+    // slot: 18.5 us for the finisher of a 1/8 band against 11 on the whole globe)
+    const bool compact = world > 0 && M <= (unsigned int)QD_MED_LDS_LIST;
+    const int src = compact ? 0 : ((world > 0) ? 2 : (hit ? 0 : 1));
     const size_t N = (src == 2) ? (size_t)world * cap : (src == 1 ? (size_t)n_field : (size_t)M);
     // leading bits shared by every value inside [lo, hi] (positive doubles order like their bit patterns)
     int common = 0;
@@ -741,7 +746,16 @@ __device__ __forceinline__ void qd_med_final_body(unsigned long long* st, const 
         pre0 = bl;
     }
     if (t == 0) { s_prefix = 0ull; s_rank = hit ? (k1 - c_lo) : k1; }
-    if (src == 0 && N <= (size_t)QD_MED_LDS_LIST) {
+    if (compact) {
+        unsigned int off = 0;
+        for (int r = 0; r < world; ++r) {
+            const double* seg = cand + (size_t)r * (cap + 4u);
+            const unsigned int cnt = (unsigned int)seg[2];               // <= cap: an overflowing segment is a miss (above)
+            for (unsigned int k = t; k < cnt; k += NT) s_list[off + k] = seg[4 + k];
+            off += cnt;
+        }
+        cand = s_list;
+    } else if (src == 0 && N <= (size_t)QD_MED_LDS_LIST) {
         for (size_t k = t; k < N; k += NT) s_list[k] = cand[k];
         cand = s_list;
     }
@@ -918,8 +932,15 @@ int qd_median_positive_dev(qd_ctx* c, const double* x, double dflt, int slot, in
         // one-workgroup scan launch in between); k_med_final resets the histogram and hands the miss flag to the host
         hipLaunchKernelGGL(k_med_scan_bracket, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, bpred, c->hist, c->sel_state,
                            seg + 4, c->sel_ccount, cap);
+        if (qd_peer_hooks(c)) {
+            // the header of my segment is written by the gathering kernel itself (QdPeerHook::pre 1 = k_med_pack)
+            QdPeerHook H; H.pre = 1; H.st = c->sel_state; H.cc = c->sel_ccount;
+            c->allreduces++;
+            if (qd_peer_allgather_hooked(c, c->med_gather, (int)segd, H)) return -1;
+        } else {
         hipLaunchKernelGGL(k_med_pack, dim3(1), dim3(64), 0, c->stream, c->sel_state, c->sel_ccount, seg);
         if (qd_allgather_f64(c, c->med_gather, (int)segd)) return -1;
+        }
         c->pub_seq += 1.0;
         hipLaunchKernelGGL(k_med_final, dim3(1), dim3(QD_FIN_BLOCK), 0, c->stream, c->sel_state, c->med_gather, c->sel_ccount, bpred, x,
                            0ull, transform, tparam, dflt, c->dscal + slot, c->dcount, world, cap, c->dscal + QD_S_TMP1, c->hist,
