@@ -64,6 +64,7 @@ struct QdPeer {
     int coarse = 0;                               // QD_PEER_COARSE=1: mailbox in ordinary device memory, full fences in the kernels
     int overlap = 0;                              // QD_PEER_OVERLAP: consumers of an exchange run their interior rows between push and unpack: 2 (default, world > 1) =
                                                   // the push rides in the interior launch itself, 1 = as a kernel of its own before it, 0 = no split
+    int one_launch = 1;                           // QD_PEER_ONE_LAUNCH=0: an exchange that is not split around a compute kernel as k_halo_push + k_halo_unpack instead of k_halo_exchange
     int hooks = 1;                                // QD_PEER_HOOKS=0: the small kernels around a reduction (k_med_pack, k_precip_rawsums, k_precip_scalars_post, k_max2_finish) stay launches of their own
     int fold = 1;                                 // QD_PEER_FOLD=0: the eta sum of a sub-step as a k_peer_reduce launch of its own
     bool pushed = false;                          // a push is out whose unpack has not been launched yet
@@ -89,6 +90,26 @@ k_halo_unpack(QdPeerHalo A, const char* my_south, const char* my_north, size_t s
     char* base = (char*)A.slab[k];
     if (dir == 0) qp_copy<false>(base, my_south + k * slab_stride, bytes, blockIdx.x, gridDim.x);                                     // my south halo <- dn's top rows
     else qp_copy<false>(base + (size_t)(A.H + A.nown) * A.nlon * esz, my_north + k * slab_stride, bytes, blockIdx.x, gridDim.x);     // my north halo <- up's bottom rows
+}
+
+// push + wait + unpack in ONE launch (rank processes / GPUs; not the in-process groups, whose kernels share hardware queues): every
+// workgroup pushes its part of its (slab, direction) segment, the last one to take a ticket publishes the exchange's number in both
+// neighbours' mailboxes, and every workgroup then waits for the neighbour's number in MY mailbox and copies the same part of the
+// staged rows into my halo.  All workgroups of the launch are resident at once (<= 32 x 32 of 256 threads), so the one that
+// publishes is never queued behind the ones that poll; the neighbours' launches do not depend on mine.
+__global__ void __launch_bounds__(256)
+k_halo_exchange(QdPeerPush J, const char* my_south, const char* my_north, const unsigned long long* flag, double* herr) {
+    qp_push_block(J, (int)blockIdx.x, (int)blockIdx.y);
+    const QdPeerHalo& A = J.A;
+    const int k = blockIdx.y >> 1, dir = blockIdx.y & 1;
+    if (threadIdx.x == 0) qp_wait(flag + dir, J.seq, herr);
+    __syncthreads();
+    qp_acquire(J.coarse);
+    const size_t esz = A.u8[k] ? 1 : sizeof(double);
+    const size_t bytes = (size_t)A.H * A.nlon * esz;
+    char* base = (char*)A.slab[k];
+    if (dir == 0) qp_copy<false>(base, my_south + k * J.slab_stride, bytes, blockIdx.x, gridDim.x);
+    else qp_copy<false>(base + (size_t)(A.H + A.nown) * A.nlon * esz, my_north + k * J.slab_stride, bytes, blockIdx.x, gridDim.x);
 }
 
 // OP 0: f64 sum in rank order, 1: f64 max, 2: u32 sum (two per 8-byte unit), 3: gather (data[q][n8] <- slot q).
@@ -247,6 +268,7 @@ static int qp_alloc(qd_ctx* c) {
     }
     { const char* ef = std::getenv("QD_PEER_FOLD"); if (ef && ef[0] == '0') P->fold = 0; }
     { const char* ef = std::getenv("QD_PEER_HOOKS"); if (ef && ef[0] == '0') P->hooks = 0; }
+    { const char* ef = std::getenv("QD_PEER_ONE_LAUNCH"); if (ef && ef[0] == '0') P->one_launch = 0; }
     P->overlap = world > 1 ? 2 : 0;
     { const char* ef = std::getenv("QD_PEER_OVERLAP"); if (ef) P->overlap = ef[0] == '0' ? 0 : (ef[0] == '1' ? 1 : 2); }
     P->pbox[P->rank] = P->box;
@@ -339,8 +361,21 @@ static int qp_halo_unpack(qd_ctx* c) {
 }
 
 int qd_peer_halo(qd_ctx* c, const QdUse* slots, int n) {
+    QdPeer* P = c->peer;
     for (int k0 = 0; k0 < n; k0 += QP_MAXSLABS) {
         const int m = std::min(QP_MAXSLABS, n - k0);
+        if (!P->local && P->one_launch) {
+            // book the exchange as a deferred push, then launch it together with its own unpack (k_halo_exchange)
+            if (qp_halo_push(c, slots + k0, m, true)) return -1;
+            const QdPeerPush& J = P->job;
+            const int par = (int)((P->hseq - 1) & 1ull);
+            const char* my_south = P->box + P->off_stage + par * P->par_stride;
+            hipLaunchKernelGGL(k_halo_exchange, dim3(J.nbx, J.nby), dim3(256), 0, c->stream, J, my_south, my_south + P->dir_stride,
+                               (const unsigned long long*)(P->box + QP_OFF_HCNT), P->herr);
+            P->job_waiting = false; P->pushed = false;
+            if (qp_check(c)) return -1;
+            continue;
+        }
         if (qp_halo_push(c, slots + k0, m, false) || qp_halo_unpack(c)) return -1;
     }
     return 0;

@@ -763,7 +763,66 @@ __device__ __forceinline__ void qd_med_final_body(unsigned long long* st, const 
     const int shifts[6] = {53, 42, 31, 20, 10, 0};
     const int widths[6] = {11, 11, 11, 11, 10, 10};
     int done = 0;
-    for (int p = 0; p < 6; ++p) {
+    // The usual case -- the ranks inside the bracket, the list in LDS -- takes digits that START at the first bit the bracket leaves
+    // open (a bracket one or two bins of 2^44 patterns wide fixes the top 19-20 bits: with the fixed digit boundaries the pass for
+    // bits 52..42 told 2-4 values apart and four more passes followed), and stops as soon as ONE candidate is left under the prefix:
+    // ~1 000 candidates spread over 2^44 patterns are alone in their 11-bit bin after the first pass, the value is then simply
+    // looked up.  Ties and crowded bins take further digits; a median of everything else takes the fixed digits below.
+    const bool lds_fast = hit && cand == s_list;
+    __shared__ unsigned int s_sel;
+    if (lds_fast) {
+        int rem = 64 - common;                                              // bits still open below the common prefix
+        if (t == 0) s_prefix = rem >= 64 ? 0ull : (rem == 0 ? pre0 : ((pre0 >> rem) << rem));
+        __syncthreads();
+        while (rem > 0) {
+            const int width = rem < 11 ? rem : 11, shift = rem - width, up = rem;
+            for (int k = t; k < QD_HIST_BINS; k += NT) sh[k] = 0u;
+            __syncthreads();
+            const unsigned long long pre = up >= 64 ? 0ull : (s_prefix >> up), r = s_rank;
+            for (size_t k = t; k < N; k += NT) {
+                const double v = cand[k];
+                if (!(v > 0.0)) continue;
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+                if (up >= 64 || (bits >> up) == pre) atomicAdd(&sh[(unsigned int)((bits >> shift) & ((1u << width) - 1u))], 1u);
+            }
+            __syncthreads();
+            constexpr int PER = QD_HIST_BINS / NT;
+            unsigned int mine = 0;
+#pragma unroll
+            for (int q = 0; q < PER; ++q) mine += sh[PER * t + q];
+            unsigned int inc = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const unsigned int y = __shfl_up(inc, o, 64); if (lane >= o) inc += y; }
+            if (lane == 63) wtot[wv] = inc;
+            __syncthreads();
+            unsigned int base = 0;
+            for (int k = 0; k < wv; ++k) base += wtot[k];
+            const unsigned long long excl = (unsigned long long)base + inc - mine;
+            if (mine > 0 && r >= excl && r < excl + mine) {
+                unsigned long long cum = excl;
+                int d = PER * t;
+                for (; d < PER * t + PER - 1; ++d) { const unsigned int hv = sh[d]; if (cum + hv > r) break; cum += hv; }
+                s_prefix = s_prefix | ((unsigned long long)d << shift);
+                s_rank = r - cum;
+                s_sel = sh[d];
+            }
+            __syncthreads();
+            rem = shift;
+            if (s_sel == 1u && rem > 0) {                                    // alone under its prefix: look the value up
+                const unsigned long long want = s_prefix >> rem;
+                __syncthreads();                                             // everybody has read s_prefix before its owner rewrites it
+                for (size_t k = t; k < N; k += NT) {
+                    const double v = cand[k];
+                    if (!(v > 0.0)) continue;
+                    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+                    if ((bits >> rem) == want) { s_prefix = bits; s_rank = 0ull; }
+                }
+                __syncthreads();
+                break;
+            }
+        }
+    }
+    for (int p = 0; p < 6 && !lds_fast; ++p) {
         const int shift = shifts[p], width = widths[p], up = shift + width;
         done += width;
         if (done <= common) {                                            // digit fixed by the bracket: take it from lo
