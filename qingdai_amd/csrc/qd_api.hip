@@ -398,6 +398,8 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
         { const char* ef = std::getenv("QD_HOIST_PRECIP"); if (ef) c->hoist_precip = ef[0] == '0' ? 0 : 1; }
         { const char* ef = std::getenv("QD_SIDE_STREAM"); if (ef) c->side_stream_on = ef[0] == '0' ? 0 : 1; }
         { const char* ef = std::getenv("QD_MERGE_FINAL"); if (ef) c->merge_final = ef[0] == '0' ? 0 : 1; }
+        { const char* ef = std::getenv("QD_MERGE_PCOND"); if (ef) c->merge_pcond = ef[0] == '0' ? 0 : 1; }
+        { const char* ef = std::getenv("QD_LAZY_DIAG"); if (ef) c->lazy_diag = ef[0] == '0' ? 0 : 1; }
         // per-workgroup CFL maxima of k_final_qnet_stress: 2 x (segments x rows) doubles
         c->n_wgmax = (int)(qd_grid2d(c->geo).x * (unsigned)c->geo.nrows);
         if ((e = hipMalloc(&c->wgmax, (size_t)2 * c->n_wgmax * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
@@ -643,6 +645,8 @@ extern "C" int qd_step_n(qd_handle c, int n, double dt, int flags, const double*
     if (with_phyto && c->phyto.S == 0) return qd_fail(c, "qd_step_n: bit6 set but qd_phyto_configure has not been called");
     if (with_eco && !with_phys) return qd_fail(c, "qd_step_n: the ecology sub-step (bit5) needs the driver physics (bit1)");
     if (with_eco && !c->eco.configured) return qd_fail(c, "qd_step_n: bit5 set but qd_eco_configure has not been called");
+    // whatever way this call ends, the per-span switches are back to what a stand-alone qd_* call expects
+    struct SpanGuard { qd_ctx* c; ~SpanGuard() { c->diag_write = 1; c->want_pcond_ahead = 0; c->pcond_ahead = 0; c->defer_final = 0; } } span_guard{c};
     for (int s = 0; s < n; ++s) {
         const double* st = stars + (size_t)7 * s;
         int rc;
@@ -652,10 +656,16 @@ extern "C" int qd_step_n(qd_handle c, int n, double dt, int flags, const double*
         // whole-globe handles: the forcing rides on the last launch of the driver physics (k_snow_albedo_forcing)
         const bool merged = with_phys && c->merge_pointwise;
         const QdForcingCall fc{st, st + 3, st[6]};
+        // lazy diagnostics: inside a span only the last step stores what nothing inside a span reads -- unless a reader comes with the flags
+        c->diag_write = (!c->lazy_diag || !c->geo.full || s == n - 1 || with_hydro || with_eco || with_phyto || want_diag) ? 1 : 0;
         if (with_phys) {
             const int part = c->precip_done ? 2 : 0;         // the precipitation block may have run inside the previous ocean step
             c->precip_done = 0;
-            if ((rc = qd_driver_physics_impl(c, dt, merged ? &fc : nullptr, part))) return rc;
+            // pass_alb: time_step follows with its P_cond median -- the last physics launch writes that P_cond (k_column<1> merged in)
+            c->want_pcond_ahead = (merged && pass_alb && c->merge_pcond) ? 1 : 0;
+            rc = qd_driver_physics_impl(c, dt, merged ? &fc : nullptr, part);
+            c->want_pcond_ahead = 0;
+            if (rc) return rc;
         }
         else if ((rc = qd_simple_albedo_impl(c, 0.08))) return rc;
         if (!merged && (rc = qd_forcing_impl(c, st, st + 3, st[6], 1))) return rc;
@@ -678,6 +688,7 @@ extern "C" int qd_step_n(qd_handle c, int n, double dt, int flags, const double*
         if (with_eco && c->eco.n_indiv > 0 && (rc = qd_indiv_substep_impl(c, dt, nullptr))) return rc;
         if (with_hydro && (rc = qd_hydrology_commit_impl(c, dt))) return rc;
     }
+    c->diag_write = 1;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return qd_fail(c, "qd_step_n: launch", e);
     return 0;

@@ -48,26 +48,13 @@ k_column(QdGeom G, QdColP P, QdColPtrs A) {
     const double T_a = 288.0 + P.ga * h;
     const double qsat_air = qd_qsat(T_a, P.p0);
 
-    double q, E, Pc, LH, LHrel;
-    {
-        // ---- humidity column: dynamics.py:282-297
-        const double fac = land ? P.s_land : ((hice > 1e-6) ? P.s_ice : P.s_ocean);
-        const double V = sqrt(u * u + v * v);
-        const double q0 = A.q[o];
-        const double deficit = qd_max(0.0, qd_qsat(Ts, P.p0) - q0);
-        E = qd_nn(P.rhoCE * V * deficit * fac);
-        LH = P.L_v * E;
-        const double q_evap = q0 + (E / P.M_col) * P.dt;
-        const double excess = qd_max(0.0, q_evap - qsat_air);
-        Pc = (excess / P.tau_c) * P.M_col;
-        double q_next = q_evap - (Pc / P.M_col) * P.dt;
-        q_next = qd_clip(qd_nn(q_next), 0.0, 0.5);
-        Pc = qd_nn(Pc);
-        LHrel = P.L_v * Pc;
-        q = qd_clip(qd_nn(q_next), 0.0, 0.5);
-        if (PHASE == 1) { A.Pcond[o] = Pc; return; }
-        A.q[o] = q; A.E[o] = E; A.Pcond[o] = Pc; A.LH[o] = LH; A.LHrel[o] = LHrel;
-    }
+    // ---- humidity column: dynamics.py:282-297 (qd_fluxes.h)
+    const QdHum Hm = qd_humidity_column(P, u, v, Ts, A.q[o], qsat_air, land, hice);
+    const double q = Hm.q, E = Hm.E, Pc = Hm.Pc, LH = Hm.LH, LHrel = Hm.LHrel;
+    if (PHASE == 1) { A.Pcond[o] = Pc; return; }
+    A.q[o] = q; A.LH[o] = LH;
+    if (PHASE != 2) A.Pcond[o] = Pc;                         // phase 2: phase 1 has stored this very value (same arithmetic on the same inputs)
+    if (P.write_diag) { A.E[o] = E; A.LHrel[o] = LHrel; }    // nobody inside a span reads these two (the hydrology commit asks for them: qd_step_n)
 
     // ---- Newton path: dynamics.py:304-322
     const double Teq = A.Teq[o];
@@ -123,10 +110,10 @@ k_column(QdGeom G, QdColP P, QdColPtrs A) {
             else Cs = P.c_sfc_safe;
             Ts_energy = qd_nn(qd_max(P.t_floor, Ts + (net / Cs) * P.dt));
         }
-        A.olr[o] = F.OLR;
+        if (P.write_diag) A.olr[o] = F.OLR;
         Ts_new = (1.0 - P.w_energy) * Ts_newton + P.w_energy * Ts_energy;
     } else {
-        A.olr[o] = olr_old;
+        if (P.write_diag) A.olr[o] = olr_old;
         Ts_new = Ts_newton;
     }
     A.Ts[o] = Ts_new;
@@ -294,6 +281,7 @@ QdColP qd_make_colp(const qd_ctx* c, double dt) {
     P.atm_couple = (p.energy_w > 0.0) ? 1 : 0;
     P.couple = p.cloud_couple; P.lw_v2 = p.lw_v2; P.gh_lock = p.gh_lock; P.seaice = p.seaice_enabled;
     P.fix_s = p.polar_freeze_fix_s; P.fix_n = p.polar_freeze_fix_n; P.has_csmap = p.has_csmap;
+    P.write_diag = c->diag_write;
     return P;
 }
 
@@ -332,7 +320,9 @@ int qd_atmos_step_impl(qd_ctx* c, double dt, int has_albedo) {
                                qd_isset(p.pcond_ref) ? p.pcond_ref : 1e-6);
             QD_ROWS(c, m, G, hipLaunchKernelGGL((k_column<0, true>), qd_grid2d(G), blk, 0, c->stream, G, P, A));
         } else {
-            QD_ROWS(c, m, G, hipLaunchKernelGGL((k_column<1, true>), qd_grid2d(G), blk, 0, c->stream, G, P, A));
+            // (whole-globe qd_step_n: the last launch of the driver physics has written this step's P_cond already: k_snow_albedo_forcing)
+            if (c->pcond_ahead) c->pcond_ahead = 0;
+            else QD_ROWS(c, m, G, hipLaunchKernelGGL((k_column<1, true>), qd_grid2d(G), blk, 0, c->stream, G, P, A));
             if (qd_median_positive_dev(c, F[QD_F_PCOND], 1e-6, QD_S_PREF, 0, 0.0, 1)) return -1;
             QD_ROWS(c, m, G, hipLaunchKernelGGL((k_column<2, true>), qd_grid2d(G), blk, 0, c->stream, G, P, A));
         }

@@ -16,6 +16,7 @@ struct QdColP {           // scalars of the column kernel, all derived on the ho
     double t_freeze, rhoiLf, rho_i, L_f, Cs_ocean, Cs_land, Cs_ice, t_floor;
     double w_energy, h_eq_fac, tau_rad, atm_denom, atm_w;
     int couple, lw_v2, gh_lock, seaice, fix_s, fix_n, has_csmap, atm_couple;
+    int write_diag = 1;   // 0: a step inside a qd_step_n span -- E, LH_release and OLR, which nothing inside a span reads, are not stored
 };
 
 __device__ __forceinline__ double qd_qsat(double T, double p0) {        // humidity.py:85-101
@@ -23,6 +24,29 @@ __device__ __forceinline__ double qd_qsat(double T, double p0) {        // humid
     const double e_s = 610.94 * exp(17.625 * T_c / (T_c + 243.04));
     const double denom = qd_max(p0 - (1.0 - QD_EPSILON) * e_s, 1.0);
     return qd_clip(QD_EPSILON * e_s / denom, 0.0, 0.5);
+}
+
+// humidity column (dynamics.py:282-297, humidity.py:104-183): evaporation, condensation of the excess over saturation, the new q.
+// One body for k_column (qd_atmos.hip, all phases) and for the P_cond that k_snow_albedo_forcing (qd_physics.hip) writes ahead of
+// time_step's median when it stands in for phase 1.
+struct QdHum { double q, E, Pc, LH, LHrel; };
+__device__ __forceinline__ QdHum qd_humidity_column(const QdColP& P, double u, double v, double Ts, double q0, double qsat_air,
+                                                    bool land, double hice) {
+    QdHum r;
+    const double fac = land ? P.s_land : ((hice > 1e-6) ? P.s_ice : P.s_ocean);
+    const double V = sqrt(u * u + v * v);
+    const double deficit = qd_max(0.0, qd_qsat(Ts, P.p0) - q0);
+    r.E = qd_nn(P.rhoCE * V * deficit * fac);
+    r.LH = P.L_v * r.E;
+    const double q_evap = q0 + (r.E / P.M_col) * P.dt;
+    const double excess = qd_max(0.0, q_evap - qsat_air);
+    double Pc = (excess / P.tau_c) * P.M_col;
+    double q_next = q_evap - (Pc / P.M_col) * P.dt;
+    q_next = qd_clip(qd_nn(q_next), 0.0, 0.5);
+    r.Pc = qd_nn(Pc);
+    r.LHrel = P.L_v * r.Pc;
+    r.q = qd_clip(qd_nn(q_next), 0.0, 0.5);
+    return r;
 }
 
 // Surface fluxes shared by the energy branch of time_step and by the ocean coupling of the

@@ -221,6 +221,15 @@ struct qd_ctx {
     // whole-globe qd_step_n: time_step's last kernel (k_final: cloud gather + damp + scrub) is not launched by qd_atmos_step_impl but
     // left here for the ocean step, whose first launch does it together with the wind stress, the CFL row maxima and Q_net
     // (k_final_qnet_stress: the three were 17 + 12 + 15 us and read each other's u, v, T_s, h again)
+    // lazy diagnostics (QD_LAZY_DIAG, default 1): inside a qd_step_n span only the LAST step stores the fields that nothing inside a span
+    // reads (P_rain, S_next, melt, C_snow, glacier, isr_A, isr_B, E, LH_release, OLR: 83 MB per step at 721 x 1440) -- unless the span's
+    // flags bring a reader (hydrology commit, ecology, tracers).  diag_write is what the kernels see.
+    int lazy_diag = 1, diag_write = 1;
+    // whole-globe qd_step_n: k_snow_albedo_forcing (the driver physics' last launch) also computes P_cond = phase 1 of the column
+    // (it reads h, h_ice, land anyway; k_column<1> was a launch of 14 us that read them again), time_step then starts with the median
+    int merge_pcond = 1;             // QD_MERGE_PCOND=0: k_column<1> stays a launch of its own
+    int want_pcond_ahead = 0;        // set by qd_step_n around the driver physics
+    int pcond_ahead = 0;             // the physics launch did write it: qd_atmos_step_impl skips k_column<1>
     int defer_final = 0;             // set by qd_step_n around qd_atmos_step_impl
     int merge_final = 1;             // QD_MERGE_FINAL=0: keep the three launches
     struct { int on = 0; double dt = 0, decay = 0, dfac = 0; } final_pending;

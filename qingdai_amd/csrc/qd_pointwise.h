@@ -92,7 +92,8 @@ __device__ __forceinline__ void qd_forcing_cell(const QdTabs& T, const QdForcing
     const double czB = qd_max(0.0, sl * P.B.sin_d + cl * P.B.cos_d * cos(hB));
     const double a_ = P.A.flux * czA, b_ = P.B.flux * czB;
     const double tot = a_ + b_;
-    isrA[o] = a_; isrB[o] = b_; isr[o] = tot;
+    if (isrA) { isrA[o] = a_; isrB[o] = b_; }                  // nullptr: a step inside a span whose per-star fluxes nobody reads (lazy diagnostics)
+    isr[o] = tot;
     if (eday) eday[o] += qd_nn(tot) * eday_dt;                 // PopulationManager.step_subdaily (population.py:267-268)
     if (P.with_teq) {
         double num = tot * (1 - alb);

@@ -558,6 +558,44 @@ def test_step_n_precipitation_block_inside_the_ocean_step_changes_nothing(gpu, m
         assert np.array_equal(s3[k], b[k], equal_nan=True), k
 
 
+def test_lazy_diagnostics_and_the_merged_pcond_launch_change_nothing_at_the_end_of_a_span(gpu, monkeypatch):
+    """Inside a qd_step_n span only the LAST step stores the fields nothing inside a span reads (P_rain, S_next, melt, C_snow, glacier,
+    isr_A, isr_B, E, LH_release, OLR: QD_LAZY_DIAG), and the driver physics' last launch writes time_step's phase-1 P_cond
+    (QD_MERGE_PCOND: k_column<1> is no launch of its own).  After spans of 5, 1 and 3 steps EVERY field -- the lazily stored ones
+    included -- must equal the eager, unmerged run bit for bit (run_simulation.py:1946-2019, dynamics.py:282-353)."""
+    from qingdai_amd.device import Device
+    from test_gpu_bands import _setup, _seed_state
+    names = ("U", "V", "H", "TS", "Q", "CLOUD", "HICE", "ISR", "ISR_A", "ISR_B", "TEQ", "ALBEDO", "OLR", "EFLUX", "PCOND", "LH", "LHREL",
+             "CLOUD_EFF", "UO", "VO", "ETA", "SST", "QNET", "PRECIP", "C_SNOW", "S_SNOW_NEXT", "MELT", "P_RAIN", "GLACIER")
+    nlat, nlon = 91, 180
+    qa, grid, mask, alb, fric, p = _setup(nlat, nlon, dict(energy_w=1.0))
+    forcing = qa.ThermalForcing(qa.SphericalGrid(nlat, nlon), qa.OrbitalSystem())
+    st = _seed_state(nlat, nlon, 5)
+    static = {"LAND_MASK": mask, "FRICTION": fric, "BASE_ALBEDO": alb}
+
+    def run(lazy, merge):
+        # the flags of bench.py's span (ocean + driver physics + albedo handed to time_step, no hydrology commit): the ones both
+        # switches act on
+        monkeypatch.setenv("QD_LAZY_DIAG", lazy)
+        monkeypatch.setenv("QD_MERGE_PCOND", merge)
+        dev = Device(grid, p)
+        for k, v in {**static, **st}.items():
+            dev.upload_now(k, v)
+        t = 0.0
+        for n in (5, 1, 3):
+            stars = forcing.star_table([t + i * 300.0 for i in range(n)])
+            dev.step_n(stars, 300.0, with_ocean=True, with_physics=True, pass_albedo=True)
+            t += 300.0 * n
+        out = {k: np.array(dev.get(k)) for k in names}
+        dev.close()
+        return out
+    ref = run("0", "0")
+    for lazy, merge in (("1", "1"), ("1", "0"), ("0", "1")):
+        got = run(lazy, merge)
+        for k in names:
+            assert np.array_equal(got[k], ref[k], equal_nan=True), (lazy, merge, k)
+
+
 def test_cloud_source_propagates_nan_like_the_reference(gpu):
     """parameterize_cloud_cover (physics.py:72-114) on a state with a NaN surface temperature and a NaN wind cell:
     np.clip(np.tanh(nan), 0, 1) is nan, so the poisoned cells -- and what the sigma = 1 blur spreads them to -- must be NaN in
