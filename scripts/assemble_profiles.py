@@ -34,8 +34,11 @@ def main():
     cells = nlat * nlon
     # calibration kernel with a known byte count: k_qnet reads nine f64 fields + the land mask and writes one f64 field + the ice mask
     # (round 2 used k_precip_blend, which round 3 merged into k_gauss_pair)
-    cal = "k_qnet" if "k_qnet" in f else "k_precip_blend"
-    cal_rd, cal_wr = ((9 * 8 + 1) * cells, 9 * cells) if cal == "k_qnet" else (2 * cells * 8, cells * 8)
+    # (round 4: k_qnet is part of k_final_qnet_stress in the bench's span -- 13 f64 fields read, one of them through a bilinear gather
+    #  that stays within a row or two, + the land mask; 9 f64 fields + the ice mask written: known to a few per cent)
+    cal = "k_qnet" if "k_qnet" in f else ("k_final_qnet_stress" if "k_final_qnet_stress" in f else "k_precip_blend")
+    cal_rd, cal_wr = {"k_qnet": ((9 * 8 + 1) * cells, 9 * cells), "k_final_qnet_stress": ((13 * 8 + 1) * cells, (9 * 8 + 1) * cells),
+                      "k_precip_blend": (2 * cells * 8, cells * 8)}[cal]
     traffic = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, no stats/sys-trace; scripts/profile_round.sh) "
                        "of `bench.py --no-cpu-baseline --no-ecology-leg --steps 12 --warmup 4`; mean per dispatch, counters in KiB.  Correction per "
                        "MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half the bytes of a coalesced streaming read -> x2, re-calibrated on "
