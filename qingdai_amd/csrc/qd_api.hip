@@ -379,6 +379,12 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
     hipMemsetAsync(c->dcount, 0, 32 * sizeof(unsigned long long), c->stream);
     hipMemsetAsync(c->hist, 0, 2 * QD_HIST_BINS * sizeof(unsigned int), c->stream);
     hipMemsetAsync(c->sel_state, 0, 8 * sizeof(unsigned long long), c->stream);
+    { const char* ef = std::getenv("QD_TAIL_FIX"); if (ef) c->tail_fix = ef[0] == '0' ? 0 : 1; }
+    if (c->tail_fix) {                                        // list of the cells whose currents the ocean tail kernel changes (qd_ocntail.h)
+        if ((e = hipMalloc(&c->fix_count, 64)) != hipSuccess) return bail("hipMalloc", e);
+        hipMemsetAsync(c->fix_count, 0, 64, c->stream);
+        if ((e = hipMalloc(&c->fix_list, c->geo.cells() * 3 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+    }
     if (!full) {
         if ((e = hipMalloc(&c->med_pred, 64 * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
         hipMemsetAsync(c->med_pred, 0, 64 * sizeof(double), c->stream);
@@ -399,6 +405,7 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
         { const char* ef = std::getenv("QD_SIDE_STREAM"); if (ef) c->side_stream_on = ef[0] == '0' ? 0 : 1; }
         { const char* ef = std::getenv("QD_MERGE_FINAL"); if (ef) c->merge_final = ef[0] == '0' ? 0 : 1; }
         { const char* ef = std::getenv("QD_MERGE_PCOND"); if (ef) c->merge_pcond = ef[0] == '0' ? 0 : 1; }
+
         { const char* ef = std::getenv("QD_LAZY_DIAG"); if (ef) c->lazy_diag = ef[0] == '0' ? 0 : 1; }
         // per-workgroup CFL maxima of k_final_qnet_stress: 2 x (segments x rows) doubles
         c->n_wgmax = (int)(qd_grid2d(c->geo).x * (unsigned)c->geo.nrows);
@@ -450,6 +457,7 @@ extern "C" int qd_destroy(qd_handle c) {
     if (c->red_partial) hipFree(c->red_partial); if (c->dscal) hipFree(c->dscal);
     if (c->red_partial_b) hipFree(c->red_partial_b);
     if (c->wgmax) hipFree(c->wgmax);
+    if (c->fix_count) hipFree(c->fix_count); if (c->fix_list) hipFree(c->fix_list);
     if (c->side_stream) { hipStreamSynchronize(c->side_stream); hipStreamDestroy(c->side_stream); }
     if (c->side_fork) hipEventDestroy(c->side_fork); if (c->side_done) hipEventDestroy(c->side_done);
     if (c->eta_acc) hipFree(c->eta_acc);

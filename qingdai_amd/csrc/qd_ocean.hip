@@ -1063,6 +1063,8 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
                 // peer exchange: the finishing wave of the owned segment's launch all-reduces the band's share itself (no launch)
                 QdPeerFold pf;
                 const bool folded = qd_peer_fold_begin(c, &pf);
+                // one launch that covers the band and has the finishing wave: uo'' / vo'' in place through the fix list, like the whole globe
+                if (c->tail_fix && c->fix_count && S.n == 1) { A.fix_count = c->fix_count; A.fix_list = c->fix_list; }
                 for (int k = 0; k < S.n; ++k) {
                     const QdGeom& Gs = S.g[k];
                     const bool owned = Gs.row0 <= c->own_row0 && c->own_row0 < Gs.row0 + Gs.nrows;      // the segment that holds the band's own rows
@@ -1074,14 +1076,18 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
                 }
                 // first read by the NEXT momentum kernel: if that kernel's inputs need a halo exchange, the sum rides in its group
                 if (!folded && qd_allreduce_sum_deferred(c, c->dscal + QD_S_ETA_MEAN)) return -1;
-                qd_mark(c, {F[QD_F_ETA], A.Ts_out, A.uo_out, A.vo_out}, m);
+                if (A.fix_count) qd_mark(c, {F[QD_F_ETA], A.Ts_out, F[QD_F_UO], F[QD_F_VO]}, m);
+                else qd_mark(c, {F[QD_F_ETA], A.Ts_out, A.uo_out, A.vo_out}, m);
             } else {
+            // uo'' / vo'' in place through the fix list (the launcher drops it when the kernel it picks has no finishing wave)
+            if (c->tail_fix && c->fix_count) { A.fix_count = c->fix_count; A.fix_list = c->fix_list; }
             if (qd_launch_ocn_tail(c, Gown, A)) return -1;
             if (!tail_acc)
                 hipLaunchKernelGGL(k_eta_mean_tail, dim3(1), dim3(256), 0, c->stream, c->red_partial, qd_ocn_tail_tiles(c, Gown), c->wsum_ocean,
                                    c->dscal + QD_S_ETA_MEAN);
             }
-            qd_swap(c, QD_F_SST, 1); qd_swap(c, QD_F_UO, 2); qd_swap(c, QD_F_VO, 3);
+            qd_swap(c, QD_F_SST, 1);
+            if (!A.fix_count) { qd_swap(c, QD_F_UO, 2); qd_swap(c, QD_F_VO, 3); }
         } else if (c->use_fused) {
             QdScope sc(c, "ocean_cont_sst");
             bool band_raw_mean = false;

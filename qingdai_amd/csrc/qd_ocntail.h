@@ -17,6 +17,11 @@ struct QdTailArgs {
     int nmid, flags;                                         // k_ocn_tail_fast: strips between the pole strips; bit0 = every wave takes the general form
     int own0, own1;                                          // rows whose eta enters the area-weighted sum (a band's owned rows; set by the launcher for whole-globe handles)
     const double* eta_in = nullptr;                          // k_ocn_fused, sequential form: eta' comes from this slab, the new eta goes to `eta` (nullptr: `eta` in place)
+    // whole-globe k_ocn_tail_fast: nan_to_num and the speed cap leave all but a handful of cells of uo', vo' as they are, so uo'' / vo''
+    // are NOT stored (2 x 8.3 MB per sub-step at 721 x 1440): a cell whose value changes is noted in a list -- {byte offset in the slab,
+    // u bits, v bits} -- and the launch's finishing wave, which runs when every wave of every strip is done, patches uo', vo' in place
+    unsigned int* fix_count = nullptr;
+    unsigned long long* fix_list = nullptr;
     QdPeerFold pf;                                           // latitude bands over the peer exchange: the finishing wave all-reduces the band's share itself (qd_peer_dev.h)
 };
 

@@ -109,6 +109,24 @@ __device__ __forceinline__ double qt_ld(qt_rsrc r, unsigned row_elems, unsigned 
 __device__ __forceinline__ void qt_st(qt_rsrc r, unsigned row_elems, unsigned vo, double v) { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(qt_u32x2, v), r, vo, row_elems * 8u, 0); }
 __device__ __forceinline__ int qt_ld8(qt_rsrc r, unsigned row_elems, unsigned vo8) { return (int)__builtin_amdgcn_raw_buffer_load_b8(r, vo8, row_elems, 0); }
 
+// uo'' / vo'' of one cell: stored -- or, with a fix list (QdTailArgs::fix_count), only noted when they differ from the uo' / vo' (uc, vc)
+// the cell holds; bit patterns are compared, so a NaN that nan_to_num turned into 0 counts as changed
+__device__ __forceinline__ void qt_put_uv(unsigned int* fixc, unsigned long long* fixl, qt_rsrc UO, qt_rsrc VO, unsigned row_elems, unsigned vs,
+                                          double u, double v, double uc, double vc) {
+    if (!fixc) { qt_st(UO, row_elems, vs, u); qt_st(VO, row_elems, vs, v); return; }
+    const unsigned long long ub = (unsigned long long)__double_as_longlong(u), vb = (unsigned long long)__double_as_longlong(v);
+    const bool ch = vs != 0x80000000u && (ub != (unsigned long long)__double_as_longlong(uc) || vb != (unsigned long long)__double_as_longlong(vc));
+    if (__builtin_amdgcn_ballot_w64(ch) != 0ull) {
+        if (ch) {
+            const unsigned k = __hip_atomic_fetch_add(fixc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long* e = fixl + (size_t)3 * k;
+            __hip_atomic_store(e, (unsigned long long)row_elems * 8ull + (unsigned long long)vs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(e + 1, ub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(e + 2, vb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 struct QtW { int n, m, lane, j, o0, o1; unsigned vo, vs, vo8, slab; bool own; int lbase, lrows, own0, own1, jbase; };      // lbase / lrows: the slab (band handles); own0 / own1: rows whose eta enters the sum
 
 // element offset of global row g, clamped into the domain and into the slab (whole-globe handles: local row = global row; band
@@ -173,7 +191,7 @@ __device__ __forceinline__ double qt_currents_wave(const QdTabs& T, const QdTail
                 u = u * sc; v = v * sc;
             }
         }
-        qt_st(UO, r0, W.vs, u); qt_st(VO, r0, W.vs, v);
+        qt_put_uv(P.fix_count, P.fix_list, UO, VO, r0, W.vs, u, v, uc, vc);
         us = uc; uc = un; vs = vc; vc = vn;
     }
     return acc;
@@ -406,7 +424,7 @@ __device__ __forceinline__ void qfu_wait_gt(const int* p, int row) {          //
 __device__ __forceinline__ double qfu_ring_ld(const double* plane, int row, int lane) { return plane[(row & (QFU_NR - 1)) * 64 + lane]; }
 
 struct QtCurSlot { double u, v, e; int l; qt_f64x2 k0, k1; };
-struct QtCurK { double dlon2, r_2dlon, dlat2, r_2dlat, msdtH, cap, cap81; int mean4; };
+struct QtCurK { double dlon2, r_2dlon, dlat2, r_2dlat, msdtH, cap, cap81; int mean4; unsigned int* fixc = nullptr; unsigned long long* fixl = nullptr; };
 
 // one row of the continuity + caps wave away from the poles; `ro`: element offset of row g in the slab
 // RING: u, v of row g + 1 and eta of row g come from the LDS ring of k_ocn_fused (R), everything else as before
@@ -447,7 +465,7 @@ __device__ __forceinline__ void qt_cur_fast_step(const QtCurK& P, const QtW& W, 
             u = u * sc; v = v * sc;
         }
     }
-    qt_st(UO, ro, W.vs, u); qt_st(VO, ro, W.vs, v);
+    qt_put_uv(P.fixc, P.fixl, UO, VO, ro, W.vs, u, v, uc, vc);
     us = uc; uc = un; vs = vc; vc = vn;
     if (RING) { if (W.lane == 0) __hip_atomic_store(R->prog + 3, g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }     // rows <= g are done with
     __builtin_amdgcn_sched_barrier(0);
@@ -469,6 +487,7 @@ __device__ __forceinline__ double qt_currents_fast(const QdTailArgs& P, const Qt
     QtCurK K;
     K.dlon2 = qt_vreg(2 * P.dlon); K.r_2dlon = qt_vreg(P.r_2dlon); K.dlat2 = qt_vreg(2 * P.dlat); K.r_2dlat = qt_vreg(P.r_2dlat);
     K.msdtH = qt_vreg(P.msdtH); K.cap = qt_vreg(P.cap); K.cap81 = qt_vreg(0.81 * (P.cap * P.cap)); K.mean4 = P.mean4;
+    K.fixc = P.fix_count; K.fixl = P.fix_list;
     QtCurSlot a, b;
     a.u = qt_ld(U, ro + m, W.vo); a.v = qt_ld(V, ro + m, W.vo); a.e = qt_ld(E, ro, W.vo); a.l = qt_ld8(L, ro, W.vo8);
     a.k0 = qt_ldk(KT, 16u * (unsigned)W.o0, 4u); a.k1 = qt_ldk(KT, 16u * (unsigned)W.o0, 5u);
@@ -645,10 +664,13 @@ k_ocn_tail_fast(QdGeom G, QdTabs T, QdTailArgs P) {
         }
         if (general) qt_sst_wave(G, T, P, W);
         QT_STAMP(2);
+        if (!P.fix_count) return;
+        __syncthreads();                                     // fix list: this strip's ticket is taken when BOTH its waves have read their uo', vo'
         return;
     }
     double acc = (plain && W.o0 >= 1 && W.o1 <= W.n - 1) ? qt_currents_fast(P, W) : qt_currents_wave(T, P, W);
     QT_STAMP(2);
+    if (P.fix_count) __syncthreads();
     acc = qt_wave_sum(acc);
     if (W.lane == 0) __hip_atomic_store(P.partial + w, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // coherent: the finisher may read it
     if (P.acc) {                                             // eta mean inside this launch: the last workgroup to arrive finishes it
@@ -657,6 +679,18 @@ k_ocn_tail_fast(QdGeom G, QdTabs T, QdTailArgs P) {
             double mm = qd_acc_finish(P.acc, P.partial, (int)gridDim.x, P.wsum);
             if (P.pf.pbox) mm = qp_fold_sum(P.pf, mm);        // bands over the peer exchange: the sum over the ranks, here and now
             if (W.lane == 0) *P.mean_out = mm;
+            if (P.fix_count) {
+                // every wave of the launch is done with uo', vo': the noted cells get their uo'' / vo'' in place (entries and count were
+                // written with agent-scope atomics before their strips' tickets: qd_acc_arrive waits for them)
+                const unsigned nfix = __hip_atomic_load(P.fix_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (unsigned k = (unsigned)W.lane; k < nfix; k += 64u) {
+                    const unsigned long long* e = P.fix_list + (size_t)3 * k;
+                    const unsigned long long off = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    *(unsigned long long*)((char*)const_cast<double*>(P.uo) + off) = __hip_atomic_load(e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    *(unsigned long long*)((char*)const_cast<double*>(P.vo) + off) = __hip_atomic_load(e + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (W.lane == 0) __hip_atomic_store(P.fix_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
@@ -1009,6 +1043,7 @@ int qd_launch_ocn_tail(qd_ctx* c, const QdGeom& G, QdTailArgs& P) {
     if (!stamps) { hipMalloc(&stamps, stamp_words * 8); hipMemcpyToSymbol(HIP_SYMBOL(qt_stamp_buf), &stamps, sizeof(stamps)); }
     hipMemsetAsync(stamps, 0, stamp_words * 8, c->stream);
 #endif
+    if (!fast || !P.acc) { P.fix_count = nullptr; P.fix_list = nullptr; }          // the fix list is applied by k_ocn_tail_fast's finishing wave
     if (fast) QD_LAUNCH_TIMED(sc, k_ocn_tail_fast, dim3(nrs * P.ntc), dim3(128), c->stream, G, c->tabs, P);
     else QD_LAUNCH_TIMED(sc, k_ocn_tail_stream<1>, dim3(nrs * P.ntc), dim3(128), c->stream, G, c->tabs, P);
 #ifdef QT_STAMPS

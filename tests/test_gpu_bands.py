@@ -151,6 +151,34 @@ def test_ocean_tail_kernel_matches_the_two_launch_form(gpu, shape, tail, monkeyp
         assert e < TAIL_TOL, (k, e)
 
 
+@pytest.mark.parametrize("shape", [(181, 360), (64, 97)])
+def test_currents_patched_in_place_equal_the_stored_ones(gpu, shape, monkeypatch):
+    """k_ocn_tail_fast on a whole-globe handle does not store uo'' / vo'' (ocean.py:409-434: nan_to_num + outlier filter + speed cap leave
+    almost every cell as the momentum kernel wrote it): cells that do change are noted in a list and patched in place by the launch's
+    finishing wave (QD_TAIL_FIX, default on).  Bit for bit the slabs of the storing form (QD_TAIL_FIX=0) -- with calm currents (an empty
+    list), with isolated spikes and NaN (a few entries, the 4-neighbour mean reading the UNPATCHED neighbours), and with every
+    twentieth ocean cell far above the cap (thousands of entries per launch, every strip contributing)."""
+    nlat, nlon = shape
+
+    def spikes(st):
+        st["UO"] = np.zeros((nlat, nlon)); st["VO"] = np.zeros((nlat, nlon))
+        st["UO"][nlat // 2, 0] = 1e6; st["VO"][nlat // 3, nlon - 1] = -2e6; st["UO"][nlat // 2 + 9, nlon // 2] = np.nan
+
+    def storm(st):
+        r = np.random.default_rng(11)
+        hit = r.random((nlat, nlon)) < 0.05
+        st["UO"] = np.where(hit, r.normal(0, 40.0, (nlat, nlon)), 0.01 * r.normal(0, 1, (nlat, nlon)))
+        st["VO"] = np.where(hit, r.normal(0, 40.0, (nlat, nlon)), 0.01 * r.normal(0, 1, (nlat, nlon)))
+    over = dict(energy_w=1.0, ocean_cfl=0.05)
+    for mutate in (None, spikes, storm):
+        monkeypatch.setenv("QD_TAIL_FIX", "0")
+        stored, _ = _run(1, nlat, nlon, 2, over, True, True, mutate=mutate)
+        monkeypatch.setenv("QD_TAIL_FIX", "1")
+        patched, _ = _run(1, nlat, nlon, 2, over, True, True, mutate=mutate)
+        for k in stored:
+            assert np.array_equal(patched[k], stored[k], equal_nan=True), (k, mutate.__name__ if mutate else None)
+
+
 @pytest.mark.parametrize("shape", [(181, 360), (91, 144), (64, 97), (121, 240)])
 def test_fast_tail_waves_equal_the_general_ones_bit_for_bit(gpu, shape, monkeypatch):
     """k_ocn_tail_fast: strips away from the poles run slim waves (two-slot streams, the SST gather taken from the nine cells
