@@ -380,6 +380,7 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
     hipMemsetAsync(c->hist, 0, 2 * QD_HIST_BINS * sizeof(unsigned int), c->stream);
     hipMemsetAsync(c->sel_state, 0, 8 * sizeof(unsigned long long), c->stream);
     { const char* ef = std::getenv("QD_TAIL_FIX"); if (ef) c->tail_fix = ef[0] == '0' ? 0 : 1; }
+    { const char* ef = std::getenv("QD_LAZY_DIAG"); if (ef) c->lazy_diag = ef[0] == '0' ? 0 : 1; }
     if (c->tail_fix) {                                        // list of the cells whose currents the ocean tail kernel changes (qd_ocntail.h)
         if ((e = hipMalloc(&c->fix_count, 64)) != hipSuccess) return bail("hipMalloc", e);
         hipMemsetAsync(c->fix_count, 0, 64, c->stream);
@@ -406,7 +407,7 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
         { const char* ef = std::getenv("QD_MERGE_FINAL"); if (ef) c->merge_final = ef[0] == '0' ? 0 : 1; }
         { const char* ef = std::getenv("QD_MERGE_PCOND"); if (ef) c->merge_pcond = ef[0] == '0' ? 0 : 1; }
 
-        { const char* ef = std::getenv("QD_LAZY_DIAG"); if (ef) c->lazy_diag = ef[0] == '0' ? 0 : 1; }
+
         // per-workgroup CFL maxima of k_final_qnet_stress: 2 x (segments x rows) doubles
         c->n_wgmax = (int)(qd_grid2d(c->geo).x * (unsigned)c->geo.nrows);
         if ((e = hipMalloc(&c->wgmax, (size_t)2 * c->n_wgmax * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
@@ -665,7 +666,7 @@ extern "C" int qd_step_n(qd_handle c, int n, double dt, int flags, const double*
         const bool merged = with_phys && c->merge_pointwise;
         const QdForcingCall fc{st, st + 3, st[6]};
         // lazy diagnostics: inside a span only the last step stores what nothing inside a span reads -- unless a reader comes with the flags
-        c->diag_write = (!c->lazy_diag || !c->geo.full || s == n - 1 || with_hydro || with_eco || with_phyto || want_diag) ? 1 : 0;
+        c->diag_write = (!c->lazy_diag || s == n - 1 || with_hydro || with_eco || with_phyto || want_diag) ? 1 : 0;
         if (with_phys) {
             const int part = c->precip_done ? 2 : 0;         // the precipitation block may have run inside the previous ocean step
             c->precip_done = 0;

@@ -102,7 +102,7 @@ k_column(QdGeom G, QdColP P, QdColPtrs A) {
             if (hi > 0.0 && ocean) Tn = qd_min(Tn, P.t_freeze);
             Tn = qd_max(P.t_floor, Tn);
             Ts_energy = qd_nn(Tn);
-            A.hice[o] = qd_nn(hi);
+            { const double hn_ = qd_nn(hi); if (__double_as_longlong(hn_) != __double_as_longlong(hice)) A.hice[o] = hn_; }    // ice-free and land cells: unchanged
         } else {
             const double net = F.SW_sfc - F.LW_sfc - F.SH - LH;
             double Cs;

@@ -202,8 +202,10 @@ k_final_qnet_stress(QdGeom G, QdColP P, QdFqsArgs A) {
         double c = qd_gather(A.cloud_in, G, b);
         c = c * A.decay;
         const double cn = qd_nn(c * A.dfac), un = qd_nn(uu * A.dfac), vn = qd_nn(vv * A.dfac);
-        const double hn = qd_nn(A.h[o] * A.dfac), tn = qd_nn(A.Ts[o]);
-        A.cloud_out[o] = cn; A.u[o] = un; A.v[o] = vn; A.h[o] = hn; A.q[o] = qd_nn(A.q[o] * A.dfac); A.Ts[o] = tn;
+        const double t0 = A.Ts[o];
+        const double hn = qd_nn(A.h[o] * A.dfac), tn = qd_nn(t0);
+        A.cloud_out[o] = cn; A.u[o] = un; A.v[o] = vn; A.h[o] = hn; A.q[o] = qd_nn(A.q[o] * A.dfac);
+        if (__double_as_longlong(tn) != __double_as_longlong(t0)) A.Ts[o] = tn;                  // nan_to_num of a finite T_s: the bits that are there
         // ---- k_stress_max
         const double u_o = A.uo[o], v_o = A.vo[o];
         const double u_rel = un - u_o, v_rel = vn - v_o;
@@ -622,8 +624,9 @@ __device__ __forceinline__ void qd_sst_clamp_cell(size_t o, double* __restrict__
                                                   double eta_cap) {
     // the deferred eta update of the LAST sub-step (nobody loads eta through the momentum kernel afterwards)
     if (eta) eta[o] = qd_clip(qd_nn(eta[o] - *eta_mean), -eta_cap, eta_cap);
-    const double t = qd_clip(sst[o], tmin, tmax);
-    sst[o] = t;
+    const double t0 = sst[o];
+    const double t = qd_clip(t0, tmin, tmax);
+    if (__double_as_longlong(t) != __double_as_longlong(t0)) sst[o] = t;      // (a store of the bits that are there already costs what any store costs)
     // gcm.T_s = where(ocean & ~ice, ocean.Ts, gcm.T_s)    run_simulation.py:2252-2253
     if (inject && land[o] == 0 && !(has_ice && ice[o] != 0)) Ts_atm[o] = t;
 }
