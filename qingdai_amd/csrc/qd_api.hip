@@ -411,8 +411,20 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
         // per-workgroup CFL maxima of k_final_qnet_stress: 2 x (segments x rows) doubles
         c->n_wgmax = (int)(qd_grid2d(c->geo).x * (unsigned)c->geo.nrows);
         if ((e = hipMalloc(&c->wgmax, (size_t)2 * c->n_wgmax * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
+        { const char* ef = std::getenv("QD_MED_SIDE"); if (ef) c->med_side = ef[0] == '0' ? 0 : 1; }
+        if (c->med_side) {
+            if ((e = hipEventCreateWithFlags(&c->med_fork, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+            if ((e = hipEventCreateWithFlags(&c->med_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+            if ((e = hipMalloc(&c->hist_b, 2 * QD_HIST_BINS * sizeof(unsigned int))) != hipSuccess) return bail("hipMalloc", e);
+            if ((e = hipMalloc(&c->sel_state_b, 8 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+            if ((e = hipMalloc(&c->sel_cand_b, 2 * cells * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
+            if ((e = hipMalloc(&c->sel_ccount_b, 2 * sizeof(unsigned int))) != hipSuccess) return bail("hipMalloc", e);
+            hipMemsetAsync(c->hist_b, 0, 2 * QD_HIST_BINS * sizeof(unsigned int), c->stream);
+            hipMemsetAsync(c->sel_state_b, 0, 8 * sizeof(unsigned long long), c->stream);
+            hipMemsetAsync(c->sel_ccount_b, 0, 2 * sizeof(unsigned int), c->stream);
+        }
+        if ((c->side_stream_on || c->med_side) && (e = hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
         if (c->side_stream_on) {
-            if ((e = hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
             if ((e = hipEventCreateWithFlags(&c->side_fork, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
             if ((e = hipEventCreateWithFlags(&c->side_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
             if ((e = hipMalloc(&c->red_partial_b, (size_t)c->red_blocks * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
@@ -461,6 +473,8 @@ extern "C" int qd_destroy(qd_handle c) {
     if (c->fix_count) hipFree(c->fix_count); if (c->fix_list) hipFree(c->fix_list);
     if (c->side_stream) { hipStreamSynchronize(c->side_stream); hipStreamDestroy(c->side_stream); }
     if (c->side_fork) hipEventDestroy(c->side_fork); if (c->side_done) hipEventDestroy(c->side_done);
+    if (c->med_fork) hipEventDestroy(c->med_fork); if (c->med_done) hipEventDestroy(c->med_done);
+    if (c->hist_b) hipFree(c->hist_b); if (c->sel_state_b) hipFree(c->sel_state_b); if (c->sel_cand_b) hipFree(c->sel_cand_b); if (c->sel_ccount_b) hipFree(c->sel_ccount_b);
     if (c->eta_acc) hipFree(c->eta_acc);
     if (c->dcount) hipFree(c->dcount); if (c->hist) hipFree(c->hist); if (c->sel_state) hipFree(c->sel_state);
     if (c->zonal_tw) hipFree(c->zonal_tw);

@@ -288,6 +288,39 @@ QdColP qd_make_colp(const qd_ctx* c, double dt) {
 __global__ void k_set_scalar(double* p, double v) { if (threadIdx.x == 0 && blockIdx.x == 0) *p = v; }
 __global__ void k_zero_count(unsigned long long* p) { if (threadIdx.x == 0 && blockIdx.x == 0) *p = 0ull; }
 
+static QdColPtrs qd_col_ptrs(qd_ctx* c) {
+    double** F = c->f;
+    QdColPtrs A;
+    A.u = F[QD_F_U]; A.v = F[QD_F_V]; A.Teq = F[QD_F_TEQ]; A.isr = F[QD_F_ISR];
+    A.albedo = F[QD_F_ALBEDO]; A.csmap = F[QD_F_CSMAP];
+    A.h = F[QD_F_H]; A.Ts = F[QD_F_TS]; A.q = F[QD_F_Q]; A.cloud = F[QD_F_CLOUD]; A.hice = F[QD_F_HICE];
+    A.E = F[QD_F_EFLUX]; A.Pcond = F[QD_F_PCOND]; A.LH = F[QD_F_LH]; A.LHrel = F[QD_F_LHREL];
+    A.olr = F[QD_F_OLR]; A.cloud_eff = F[QD_F_CLOUD_EFF];
+    A.land = c->land; A.pref = c->dscal + QD_S_PREF; A.npos = c->dcount;
+    return A;
+}
+
+// QD_MED_SIDE (whole-globe qd_step_n): phase 1 of the column and the P_cond median read nothing the driver physics writes and are
+// four launches that leave most of the chip idle (one workgroup per CU, chains of dependent round trips): they run on the side
+// stream BESIDE the physics' launches.  Fork: everything queued so far (the ocean step's T_s injection is the last writer of an
+// input); join: qd_atmos_step_impl, in front of the column's phase 2.
+int qd_pcond_median_side(qd_ctx* c, double dt) {
+    QD_HIP(c, hipEventRecord(c->med_fork, c->stream));
+    QD_HIP(c, hipStreamWaitEvent(c->side_stream, c->med_fork, 0));
+    std::swap(c->stream, c->side_stream);
+    c->med_side_active = true;
+    const QdColP P = qd_make_colp(c, dt);
+    const QdColPtrs A = qd_col_ptrs(c);
+    hipLaunchKernelGGL((k_column<1, true>), qd_grid2d(c->geo), dim3(QD_BLOCK), 0, c->stream, c->geo, P, A);
+    const int r = qd_median_positive_dev(c, c->f[QD_F_PCOND], 1e-6, QD_S_PREF, 0, 0.0, 1);
+    c->med_side_active = false;
+    std::swap(c->stream, c->side_stream);
+    if (r) return -1;
+    QD_HIP(c, hipEventRecord(c->med_done, c->side_stream));
+    c->pcond_ahead = 2;
+    return 0;
+}
+
 int qd_atmos_step_impl(qd_ctx* c, double dt, int has_albedo) {
     const qd_params& p = c->p;
     const QdGeom& G0 = c->geo;
@@ -321,9 +354,11 @@ int qd_atmos_step_impl(qd_ctx* c, double dt, int has_albedo) {
             QD_ROWS(c, m, G, hipLaunchKernelGGL((k_column<0, true>), qd_grid2d(G), blk, 0, c->stream, G, P, A));
         } else {
             // (whole-globe qd_step_n: the last launch of the driver physics has written this step's P_cond already: k_snow_albedo_forcing)
-            if (c->pcond_ahead) c->pcond_ahead = 0;
-            else QD_ROWS(c, m, G, hipLaunchKernelGGL((k_column<1, true>), qd_grid2d(G), blk, 0, c->stream, G, P, A));
-            if (qd_median_positive_dev(c, F[QD_F_PCOND], 1e-6, QD_S_PREF, 0, 0.0, 1)) return -1;
+            const int ahead = c->pcond_ahead;                // 1: P_cond is there; 2: its median too, on the side stream (qd_pcond_median_side)
+            c->pcond_ahead = 0;
+            if (!ahead) QD_ROWS(c, m, G, hipLaunchKernelGGL((k_column<1, true>), qd_grid2d(G), blk, 0, c->stream, G, P, A));
+            if (ahead == 2) QD_HIP(c, hipStreamWaitEvent(c->stream, c->med_done, 0));
+            else if (qd_median_positive_dev(c, F[QD_F_PCOND], 1e-6, QD_S_PREF, 0, 0.0, 1)) return -1;
             QD_ROWS(c, m, G, hipLaunchKernelGGL((k_column<2, true>), qd_grid2d(G), blk, 0, c->stream, G, P, A));
         }
         qd_mark(c, {F[QD_F_H], F[QD_F_TS], F[QD_F_Q], F[QD_F_EFLUX], F[QD_F_PCOND], F[QD_F_LH], F[QD_F_LHREL], F[QD_F_OLR]}, m);

@@ -228,6 +228,13 @@ struct qd_ctx {
     // whole-globe qd_step_n: k_snow_albedo_forcing (the driver physics' last launch) also computes P_cond = phase 1 of the column
     // (it reads h, h_ice, land anyway; k_column<1> was a launch of 14 us that read them again), time_step then starts with the median
     int merge_pcond = 1;             // QD_MERGE_PCOND=0: k_column<1> stays a launch of its own
+    // QD_MED_SIDE=1: k_column<1> + the P_cond median (four launches of one workgroup per CU or less: latency chains, not bandwidth) run on
+    // the SIDE stream beside the driver physics' launches instead of between them and time_step's column (pcond_ahead = 2: the median
+    // is done too; qd_atmos_step_impl joins).  Its median has buffers of its own (qd_reduce.hip).
+    int med_side = 0;
+    bool med_side_active = false;    // set around the side median's qd_median_positive_dev call
+    hipEvent_t med_fork = nullptr, med_done = nullptr;
+    unsigned int* hist_b = nullptr; unsigned long long* sel_state_b = nullptr; double* sel_cand_b = nullptr; unsigned int* sel_ccount_b = nullptr;
     int want_pcond_ahead = 0;        // set by qd_step_n around the driver physics
     int pcond_ahead = 0;             // the physics launch did write it: qd_atmos_step_impl skips k_column<1>
     // whole-globe k_ocn_tail_fast does not store uo'' / vo'': changed cells go through a list and are patched in place (qd_ocntail.h)
@@ -345,7 +352,8 @@ int qd_exchange(qd_ctx* c, const QdUse* slots, int n);
 // (qd_plan_peek), calls qd_plan_end (wait + unpack, margins back to the halo width) and launches the remaining boundary rows
 struct QdSegList { QdGeom g[6]; int n; };
 QdSegList qd_segments_rows(qd_ctx* c, int vr0, int cnt, QdSegList S = QdSegList{{}, 0});   // rows [vr0, vr0 + cnt) of the ring (period n_lat), appended to S
-int qd_side_join(qd_ctx* c);         // the main stream waits for what the side stream holds (no-op when nothing is pending)
+int qd_side_join(qd_ctx* c);
+int qd_pcond_median_side(qd_ctx* c, double dt);   // qd_atmos.hip: k_column<1> + the P_cond median on the side stream (fork here, join in qd_atmos_step_impl)         // the main stream waits for what the side stream holds (no-op when nothing is pending)
 int qd_plan_begin(qd_ctx* c, const QdUse* in, int n, bool* pending);
 int qd_plan_end(qd_ctx* c);
 int qd_plan_peek(qd_ctx* c, const QdUse* in, int n);

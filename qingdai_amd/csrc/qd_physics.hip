@@ -376,6 +376,10 @@ int qd_driver_physics_impl(qd_ctx* c, double dt, const QdForcingCall* fc, int pa
     // the block's row partials: its own buffer when it may run beside the ocean step, which owns red_partial (QD_SIDE_STREAM)
     double* const rp = (c->side_stream_on && c->red_partial_b) ? c->red_partial_b : c->red_partial;
     if (part == 2 && qd_side_join(c)) return -1;              // the block ran on the side stream: its products are read from here on
+    // QD_MED_SIDE: time_step's P_cond + its median start here, on the side stream, beside everything below (qd_atmos.hip)
+    const bool pcond_side = part != 1 && c->want_pcond_ahead && c->med_side && c->side_stream && c->geo.full && p.cloud_couple && !isset(p.pcond_ref) &&
+                            c->timing != 1;
+    if (pcond_side && qd_pcond_median_side(c, dt)) return -1;
     if (part != 2) {
         QdScope sc(c, "phys_precip");
         // median of pos = max(0, -(div - D_crit)) over pos > 0, straight from the divergence field
@@ -563,7 +567,7 @@ int qd_driver_physics_impl(qd_ctx* c, double dt, const QdForcingCall* fc, int pa
                 QdSafExtra X;
                 X.write_diag = c->diag_write;
                 // time_step's column phase 1 rides along when qd_step_n says the next thing is time_step with the P_cond median
-                X.col1 = (c->want_pcond_ahead && c->geo.full && p.cloud_couple && !isset(p.pcond_ref)) ? 1 : 0;
+                X.col1 = (c->want_pcond_ahead && !pcond_side && c->geo.full && p.cloud_couple && !isset(p.pcond_ref)) ? 1 : 0;
                 X.P = qd_make_colp(c, dt);
                 X.u = F[QD_F_U]; X.v = F[QD_F_V]; X.Ts = F[QD_F_TS]; X.q = F[QD_F_Q]; X.Pcond = F[QD_F_PCOND];
                 QD_ROWS(c, mm, G, hipLaunchKernelGGL(k_snow_albedo_forcing, qd_grid2d(G), blk, 0, c->stream, G, c->tabs, S, A, Fo, F[QD_F_PRECIP], F[QD_F_H],

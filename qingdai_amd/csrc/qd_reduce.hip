@@ -942,24 +942,32 @@ int qd_median_positive_dev(qd_ctx* c, const double* x, double dflt, int slot, in
     if (c->geo.full && c->sel_cand && c->med_pred && c->med_predict && site >= 0 && site < QD_MED_SITES) {
         // windowed histogram around the site's last median, one collecting pass, one finishing workgroup
         double* pred = c->med_pred + 16 * site;
+        // a median that runs on the side stream BESIDE the main stream's medians (qd_pcond_median_side, qd_atmos.hip) has a select
+        // state, histogram, candidate list and counter of its own
+        const bool sb = c->med_side_active && c->hist_b;
+        unsigned int* const hist = sb ? c->hist_b : c->hist;
+        unsigned long long* const sel_state = sb ? c->sel_state_b : c->sel_state;
+        double* const sel_cand = sb ? c->sel_cand_b : c->sel_cand;
+        unsigned int* const sel_ccount = sb ? c->sel_ccount_b : c->sel_ccount;
+        unsigned long long* const dcount = sb ? c->dcount + 8 : c->dcount;
         if (c->med_seen[site]) {
-            hipLaunchKernelGGL(k_med_hist, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, pred, c->hist, 1);
-            hipLaunchKernelGGL(k_med_scan_bracket, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, pred, c->hist, c->sel_state,
-                               c->sel_cand, c->sel_ccount, (unsigned int)c->geo.cells());
-            hipLaunchKernelGGL(k_med_final, dim3(1), dim3(QD_FIN_BLOCK), 0, c->stream, c->sel_state, c->sel_cand, c->sel_ccount, pred, x,
-                               (unsigned long long)c->geo.cells(), transform, tparam, dflt, c->dscal + slot, c->dcount, 0, 0u,
-                               (double*)nullptr, c->hist, (double*)nullptr, (double*)nullptr, 0.0);
+            hipLaunchKernelGGL(k_med_hist, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, pred, hist, 1);
+            hipLaunchKernelGGL(k_med_scan_bracket, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, pred, hist, sel_state,
+                               sel_cand, sel_ccount, (unsigned int)c->geo.cells());
+            hipLaunchKernelGGL(k_med_final, dim3(1), dim3(QD_FIN_BLOCK), 0, c->stream, sel_state, sel_cand, sel_ccount, pred, x,
+                               (unsigned long long)c->geo.cells(), transform, tparam, dflt, c->dscal + slot, dcount, 0, 0u,
+                               (double*)nullptr, hist, (double*)nullptr, (double*)nullptr, 0.0);
             return 0;
         }
         c->med_seen[site] = 1;                                // first use: the digit-by-digit select below, then seed the window
         for (int p = 0; p < 2; ++p)
-            hipLaunchKernelGGL(k_sel_pass, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, c->sel_state,
-                               c->hist, shifts[p], widths[p], p == 0 ? 1 : 0, 0);
-        hipLaunchKernelGGL(k_sel_collect, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, c->sel_state,
-                           c->sel_cand, c->sel_ccount, (unsigned long long)c->geo.cells(), 22);
-        hipLaunchKernelGGL(k_sel_final, dim3(1), dim3(QD_FIN_BLOCK), 0, c->stream, c->sel_state, c->sel_cand, c->sel_ccount,
-                           (unsigned long long)c->geo.cells(), 22, dflt, c->dscal + slot, c->dcount);
-        hipLaunchKernelGGL(k_med_seed, dim3(1), dim3(64), 0, c->stream, pred, c->dscal + slot, c->dcount);
+            hipLaunchKernelGGL(k_sel_pass, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, sel_state,
+                               hist, shifts[p], widths[p], p == 0 ? 1 : 0, 0);
+        hipLaunchKernelGGL(k_sel_collect, grid, dim3(QD_BLOCK), 0, c->stream, G, x, transform, tparam, sel_state,
+                           sel_cand, sel_ccount, (unsigned long long)c->geo.cells(), 22);
+        hipLaunchKernelGGL(k_sel_final, dim3(1), dim3(QD_FIN_BLOCK), 0, c->stream, sel_state, sel_cand, sel_ccount,
+                           (unsigned long long)c->geo.cells(), 22, dflt, c->dscal + slot, dcount);
+        hipLaunchKernelGGL(k_med_seed, dim3(1), dim3(64), 0, c->stream, pred, c->dscal + slot, dcount);
         return 0;
     }
     if (c->geo.full && c->sel_cand) {

@@ -573,11 +573,12 @@ def test_lazy_diagnostics_and_the_merged_pcond_launch_change_nothing_at_the_end_
     st = _seed_state(nlat, nlon, 5)
     static = {"LAND_MASK": mask, "FRICTION": fric, "BASE_ALBEDO": alb}
 
-    def run(lazy, merge):
+    def run(lazy, merge, side="0"):
         # the flags of bench.py's span (ocean + driver physics + albedo handed to time_step, no hydrology commit): the ones both
-        # switches act on
+        # switches act on.  side = QD_MED_SIDE: k_column<1> + the P_cond median on a second stream beside the driver physics' launches
         monkeypatch.setenv("QD_LAZY_DIAG", lazy)
         monkeypatch.setenv("QD_MERGE_PCOND", merge)
+        monkeypatch.setenv("QD_MED_SIDE", side)
         dev = Device(grid, p)
         for k, v in {**static, **st}.items():
             dev.upload_now(k, v)
@@ -590,10 +591,10 @@ def test_lazy_diagnostics_and_the_merged_pcond_launch_change_nothing_at_the_end_
         dev.close()
         return out
     ref = run("0", "0")
-    for lazy, merge in (("1", "1"), ("1", "0"), ("0", "1")):
-        got = run(lazy, merge)
+    for lazy, merge, side in (("1", "1", "0"), ("1", "0", "0"), ("0", "1", "0"), ("1", "1", "1"), ("0", "0", "1")):
+        got = run(lazy, merge, side)
         for k in names:
-            assert np.array_equal(got[k], ref[k], equal_nan=True), (lazy, merge, k)
+            assert np.array_equal(got[k], ref[k], equal_nan=True), (lazy, merge, side, k)
 
 
 def test_cloud_source_propagates_nan_like_the_reference(gpu):
