@@ -412,9 +412,12 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
         c->n_wgmax = (int)(qd_grid2d(c->geo).x * (unsigned)c->geo.nrows);
         if ((e = hipMalloc(&c->wgmax, (size_t)2 * c->n_wgmax * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
         { const char* ef = std::getenv("QD_MED_SIDE"); if (ef) c->med_side = ef[0] == '0' ? 0 : 1; }
+        { const char* ef = std::getenv("QD_MED_PAIR"); if (ef) c->med_pair = ef[0] == '0' ? 0 : 1; }
         if (c->med_side) {
             if ((e = hipEventCreateWithFlags(&c->med_fork, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
             if ((e = hipEventCreateWithFlags(&c->med_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+        }
+        if (c->med_side || c->med_pair) {                    // a second set of median buffers
             if ((e = hipMalloc(&c->hist_b, 2 * QD_HIST_BINS * sizeof(unsigned int))) != hipSuccess) return bail("hipMalloc", e);
             if ((e = hipMalloc(&c->sel_state_b, 8 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
             if ((e = hipMalloc(&c->sel_cand_b, 2 * cells * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);

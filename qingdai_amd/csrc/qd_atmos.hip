@@ -304,6 +304,10 @@ static QdColPtrs qd_col_ptrs(qd_ctx* c) {
 // four launches that leave most of the chip idle (one workgroup per CU, chains of dependent round trips): they run on the side
 // stream BESIDE the physics' launches.  Fork: everything queued so far (the ocean step's T_s injection is the last writer of an
 // input); join: qd_atmos_step_impl, in front of the column's phase 2.
+int qd_pcond_phase1(qd_ctx* c, double dt) {
+    hipLaunchKernelGGL((k_column<1, true>), qd_grid2d(c->geo), dim3(QD_BLOCK), 0, c->stream, c->geo, qd_make_colp(c, dt), qd_col_ptrs(c));
+    return 0;
+}
 int qd_pcond_median_side(qd_ctx* c, double dt) {
     QD_HIP(c, hipEventRecord(c->med_fork, c->stream));
     QD_HIP(c, hipStreamWaitEvent(c->side_stream, c->med_fork, 0));
@@ -354,11 +358,13 @@ int qd_atmos_step_impl(qd_ctx* c, double dt, int has_albedo) {
             QD_ROWS(c, m, G, hipLaunchKernelGGL((k_column<0, true>), qd_grid2d(G), blk, 0, c->stream, G, P, A));
         } else {
             // (whole-globe qd_step_n: the last launch of the driver physics has written this step's P_cond already: k_snow_albedo_forcing)
-            const int ahead = c->pcond_ahead;                // 1: P_cond is there; 2: its median too, on the side stream (qd_pcond_median_side)
+            // 1: P_cond is there; 2: its median too, on the side stream (qd_pcond_median_side); 3: its median too, on this stream (the
+            // cloud block ran it together with the precipitation median: qd_median_pair_dev)
+            const int ahead = c->pcond_ahead;
             c->pcond_ahead = 0;
             if (!ahead) QD_ROWS(c, m, G, hipLaunchKernelGGL((k_column<1, true>), qd_grid2d(G), blk, 0, c->stream, G, P, A));
             if (ahead == 2) QD_HIP(c, hipStreamWaitEvent(c->stream, c->med_done, 0));
-            else if (qd_median_positive_dev(c, F[QD_F_PCOND], 1e-6, QD_S_PREF, 0, 0.0, 1)) return -1;
+            else if (ahead != 3 && qd_median_positive_dev(c, F[QD_F_PCOND], 1e-6, QD_S_PREF, 0, 0.0, 1)) return -1;
             QD_ROWS(c, m, G, hipLaunchKernelGGL((k_column<2, true>), qd_grid2d(G), blk, 0, c->stream, G, P, A));
         }
         qd_mark(c, {F[QD_F_H], F[QD_F_TS], F[QD_F_Q], F[QD_F_EFLUX], F[QD_F_PCOND], F[QD_F_LH], F[QD_F_LHREL], F[QD_F_OLR]}, m);

@@ -231,6 +231,8 @@ struct qd_ctx {
     // QD_MED_SIDE=1: k_column<1> + the P_cond median (four launches of one workgroup per CU or less: latency chains, not bandwidth) run on
     // the SIDE stream beside the driver physics' launches instead of between them and time_step's column (pcond_ahead = 2: the median
     // is done too; qd_atmos_step_impl joins).  Its median has buffers of its own (qd_reduce.hip).
+    int med_pair = 1;                // QD_MED_PAIR=0: the precipitation median and the P_cond median as two chains of three launches instead of one
+                                     // (whole-globe qd_step_n: k_column<1> moves in front of the cloud block, pcond_ahead = 3)
     int med_side = 0;
     bool med_side_active = false;    // set around the side median's qd_median_positive_dev call
     hipEvent_t med_fork = nullptr, med_done = nullptr;
@@ -353,6 +355,7 @@ int qd_exchange(qd_ctx* c, const QdUse* slots, int n);
 struct QdSegList { QdGeom g[6]; int n; };
 QdSegList qd_segments_rows(qd_ctx* c, int vr0, int cnt, QdSegList S = QdSegList{{}, 0});   // rows [vr0, vr0 + cnt) of the ring (period n_lat), appended to S
 int qd_side_join(qd_ctx* c);
+int qd_pcond_phase1(qd_ctx* c, double dt);        // qd_atmos.hip: k_column<1> on the handle's stream (whole globe)
 int qd_pcond_median_side(qd_ctx* c, double dt);   // qd_atmos.hip: k_column<1> + the P_cond median on the side stream (fork here, join in qd_atmos_step_impl)         // the main stream waits for what the side stream holds (no-op when nothing is pending)
 int qd_plan_begin(qd_ctx* c, const QdUse* in, int n, bool* pending);
 int qd_plan_end(qd_ctx* c);
@@ -423,6 +426,8 @@ void qd_eco_convert_slab(qd_ctx* c, const double* src, int src_f32, double* dst,
 int qd_reduce_field(qd_ctx* c, const double* x, int op, double* host_out);
 // site: call-site id 0..3 (keeps a predicted bracket per site on whole-globe handles), -1 = no prediction
 int qd_median_positive_dev(qd_ctx* c, const double* x, double dflt, int slot, int transform, double tparam, int site = -1);
+int qd_median_pair_dev(qd_ctx* c, const double* x0, double dflt0, int slot0, int tr0, double tp0, int site0,
+                       const double* x1, double dflt1, int slot1, int tr1, double tp1, int site1);      // two medians in one set of three launches
 
 // qd_atmos.hip
 int qd_atmos_step_impl(qd_ctx* c, double dt, int has_albedo);

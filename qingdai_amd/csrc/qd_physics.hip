@@ -380,6 +380,8 @@ int qd_driver_physics_impl(qd_ctx* c, double dt, const QdForcingCall* fc, int pa
     const bool pcond_side = part != 1 && c->want_pcond_ahead && c->med_side && c->side_stream && c->geo.full && p.cloud_couple && !isset(p.pcond_ref) &&
                             c->timing != 1;
     if (pcond_side && qd_pcond_median_side(c, dt)) return -1;
+    const bool pcond_pair = part != 1 && !pcond_side && c->want_pcond_ahead && c->med_pair && c->hist_b && c->geo.full && p.cloud_couple &&
+                            !isset(p.pcond_ref) && !(isset(p.pref) && p.pref != 0.0);
     if (part != 2) {
         QdScope sc(c, "phys_precip");
         // median of pos = max(0, -(div - D_crit)) over pos > 0, straight from the divergence field
@@ -475,6 +477,12 @@ int qd_driver_physics_impl(qd_ctx* c, double dt, const QdForcingCall* fc, int pa
         QdScope sc(c, "phys_cloud");
         if (isset(p.pref) && p.pref != 0.0) {
             hipMemcpyAsync(c->dscal + QD_S_MED_OUT, &p.pref, sizeof(double), hipMemcpyHostToDevice, c->stream);
+        } else if (pcond_pair) {
+            // time_step's P_cond (phase 1 of its column) is computed HERE, so that its median and the precipitation median go through
+            // ONE chain of three launches (qd_median_pair_dev); time_step then starts with the column's phase 2
+            if (qd_pcond_phase1(c, dt)) return -1;
+            if (qd_median_pair_dev(c, F[QD_F_PRECIP], 1e-6, QD_S_MED_OUT, 0, 0.0, 3, F[QD_F_PCOND], 1e-6, QD_S_PREF, 0, 0.0, 1)) return -1;
+            c->pcond_ahead = 3;
         } else {
             if (qd_median_positive_dev(c, F[QD_F_PRECIP], 1e-6, QD_S_MED_OUT, 0, 0.0, 3)) return -1;
         }
@@ -567,7 +575,7 @@ int qd_driver_physics_impl(qd_ctx* c, double dt, const QdForcingCall* fc, int pa
                 QdSafExtra X;
                 X.write_diag = c->diag_write;
                 // time_step's column phase 1 rides along when qd_step_n says the next thing is time_step with the P_cond median
-                X.col1 = (c->want_pcond_ahead && !pcond_side && c->geo.full && p.cloud_couple && !isset(p.pcond_ref)) ? 1 : 0;
+                X.col1 = (c->want_pcond_ahead && !pcond_side && !pcond_pair && c->geo.full && p.cloud_couple && !isset(p.pcond_ref)) ? 1 : 0;
                 X.P = qd_make_colp(c, dt);
                 X.u = F[QD_F_U]; X.v = F[QD_F_V]; X.Ts = F[QD_F_TS]; X.q = F[QD_F_Q]; X.Pcond = F[QD_F_PCOND];
                 QD_ROWS(c, mm, G, hipLaunchKernelGGL(k_snow_albedo_forcing, qd_grid2d(G), blk, 0, c->stream, G, c->tabs, S, A, Fo, F[QD_F_PRECIP], F[QD_F_H],

@@ -377,6 +377,7 @@ k_sel_final(unsigned long long* st, const double* __restrict__ cand, unsigned in
 #define QD_MED_SITES 4
 #define QD_MED_BAND_CAP 4092u      // candidates per band in the gathered segments (4096 doubles each)
 #define QD_MED_WSHIFT 44
+#define QD_MED_WG_STAGE 512        // candidates a workgroup of the collecting pass stages in LDS (4 KB)
 #define QD_MED_LDS_LIST 4096       // candidates the finishing workgroup keeps in LDS (32 KB)
 // window of bit patterns [base, base + 2048 << 44) around a site's last median: centre / 16 .. centre * 16 (8 binades)
 __device__ __forceinline__ unsigned long long qd_med_window_base(bool valid, double centre) {
@@ -590,13 +591,19 @@ k_med_bracket(QdGeom G, const double* __restrict__ x, int transform, double tpar
 // behind a ticket, a fence and a launch boundary (round 3: k_med_hist was 17 us of which the ticket -> acquire -> 2050 loads -> scan
 // -> publish -> reset tail of its last workgroup was 6) -- while the first row of the field is already on its way.  Workgroup
 // (0, 0) also publishes the bracket for the finisher (pred[8..11]).  k_med_final resets the histogram.
-__global__ void __launch_bounds__(QD_BLOCK)
-k_med_scan_bracket(QdGeom G, const double* __restrict__ x, int transform, double tparam, double* pred, const unsigned int* __restrict__ hist,
-                   unsigned long long* st, double* __restrict__ cand, unsigned int* __restrict__ ccount, unsigned int cap) {
+__device__ __forceinline__ void qd_med_scan_bracket_body(const QdGeom& G, const double* __restrict__ x, int transform, double tparam, double* pred,
+                                                         const unsigned int* __restrict__ hist, unsigned long long* st, double* __restrict__ cand,
+                                                         unsigned int* __restrict__ ccount, unsigned int cap) {
     __shared__ unsigned int sh[QD_HIST_BINS];
     __shared__ unsigned long long s_cnt[2];
     __shared__ unsigned int s_c[2][QD_BLOCK / 64];
+    // candidates of this workgroup are staged in LDS and appended to the list with ONE returning global atomic per workgroup: one per
+    // wavefront with a hit was ~1 000 atomics on one word per launch, which serialise at ~90 per us -- the collecting pass of a site
+    // with 950 candidates took 13.6 us, of one with 240 candidates 9.7
+    __shared__ double s_cand[QD_MED_WG_STAGE];
+    __shared__ unsigned int s_n, s_base;
     const int t = threadIdx.x, lane = t & 63;
+    if (t == 0) s_n = 0u;
     const int nby = (int)gridDim.y, by = (int)blockIdx.y;
     const bool valid = pred[3] != 0.0;
     const unsigned long long base = qd_med_window_base(valid, pred[0]);
@@ -652,7 +659,22 @@ k_med_scan_bracket(QdGeom G, const double* __restrict__ x, int transform, double
                 if (j0 >= G.nlon) break;                                  // wave-uniform
                 const int j = j0 + t;
                 const double v = (j < G.nlon) ? qd_med_value(cur[q], transform, tparam) : 0.0;
-                qd_med_collect(v, lo, hi, lane, lt, n_pos, n_below, cand, ccount, cap);
+                const bool pos = v > 0.0;
+                n_pos += pos ? 1u : 0u;
+                n_below += (pos && v < lo) ? 1u : 0u;
+                const bool in = pos && v >= lo && v <= hi;
+                const unsigned long long m = __ballot(in);
+                if (m) {
+                    unsigned int base = 0;
+                    const int leader = __ffsll((long long)m) - 1;
+                    if (lane == leader) base = atomicAdd(&s_n, (unsigned int)__popcll(m));       // LDS
+                    base = (unsigned int)__shfl((int)base, leader, 64);
+                    const unsigned int idx = base + (unsigned int)__popcll(m & lt);
+                    if (in) {
+                        if (idx < (unsigned int)QD_MED_WG_STAGE) s_cand[idx] = v;
+                        else { const unsigned int g = atomicAdd(&ccount[0], 1u); if (g < cap) cand[g] = v; }     // a crowded bracket: straight to the list
+                    }
+                }
             }
         }
     }
@@ -660,11 +682,42 @@ k_med_scan_bracket(QdGeom G, const double* __restrict__ x, int transform, double
     for (int o = 32; o > 0; o >>= 1) { n_pos += __shfl_down(n_pos, o, 64); n_below += __shfl_down(n_below, o, 64); }
     if (lane == 0) { s_c[0][t >> 6] = n_pos; s_c[1][t >> 6] = n_below; }
     __syncthreads();
+    {
+        const unsigned int ns = s_n < (unsigned int)QD_MED_WG_STAGE ? s_n : (unsigned int)QD_MED_WG_STAGE;
+        if (t == 0 && ns) s_base = atomicAdd(&ccount[0], ns);               // the count keeps running past the capacity: overflow is visible
+        __syncthreads();
+        for (unsigned int k = t; k < ns; k += QD_BLOCK) { const unsigned int g = s_base + k; if (g < cap) cand[g] = s_cand[k]; }
+    }
     if (t < 2) {                                              // one global atomic per workgroup and counter
         unsigned int a = 0;
         for (int k = 0; k < QD_BLOCK / 64; ++k) a += s_c[t][k];
         if (a) atomicAdd(&st[t], (unsigned long long)a);
     }
+}
+
+__global__ void __launch_bounds__(QD_BLOCK)
+k_med_scan_bracket(QdGeom G, const double* __restrict__ x, int transform, double tparam, double* pred, const unsigned int* __restrict__ hist,
+                   unsigned long long* st, double* __restrict__ cand, unsigned int* __restrict__ ccount, unsigned int cap) {
+    qd_med_scan_bracket_body(G, x, transform, tparam, pred, hist, st, cand, ccount, cap);
+}
+
+// ---- two medians in ONE set of three launches (whole-globe handles): the median of a field is a chain of dependent round trips that
+// leaves most of the chip idle (256 workgroups, one finishing workgroup), so two fields that are both there -- the precipitation
+// field and time_step's P_cond at the start of the cloud block -- go through the chain side by side: blockIdx.z picks the job, every
+// job has a histogram, select state and candidate list of its own.  Same device functions as the single kernels: same bits.
+struct QdMedJob {
+    const double* x; int transform; double tparam, dflt; double* pred; unsigned int* hist; unsigned long long* st; double* cand;
+    unsigned int* ccount; double* out; unsigned long long* count_out;
+};
+__global__ void __launch_bounds__(QD_BLOCK)
+k_med_hist2(QdGeom G, QdMedJob J0, QdMedJob J1) {
+    const QdMedJob& J = blockIdx.z ? J1 : J0;
+    qd_med_hist_body(G, J.x, J.transform, J.tparam, J.pred, J.hist, 1, (int)gridDim.x, (int)gridDim.y, (int)blockIdx.x, (int)blockIdx.y);
+}
+__global__ void __launch_bounds__(QD_BLOCK)
+k_med_scan_bracket2(QdGeom G, QdMedJob J0, QdMedJob J1, unsigned int cap) {
+    const QdMedJob& J = blockIdx.z ? J1 : J0;
+    qd_med_scan_bracket_body(G, J.x, J.transform, J.tparam, J.pred, J.hist, J.st, J.cand, J.ccount, cap);
 }
 
 // value of element k of the select source: the candidate list, or (fallback) the transformed field; non-positive = skip
@@ -916,6 +969,13 @@ k_med_final(unsigned long long* st, const double* __restrict__ cand, unsigned in
     }
 }
 
+__global__ void __launch_bounds__(QD_FIN_BLOCK)
+k_med_final2(QdMedJob J0, QdMedJob J1, unsigned long long n_field) {
+    const QdMedJob& J = blockIdx.x ? J1 : J0;
+    qd_med_final_body<QD_FIN_BLOCK>(J.st, J.cand, J.ccount, J.pred, J.x, n_field, J.transform, J.tparam, J.dflt, J.out, J.count_out, 0, 0u,
+                                    (double*)nullptr, J.hist);
+}
+
 // result + reset of the select state for the next call; `count_out` (optional) keeps the count
 __global__ void k_sel_finish(unsigned long long* st, double dflt, double* out, unsigned long long* count_out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -929,6 +989,27 @@ __global__ void k_sel_finish(unsigned long long* st, double dflt, double* out, u
         if (count_out) *count_out = n;
         for (int k = 0; k < 8; ++k) st[k] = 0ull;
     }
+}
+
+// Two medians at once (see k_med_hist2): job 0 on the handle's first set of median buffers, job 1 on the second (hist_b ...).  Falls back to
+// two calls in a row when a site has no window yet, or the handle has no second set.
+int qd_median_pair_dev(qd_ctx* c, const double* x0, double dflt0, int slot0, int tr0, double tp0, int site0,
+                       const double* x1, double dflt1, int slot1, int tr1, double tp1, int site1) {
+    const bool ok = c->geo.full && c->sel_cand && c->med_pred && c->med_predict && c->hist_b && site0 >= 0 && site0 < QD_MED_SITES &&
+                    site1 >= 0 && site1 < QD_MED_SITES && site0 != site1 && c->med_seen[site0] && c->med_seen[site1];
+    if (!ok) {
+        if (qd_median_positive_dev(c, x0, dflt0, slot0, tr0, tp0, site0)) return -1;
+        return qd_median_positive_dev(c, x1, dflt1, slot1, tr1, tp1, site1);
+    }
+    const QdGeom G = qd_segments(c, 0).g[0];
+    const dim3 grid(1, std::min(G.nrows, c->tune.med_blocks), 2);
+    const QdMedJob J0{x0, tr0, tp0, dflt0, c->med_pred + 16 * site0, c->hist, c->sel_state, c->sel_cand, c->sel_ccount, c->dscal + slot0, c->dcount};
+    const QdMedJob J1{x1, tr1, tp1, dflt1, c->med_pred + 16 * site1, c->hist_b, c->sel_state_b, c->sel_cand_b, c->sel_ccount_b, c->dscal + slot1,
+                      c->dcount + 8};
+    hipLaunchKernelGGL(k_med_hist2, grid, dim3(QD_BLOCK), 0, c->stream, G, J0, J1);
+    hipLaunchKernelGGL(k_med_scan_bracket2, grid, dim3(QD_BLOCK), 0, c->stream, G, J0, J1, (unsigned int)c->geo.cells());
+    hipLaunchKernelGGL(k_med_final2, dim3(2), dim3(QD_FIN_BLOCK), 0, c->stream, J0, J1, (unsigned long long)c->geo.cells());
+    return 0;
 }
 
 // median of the positive entries of x (after `transform`) -> device scalar slot; `dflt` if none
