@@ -380,6 +380,7 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
     hipMemsetAsync(c->hist, 0, 2 * QD_HIST_BINS * sizeof(unsigned int), c->stream);
     hipMemsetAsync(c->sel_state, 0, 8 * sizeof(unsigned long long), c->stream);
     { const char* ef = std::getenv("QD_TAIL_FIX"); if (ef) c->tail_fix = ef[0] == '0' ? 0 : 1; }
+    { const char* ef = std::getenv("QD_TAIL_FIX_DENSE"); if (ef) c->fix_dense = std::atof(ef); }
     { const char* ef = std::getenv("QD_LAZY_DIAG"); if (ef) c->lazy_diag = ef[0] == '0' ? 0 : 1; }
     if (c->tail_fix) {                                        // list of the cells whose currents the ocean tail kernel changes (qd_ocntail.h)
         if ((e = hipMalloc(&c->fix_count, 64)) != hipSuccess) return bail("hipMalloc", e);
@@ -436,7 +437,7 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
     if ((e = hipHostMalloc((void**)&c->hpin, 64 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return bail("hipHostMalloc", e);
     if ((e = hipHostMalloc((void**)&c->hpin_rows, (size_t)3 * c->geo.lrows() * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return bail("hipHostMalloc", e);
     std::memset(c->hpin, 0, 64 * sizeof(double));
-    c->hpin[58] = -1.0; c->hpin[59] = -1.0;                  // self-validating slots of k_max2_publish (qd_wait_host_nonneg)
+    c->hpin[57] = -1.0; c->hpin[58] = -1.0; c->hpin[59] = -1.0;                  // self-validating slots of k_max2_publish (qd_wait_host_nonneg)
     std::memset(c->hpin_rows, 0, (size_t)3 * c->geo.lrows() * sizeof(double));      // [2 n .. 3 n): per-row arrival stamps of k_stress_max
     // reference initial state
     const double q0 = std::min(std::max(q_init_rh, 0.0), 1.0) * host_qsat(288.0, params->p0);
@@ -473,6 +474,12 @@ extern "C" int qd_destroy(qd_handle c) {
     if (c->red_partial) hipFree(c->red_partial); if (c->dscal) hipFree(c->dscal);
     if (c->red_partial_b) hipFree(c->red_partial_b);
     if (c->wgmax) hipFree(c->wgmax);
+    if (c->fix_count && std::getenv("QD_TAIL_FIX_DEBUG")) {
+        unsigned int h[8] = {0};
+        if (hipMemcpy(h, c->fix_count, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess)
+            fprintf(stderr, "[tail fix list] %u entries in %u launches (%.1f per launch), longest list %u of %zu cells\n", h[4], h[5],
+                    h[5] ? (double)h[4] / h[5] : 0.0, h[6], c->geo.cells());
+    }
     if (c->fix_count) hipFree(c->fix_count); if (c->fix_list) hipFree(c->fix_list);
     if (c->side_stream) { hipStreamSynchronize(c->side_stream); hipStreamDestroy(c->side_stream); }
     if (c->side_fork) hipEventDestroy(c->side_fork); if (c->side_done) hipEventDestroy(c->side_done);

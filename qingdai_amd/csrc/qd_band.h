@@ -42,6 +42,7 @@ struct QdPeerHook {
                                // 3: k_max2_finish per row segment (data[2k], data[2k+1] = maxima of partial[k * pstride ..], k < nseg; the rest of data[0..6) = 0)
     const double* partial = nullptr; int n = 0, nseg = 0, nsegrows[3] = {0, 0, 0}; size_t pstride = 0;
     unsigned long long* st = nullptr; unsigned int* cc = nullptr;
+    unsigned int* fixstat = nullptr;   // pre 3: data[6] = this band's average fix-list length since the last step, -2 = no news (qd_ocean.hip: the ocean tail's fix list)
     int post = 0;              // 1: k_precip_scalars_post on the reduced (num, den)
     double wsum = 0, pq_min = 0, p_blend = 0; int use_fb = 0; double* out = nullptr;
 };

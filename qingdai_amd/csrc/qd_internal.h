@@ -241,8 +241,10 @@ struct qd_ctx {
     int pcond_ahead = 0;             // the physics launch did write it: qd_atmos_step_impl skips k_column<1>
     // whole-globe k_ocn_tail_fast does not store uo'' / vo'': changed cells go through a list and are patched in place (qd_ocntail.h)
     int tail_fix = 1;                // QD_TAIL_FIX=0: uo'' / vo'' stored to slabs of their own as before
-    unsigned int* fix_count = nullptr;
+    unsigned int* fix_count = nullptr;           // [0] entries of the launch in flight, [4] entries / [5] launches since the last publish, [6] longest list
     unsigned long long* fix_list = nullptr;      // [cells][3]
+    double fix_avg = 0.0;                        // entries per launch in the last step that used the list (k_max2_publish / the bands' CFL reduce)
+    double fix_dense = 256.0;                    // QD_TAIL_FIX_DENSE: longer lists on average -> the storing form
     int defer_final = 0;             // set by qd_step_n around qd_atmos_step_impl
     int merge_final = 1;             // QD_MERGE_FINAL=0: keep the three launches
     struct { int on = 0; double dt = 0, decay = 0, dfac = 0; } final_pending;

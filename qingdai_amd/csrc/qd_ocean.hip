@@ -236,7 +236,7 @@ k_final_qnet_stress(QdGeom G, QdColP P, QdFqsArgs A) {
 // the two maxima over the per-workgroup maxima of k_final_qnet_stress -> two self-validating slots in pinned host memory (the host
 // keeps them at -1 and polls for >= 0: qd_wait_host_nonneg; no stamp, so nothing to wait for here).  One workgroup.
 __global__ void __launch_bounds__(1024)
-k_max2_publish(const double* __restrict__ wgmax, int n, double* host2) {
+k_max2_publish(const double* __restrict__ wgmax, int n, double* host2, unsigned int* fixstat) {
     __shared__ double sm[2][16];
     double a = 0.0, b = 0.0;
     for (int k = threadIdx.x; k < n; k += 1024) { const double x = wgmax[k], y = wgmax[n + k]; a = x > a ? x : a; b = y > b ? y : b; }
@@ -246,6 +246,17 @@ k_max2_publish(const double* __restrict__ wgmax, int n, double* host2) {
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int k = 1; k < 16; ++k) { a = sm[0][k] > a ? sm[0][k] : a; b = sm[1][k] > b ? sm[1][k] : b; }
+        // how long the ocean tail's fix lists were since the last step (entries per launch; no launch with a list: "no news", -2 -- the
+        // host keeps the slot at -1): the host takes the storing form while they are long (qd_ocean_step_impl).  Stored FIRST: the host
+        // reads it once the two maxima behind it have arrived (uncached stores of one thread leave in order)
+        double avg = -2.0;
+        if (fixstat) {
+            const unsigned e = fixstat[4], l = fixstat[5];
+            if (l) avg = (double)e / (double)l;
+            fixstat[4] = 0u; fixstat[5] = 0u;
+        }
+        __hip_atomic_store((unsigned long long*)host2 - 1, (unsigned long long)__double_as_longlong(avg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store((unsigned long long*)host2, (unsigned long long)__double_as_longlong(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store((unsigned long long*)host2 + 1, (unsigned long long)__double_as_longlong(b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -774,6 +785,7 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
     double*& taux = c->scratch[14];
     double*& tauy = c->scratch[15];
     int n_sub;
+    bool band_fix_stats = false;                              // a band learns how long its fix lists are only through the hooked CFL reduce
     {
         QdScope sc(c, "ocean_stress");
         // stress on the widest valid margin (sub-steps read it under the fused kernel's halo);
@@ -804,7 +816,7 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
                 A.dev_wg = c->wgmax; A.n_wg = c->n_wgmax;
                 merged_final = true;
                 hipLaunchKernelGGL(k_final_qnet_stress, qd_grid2d(G), blk, 0, c->stream, G, qd_make_colp_driver(c, dt), A);
-                hipLaunchKernelGGL(k_max2_publish, dim3(1), dim3(1024), 0, c->stream, c->wgmax, c->n_wgmax, c->hpin + 58);
+                hipLaunchKernelGGL(k_max2_publish, dim3(1), dim3(1024), 0, c->stream, c->wgmax, c->n_wgmax, c->hpin + 58, c->fix_count);
                 qd_swap(c, QD_F_CLOUD, 0);
                 use_ice_mask = 1;
             } else {
@@ -835,6 +847,8 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
             if (merged_final) {
                 if (qd_wait_host_nonneg(c, c->hpin + 58, &maxVa, "ocean step: the CFL maxima never arrived") ||
                     qd_wait_host_nonneg(c, c->hpin + 59, &maxUo, "ocean step: the CFL maxima never arrived")) return -1;
+                // the same launch stored the fix lists' average length in front of the maxima (written before them by the same thread)
+                { const double avg = c->hpin[57]; c->hpin[57] = -1.0; if (avg >= 0.0) c->fix_avg = avg; }
             } else {
             for (int k = 0; k < G.nrows; ++k)
                 if (qd_wait_host_flag(c, c->hpin_rows + (size_t)2 * G0.lrows() + k, c->eta_seq, "ocean step: the CFL maxima never arrived")) return -1;
@@ -860,9 +874,13 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
             for (int k = 0; k < S.n; ++k) H.nsegrows[k] = S.g[k].nrows;
             c->allreduces++;
             c->pub_seq += 1.0;
-            if (qd_peer_allreduce_hooked(c, c->dscal + QD_S_TMP0, 6, 1, H, c->hpin, c->pub_seq)) return -1;
+            // (a seventh value rides along: the longest average fix list of any band since the last step -- every band takes the same form)
+            H.fixstat = (c->tail_fix && c->fix_count) ? c->fix_count : nullptr;
+            if (qd_peer_allreduce_hooked(c, c->dscal + QD_S_TMP0, H.fixstat ? 7 : 6, 1, H, c->hpin, c->pub_seq)) return -1;
             if (qd_wait_host_flag(c, c->hpin + 61, c->pub_seq, "reduced scalars never reached the host")) return -1;
             if (c->hpin[60] != 0.0) return qd_fail(c, "peer exchange: a rank did not arrive within the deadline");
+            if (H.fixstat && c->hpin[6] >= 0.0) c->fix_avg = c->hpin[6];
+            band_fix_stats = H.fixstat != nullptr;
         } else if (qd_has_host_ring(c)) {
             // the host waits for these six maxima anyway: reduce them across the ranks in the host ring, no RCCL launch
             QD_HIP(c, hipMemcpyAsync(c->hpin, c->dscal + QD_S_TMP0, 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -888,6 +906,11 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
         n_sub = (v != v) ? 1 : (v > 500.0 ? 500 : (v < 1.0 ? 1 : (int)v));
         c->last_nsub = n_sub;
     }
+    // the ocean tail's fix list (QD_TAIL_FIX) pays while few cells change (a run from rest: ~40 per launch, -1.2 us per launch on the whole
+    // globe, -2.5 on a 1/8 band) and costs once the polar currents sit at the cap (~700 per launch at step 240 of the benchmark: the
+    // finishing wave's patch loop, +1.3 us): taken while the lists of the last step that had any averaged <= fix_dense entries, probed
+    // again every 32nd step while it is off
+    const bool fix_now = c->tail_fix && c->fix_count && (c->fix_avg <= c->fix_dense || (step & 31) == 0) && (!band || band_fix_stats);
     const double sub_dt = dt / n_sub;
     QdOcnP OP{p.a, p.g_ocean, c->dlat, c->dlon, sub_dt, p.rho_w * H, p.r_bot};
     QdHeatP HP{sub_dt, p.K_h, p.rho_w * p.cp_w * H, p.ocean_ice_qfac, p.ocean_use_qnet ? 1 : 0, use_ice_mask ? 1 : 0};
@@ -1067,7 +1090,7 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
                 QdPeerFold pf;
                 const bool folded = qd_peer_fold_begin(c, &pf);
                 // one launch that covers the band and has the finishing wave: uo'' / vo'' in place through the fix list, like the whole globe
-                if (c->tail_fix && c->fix_count && S.n == 1) { A.fix_count = c->fix_count; A.fix_list = c->fix_list; }
+                if (fix_now && S.n == 1) { A.fix_count = c->fix_count; A.fix_list = c->fix_list; }
                 for (int k = 0; k < S.n; ++k) {
                     const QdGeom& Gs = S.g[k];
                     const bool owned = Gs.row0 <= c->own_row0 && c->own_row0 < Gs.row0 + Gs.nrows;      // the segment that holds the band's own rows
@@ -1083,7 +1106,7 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
                 else qd_mark(c, {F[QD_F_ETA], A.Ts_out, A.uo_out, A.vo_out}, m);
             } else {
             // uo'' / vo'' in place through the fix list (the launcher drops it when the kernel it picks has no finishing wave)
-            if (c->tail_fix && c->fix_count) { A.fix_count = c->fix_count; A.fix_list = c->fix_list; }
+            if (fix_now) { A.fix_count = c->fix_count; A.fix_list = c->fix_list; }
             if (qd_launch_ocn_tail(c, Gown, A)) return -1;
             if (!tail_acc)
                 hipLaunchKernelGGL(k_eta_mean_tail, dim3(1), dim3(256), 0, c->stream, c->red_partial, qd_ocn_tail_tiles(c, Gown), c->wsum_ocean,

@@ -110,21 +110,54 @@ __device__ __forceinline__ void qt_st(qt_rsrc r, unsigned row_elems, unsigned vo
 __device__ __forceinline__ int qt_ld8(qt_rsrc r, unsigned row_elems, unsigned vo8) { return (int)__builtin_amdgcn_raw_buffer_load_b8(r, vo8, row_elems, 0); }
 
 // uo'' / vo'' of one cell: stored -- or, with a fix list (QdTailArgs::fix_count), only noted when they differ from the uo' / vo' (uc, vc)
-// the cell holds; bit patterns are compared, so a NaN that nan_to_num turned into 0 counts as changed
-__device__ __forceinline__ void qt_put_uv(unsigned int* fixc, unsigned long long* fixl, qt_rsrc UO, qt_rsrc VO, unsigned row_elems, unsigned vs,
+// the cell holds; bit patterns are compared, so a NaN that nan_to_num turned into 0 counts as changed.  The notes of a strip are staged
+// in LDS by the strip's currents wave (the only wave of the workgroup that makes any: a plain counter, no atomic) and go to the list
+// behind ONE returning global atomic per strip (qt_fix_flush) -- returning atomics on one word serialise at ~90 per us, and one per
+// row with a hit put ten extra round trips on the critical path of exactly the strips that were the slow ones already (polar
+// currents at the cap).  A strip with more notes than the stage holds appends the rest directly.
+#define QT_FIX_STAGE 512                   // entries of 24 bytes
+struct QtFixW { unsigned int* fixc; unsigned long long* fixl; unsigned long long* stage; unsigned int* nstage; };
+__device__ __forceinline__ void qt_put_uv(const QtFixW& X, qt_rsrc UO, qt_rsrc VO, unsigned row_elems, unsigned vs,
                                           double u, double v, double uc, double vc) {
-    if (!fixc) { qt_st(UO, row_elems, vs, u); qt_st(VO, row_elems, vs, v); return; }
+    if (!X.fixc) { qt_st(UO, row_elems, vs, u); qt_st(VO, row_elems, vs, v); return; }
     const unsigned long long ub = (unsigned long long)__double_as_longlong(u), vb = (unsigned long long)__double_as_longlong(v);
     const bool ch = vs != 0x80000000u && (ub != (unsigned long long)__double_as_longlong(uc) || vb != (unsigned long long)__double_as_longlong(vc));
-    if (__builtin_amdgcn_ballot_w64(ch) != 0ull) {
-        if (ch) {
-            const unsigned k = __hip_atomic_fetch_add(fixc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned long long* e = fixl + (size_t)3 * k;
-            __hip_atomic_store(e, (unsigned long long)row_elems * 8ull + (unsigned long long)vs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(e + 1, ub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(e + 2, vb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long chm = __builtin_amdgcn_ballot_w64(ch);
+    if (chm != 0ull) {
+        const int lane = (int)(threadIdx.x & 63u);
+        const unsigned cnt = (unsigned)__popcll(chm);
+        const unsigned base = __hip_atomic_load(X.nstage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);    // wave-uniform: this wave is the only writer
+        const unsigned k = base + (unsigned)__popcll(chm & ((1ull << lane) - 1ull));
+        const unsigned long long off = (unsigned long long)row_elems * 8ull + (unsigned long long)vs;
+        if (base + cnt <= (unsigned)QT_FIX_STAGE) {
+            if (ch) { X.stage[3u * k] = off; X.stage[3u * k + 1u] = ub; X.stage[3u * k + 2u] = vb; }
+            if (lane == 0) __hip_atomic_store(X.nstage, base + cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        } else {
+            const int leader = __ffsll((long long)chm) - 1;
+            unsigned g = 0;
+            if (lane == leader) g = __hip_atomic_fetch_add(X.fixc, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            g = (unsigned)__shfl((int)g, leader, 64);
+            if (ch) {
+                unsigned long long* e = X.fixl + (size_t)3 * (g + (k - base));
+                __hip_atomic_store(e, off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(e + 1, ub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(e + 2, vb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
+}
+// end of the strip (all 64 lanes of the currents wave): the staged notes go to the list
+__device__ __forceinline__ void qt_fix_flush(const QtFixW& X) {
+    if (!X.fixc) return;
+    const unsigned n = __hip_atomic_load(X.nstage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    if (n == 0u) return;
+    const int lane = (int)(threadIdx.x & 63u);
+    unsigned g = 0;
+    if (lane == 0) g = __hip_atomic_fetch_add(X.fixc, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    g = (unsigned)__shfl((int)g, 0, 64);
+    for (unsigned w = (unsigned)lane; w < 3u * n; w += 64u)
+        __hip_atomic_store(X.fixl + (size_t)3 * g + w, X.stage[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) __hip_atomic_store(X.nstage, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
 struct QtW { int n, m, lane, j, o0, o1; unsigned vo, vs, vo8, slab; bool own; int lbase, lrows, own0, own1, jbase; };      // lbase / lrows: the slab (band handles); own0 / own1: rows whose eta enters the sum
@@ -140,7 +173,7 @@ __device__ __forceinline__ unsigned qt_row(const QtW& W, int g) {
 __device__ __forceinline__ unsigned qt_row_roll(const QtW& W, int g) { if (g < 0) g += W.n; else if (g >= W.n) g -= W.n; return qt_row(W, g); }
 
 // ---- wave 0: continuity (ocean.py:365-374) + outlier filter and caps (ocean.py:409-434)
-__device__ __forceinline__ double qt_currents_wave(const QdTabs& T, const QdTailArgs& P, const QtW& W) {
+__device__ __forceinline__ double qt_currents_wave(const QdTabs& T, const QdTailArgs& P, const QtW& W, const QtFixW& FX = QtFixW{nullptr, nullptr, nullptr, nullptr}) {
     const unsigned sb = W.slab;
     const qt_rsrc U = qt_make_rsrc(P.uo, sb), V = qt_make_rsrc(P.vo, sb), E = qt_make_rsrc(P.eta, sb), L = qt_make_rsrc(P.land, sb / 8u);
     const qt_rsrc EI = qt_make_rsrc(P.eta_in ? P.eta_in : P.eta, sb);       // (k_ocn_fused's sequential form reads eta' from a slab of its own)
@@ -191,7 +224,7 @@ __device__ __forceinline__ double qt_currents_wave(const QdTabs& T, const QdTail
                 u = u * sc; v = v * sc;
             }
         }
-        qt_put_uv(P.fix_count, P.fix_list, UO, VO, r0, W.vs, u, v, uc, vc);
+        qt_put_uv(FX, UO, VO, r0, W.vs, u, v, uc, vc);
         us = uc; uc = un; vs = vc; vc = vn;
     }
     return acc;
@@ -424,7 +457,7 @@ __device__ __forceinline__ void qfu_wait_gt(const int* p, int row) {          //
 __device__ __forceinline__ double qfu_ring_ld(const double* plane, int row, int lane) { return plane[(row & (QFU_NR - 1)) * 64 + lane]; }
 
 struct QtCurSlot { double u, v, e; int l; qt_f64x2 k0, k1; };
-struct QtCurK { double dlon2, r_2dlon, dlat2, r_2dlat, msdtH, cap, cap81; int mean4; unsigned int* fixc = nullptr; unsigned long long* fixl = nullptr; };
+struct QtCurK { double dlon2, r_2dlon, dlat2, r_2dlat, msdtH, cap, cap81; int mean4; QtFixW fx = QtFixW{nullptr, nullptr, nullptr, nullptr}; };
 
 // one row of the continuity + caps wave away from the poles; `ro`: element offset of row g in the slab
 // RING: u, v of row g + 1 and eta of row g come from the LDS ring of k_ocn_fused (R), everything else as before
@@ -465,7 +498,7 @@ __device__ __forceinline__ void qt_cur_fast_step(const QtCurK& P, const QtW& W, 
             u = u * sc; v = v * sc;
         }
     }
-    qt_put_uv(P.fixc, P.fixl, UO, VO, ro, W.vs, u, v, uc, vc);
+    qt_put_uv(P.fx, UO, VO, ro, W.vs, u, v, uc, vc);
     us = uc; uc = un; vs = vc; vc = vn;
     if (RING) { if (W.lane == 0) __hip_atomic_store(R->prog + 3, g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }     // rows <= g are done with
     __builtin_amdgcn_sched_barrier(0);
@@ -476,7 +509,7 @@ __device__ __forceinline__ void qt_cur_fast_step(const QtCurK& P, const QtW& W, 
     __builtin_amdgcn_sched_barrier(0);                       // (else the next step's arithmetic is scheduled in front of these loads)
 }
 
-__device__ __forceinline__ double qt_currents_fast(const QdTailArgs& P, const QtW& W) {
+__device__ __forceinline__ double qt_currents_fast(const QdTailArgs& P, const QtW& W, const QtFixW& FX = QtFixW{nullptr, nullptr, nullptr, nullptr}) {
     const unsigned sb = W.slab, m = (unsigned)W.m;
     const qt_rsrc U = qt_make_rsrc(P.uo, sb), V = qt_make_rsrc(P.vo, sb), E = qt_make_rsrc(P.eta, sb), L = qt_make_rsrc(P.land, sb / 8u);
     const qt_rsrc UO = qt_make_rsrc(P.uo_out, sb), VO = qt_make_rsrc(P.vo_out, sb), KT = qt_make_rsrc(P.tab, (unsigned)W.n * 128u);
@@ -487,7 +520,7 @@ __device__ __forceinline__ double qt_currents_fast(const QdTailArgs& P, const Qt
     QtCurK K;
     K.dlon2 = qt_vreg(2 * P.dlon); K.r_2dlon = qt_vreg(P.r_2dlon); K.dlat2 = qt_vreg(2 * P.dlat); K.r_2dlat = qt_vreg(P.r_2dlat);
     K.msdtH = qt_vreg(P.msdtH); K.cap = qt_vreg(P.cap); K.cap81 = qt_vreg(0.81 * (P.cap * P.cap)); K.mean4 = P.mean4;
-    K.fixc = P.fix_count; K.fixl = P.fix_list;
+    K.fx = FX;
     QtCurSlot a, b;
     a.u = qt_ld(U, ro + m, W.vo); a.v = qt_ld(V, ro + m, W.vo); a.e = qt_ld(E, ro, W.vo); a.l = qt_ld8(L, ro, W.vo8);
     a.k0 = qt_ldk(KT, 16u * (unsigned)W.o0, 4u); a.k1 = qt_ldk(KT, 16u * (unsigned)W.o0, 5u);
@@ -668,7 +701,12 @@ k_ocn_tail_fast(QdGeom G, QdTabs T, QdTailArgs P) {
         __syncthreads();                                     // fix list: this strip's ticket is taken when BOTH its waves have read their uo', vo'
         return;
     }
-    double acc = (plain && W.o0 >= 1 && W.o1 <= W.n - 1) ? qt_currents_fast(P, W) : qt_currents_wave(T, P, W);
+    __shared__ unsigned long long s_fix[3 * QT_FIX_STAGE];
+    __shared__ unsigned int s_nfix;
+    const QtFixW FX{P.fix_count, P.fix_list, s_fix, &s_nfix};
+    if (P.fix_count && W.lane == 0) __hip_atomic_store(&s_nfix, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);             // (this wave is the only one that touches the stage: its LDS accesses are in order)
+    double acc = (plain && W.o0 >= 1 && W.o1 <= W.n - 1) ? qt_currents_fast(P, W, FX) : qt_currents_wave(T, P, W, FX);
+    qt_fix_flush(FX);
     QT_STAMP(2);
     if (P.fix_count) __syncthreads();
     acc = qt_wave_sum(acc);
@@ -683,13 +721,29 @@ k_ocn_tail_fast(QdGeom G, QdTabs T, QdTailArgs P) {
                 // every wave of the launch is done with uo', vo': the noted cells get their uo'' / vo'' in place (entries and count were
                 // written with agent-scope atomics before their strips' tickets: qd_acc_arrive waits for them)
                 const unsigned nfix = __hip_atomic_load(P.fix_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                for (unsigned k = (unsigned)W.lane; k < nfix; k += 64u) {
-                    const unsigned long long* e = P.fix_list + (size_t)3 * k;
-                    const unsigned long long off = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    *(unsigned long long*)((char*)const_cast<double*>(P.uo) + off) = __hip_atomic_load(e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    *(unsigned long long*)((char*)const_cast<double*>(P.vo) + off) = __hip_atomic_load(e + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // one wave, eight entries per lane in flight: the loop is a chain of round trips, 512 entries each
+                for (unsigned k0 = 0; k0 < nfix; k0 += 512u) {
+                    unsigned long long off[8], ub[8], vb[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const unsigned k = k0 + (unsigned)q * 64u + (unsigned)W.lane;
+                        const unsigned long long* e = P.fix_list + (size_t)3 * (k < nfix ? k : nfix - 1u);
+                        off[q] = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ub[q] = __hip_atomic_load(e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        vb[q] = __hip_atomic_load(e + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        if (k0 + (unsigned)q * 64u + (unsigned)W.lane >= nfix) continue;
+                        *(unsigned long long*)((char*)const_cast<double*>(P.uo) + off[q]) = ub[q];
+                        *(unsigned long long*)((char*)const_cast<double*>(P.vo) + off[q]) = vb[q];
+                    }
                 }
-                if (W.lane == 0) __hip_atomic_store(P.fix_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (W.lane == 0) {
+                    __hip_atomic_store(P.fix_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // statistics (QD_TAIL_FIX_DEBUG prints them when the handle is destroyed): entries of all launches, launches, the longest list
+                    P.fix_count[4] += nfix; P.fix_count[5] += 1u; if (nfix > P.fix_count[6]) P.fix_count[6] = nfix;
+                }
             }
         }
     }

@@ -155,6 +155,11 @@ __device__ __forceinline__ void qp_hook_pre(const QdPeerHook& H, unsigned long l
                 ((double*)data)[2 * s] = a; ((double*)data)[2 * s + 1] = b;
             }
         }
+        if (t == 0 && H.fixstat) {
+            const unsigned e = H.fixstat[4], l = H.fixstat[5];
+            ((double*)data)[6] = l ? (double)e / (double)l : -2.0;
+            H.fixstat[4] = 0u; H.fixstat[5] = 0u;
+        }
     }
     __syncthreads();                                              // workgroup 0 deposits what thread 0 has just written
 }
