@@ -456,25 +456,41 @@ __device__ __forceinline__ void qd_med_hist_body(const QdGeom& G, const double* 
     const bool valid = pred[3] != 0.0;
     const unsigned long long base = qd_med_window_base(valid, pred[0]);
     if (mode != 2) {
-        for (int k = t; k < QD_HIST_BINS + 2; k += QD_BLOCK) sh[k] = 0u;
-        __syncthreads();
         const int jstep = nblk_x * QD_BLOCK;
         unsigned int n_pos = 0, n_below = 0;
-        for (int i = G.row0 + by; i < G.row0 + G.nrows; i += nblk_y) {
-            const size_t b = (size_t)qd_lrow(G, i) * G.nlon;
-            for (int jb = bx * QD_BLOCK; jb < G.nlon; jb += 8 * jstep) {
-                double vbuf[8];
+        const int i_end = G.row0 + G.nrows;
+        // the NEXT batch (the next column block of the row, or the next row of this workgroup) is in flight while this one is binned: a
+        // workgroup has three rows at 721 x 1440, and three dependent round trips were a quarter of the launch
+        double vbuf[8];
+        {
+            const int i0 = G.row0 + by;
+            const size_t b0 = (size_t)qd_lrow(G, i0 < i_end ? i0 : i_end - 1) * G.nlon;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int j = jb + q * jstep + t;
-                    vbuf[q] = x[b + (j < G.nlon ? j : G.nlon - 1)];
+            for (int q = 0; q < 8; ++q) { const int j = bx * QD_BLOCK + q * jstep + t; vbuf[q] = x[b0 + (j < G.nlon ? j : G.nlon - 1)]; }
+        }
+        for (int k = t; k < QD_HIST_BINS + 2; k += QD_BLOCK) sh[k] = 0u;      // (behind the first loads: they fly while the bins are cleared)
+        __syncthreads();
+        for (int i = G.row0 + by; i < i_end; i += nblk_y) {
+            for (int jb = bx * QD_BLOCK; jb < G.nlon; jb += 8 * jstep) {
+                double cur[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) cur[q] = vbuf[q];
+                {
+                    const bool more_cols = jb + 8 * jstep < G.nlon;
+                    const int in = more_cols ? i : i + nblk_y;
+                    const int jn = more_cols ? jb + 8 * jstep : bx * QD_BLOCK;
+                    if (in < i_end) {
+                        const size_t bn = (size_t)qd_lrow(G, in) * G.nlon;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) { const int j = jn + q * jstep + t; vbuf[q] = x[bn + (j < G.nlon ? j : G.nlon - 1)]; }
+                    }
                 }
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int j0 = jb + q * jstep;
                     if (j0 >= G.nlon) break;
                     const int j = j0 + t;
-                    const double v = (j < G.nlon) ? qd_med_value(vbuf[q], transform, tparam) : 0.0;
+                    const double v = (j < G.nlon) ? qd_med_value(cur[q], transform, tparam) : 0.0;
                     const bool pos = v > 0.0;
                     const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
                     n_pos += pos ? 1u : 0u;
