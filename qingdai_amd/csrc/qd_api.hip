@@ -679,7 +679,7 @@ extern "C" int qd_step_n(qd_handle c, int n, double dt, int flags, const double*
     if (with_eco && !with_phys) return qd_fail(c, "qd_step_n: the ecology sub-step (bit5) needs the driver physics (bit1)");
     if (with_eco && !c->eco.configured) return qd_fail(c, "qd_step_n: bit5 set but qd_eco_configure has not been called");
     // whatever way this call ends, the per-span switches are back to what a stand-alone qd_* call expects
-    struct SpanGuard { qd_ctx* c; ~SpanGuard() { c->diag_write = 1; c->want_pcond_ahead = 0; c->pcond_ahead = 0; c->defer_final = 0; } } span_guard{c};
+    struct SpanGuard { qd_ctx* c; ~SpanGuard() { c->diag_write = 1; c->want_pcond_ahead = 0; c->pcond_ahead = 0; c->defer_final = 0; c->final_pending.on = 0; } } span_guard{c};
     for (int s = 0; s < n; ++s) {
         const double* st = stars + (size_t)7 * s;
         int rc;
