@@ -414,6 +414,7 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
         if ((e = hipMalloc(&c->wgmax, (size_t)2 * c->n_wgmax * sizeof(double))) != hipSuccess) return bail("hipMalloc", e);
         { const char* ef = std::getenv("QD_MED_SIDE"); if (ef) c->med_side = ef[0] == '0' ? 0 : 1; }
         { const char* ef = std::getenv("QD_MED_PAIR"); if (ef) c->med_pair = ef[0] == '0' ? 0 : 1; }
+        { const char* ef = std::getenv("QD_MED_FOLD"); if (ef) c->med_fold = ef[0] == '0' ? 0 : 1; }
         if (c->med_side) {
             if ((e = hipEventCreateWithFlags(&c->med_fork, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
             if ((e = hipEventCreateWithFlags(&c->med_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);

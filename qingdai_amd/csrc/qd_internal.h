@@ -233,6 +233,7 @@ struct qd_ctx {
     // is done too; qd_atmos_step_impl joins).  Its median has buffers of its own (qd_reduce.hip).
     int med_pair = 1;                // QD_MED_PAIR=0: the precipitation median and the P_cond median as two chains of three launches instead of one
                                      // (whole-globe qd_step_n: k_column<1> moves in front of the cloud block, pcond_ahead = 3)
+    int med_fold = 0;                // QD_MED_FOLD=1 (experiment, slower): no k_column<1> launch -- the pair's histogram pass computes, stores and bins P_cond (k_med_hist2p)
     int med_side = 0;
     bool med_side_active = false;    // set around the side median's qd_median_positive_dev call
     hipEvent_t med_fork = nullptr, med_done = nullptr;
@@ -357,6 +358,10 @@ int qd_exchange(qd_ctx* c, const QdUse* slots, int n);
 struct QdSegList { QdGeom g[6]; int n; };
 QdSegList qd_segments_rows(qd_ctx* c, int vr0, int cnt, QdSegList S = QdSegList{{}, 0});   // rows [vr0, vr0 + cnt) of the ring (period n_lat), appended to S
 int qd_side_join(qd_ctx* c);
+bool qd_median_pair_ready(const qd_ctx* c, int site0, int site1);
+struct QdColP;
+int qd_median_pair_pcond_dev(qd_ctx* c, const double* x0, double dflt0, int slot0, int tr0, double tp0, int site0,
+                             const QdColP& P, double dflt1, int slot1, int site1);      // ... with time_step's P_cond produced by the histogram pass
 int qd_pcond_phase1(qd_ctx* c, double dt);        // qd_atmos.hip: k_column<1> on the handle's stream (whole globe)
 int qd_pcond_median_side(qd_ctx* c, double dt);   // qd_atmos.hip: k_column<1> + the P_cond median on the side stream (fork here, join in qd_atmos_step_impl)         // the main stream waits for what the side stream holds (no-op when nothing is pending)
 int qd_plan_begin(qd_ctx* c, const QdUse* in, int n, bool* pending);

@@ -480,8 +480,13 @@ int qd_driver_physics_impl(qd_ctx* c, double dt, const QdForcingCall* fc, int pa
         } else if (pcond_pair) {
             // time_step's P_cond (phase 1 of its column) is computed HERE, so that its median and the precipitation median go through
             // ONE chain of three launches (qd_median_pair_dev); time_step then starts with the column's phase 2
-            if (qd_pcond_phase1(c, dt)) return -1;
-            if (qd_median_pair_dev(c, F[QD_F_PRECIP], 1e-6, QD_S_MED_OUT, 0, 0.0, 3, F[QD_F_PCOND], 1e-6, QD_S_PREF, 0, 0.0, 1)) return -1;
+            if (c->med_fold && qd_median_pair_ready(c, 3, 1)) {
+                // ... and P_cond itself comes out of the pair's histogram pass (k_med_hist2p): no k_column<1> launch
+                if (qd_median_pair_pcond_dev(c, F[QD_F_PRECIP], 1e-6, QD_S_MED_OUT, 0, 0.0, 3, qd_make_colp(c, dt), 1e-6, QD_S_PREF, 1)) return -1;
+            } else {
+                if (qd_pcond_phase1(c, dt)) return -1;
+                if (qd_median_pair_dev(c, F[QD_F_PRECIP], 1e-6, QD_S_MED_OUT, 0, 0.0, 3, F[QD_F_PCOND], 1e-6, QD_S_PREF, 0, 0.0, 1)) return -1;
+            }
             c->pcond_ahead = 3;
         } else {
             if (qd_median_positive_dev(c, F[QD_F_PRECIP], 1e-6, QD_S_MED_OUT, 0, 0.0, 3)) return -1;

@@ -11,6 +11,7 @@
 // two middle ranks at once for even counts.
 #include "qd_internal.h"
 #include "qd_band.h"
+#include "qd_fluxes.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -730,6 +731,66 @@ k_med_hist2(QdGeom G, QdMedJob J0, QdMedJob J1) {
     const QdMedJob& J = blockIdx.z ? J1 : J0;
     qd_med_hist_body(G, J.x, J.transform, J.tparam, J.pred, J.hist, 1, (int)gridDim.x, (int)gridDim.y, (int)blockIdx.x, (int)blockIdx.y);
 }
+// k_med_hist2 whose second job PRODUCES its field: time_step's P_cond (phase 1 of the column: dynamics.py:282-297, the humidity column of
+// qd_fluxes.h -- the same device function k_column runs, so the same bits) is computed, stored and binned in one go; k_column<1> was a
+// launch of 13 us in front of the pair.  Workgroups [0, nb0) are job 0's fat workgroups (qd_med_hist_body), [nb0, 2 nb0) job 1's.
+struct QdPcondSrc { QdColP P; const double *u, *v, *h, *Ts, *q, *hice; const uint8_t* land; double* Pcond; };
+__global__ void __launch_bounds__(QD_BLOCK)
+k_med_hist2p(QdGeom G, QdMedJob J0, QdMedJob J1, QdPcondSrc S, int nb0) {
+    if ((int)blockIdx.y < nb0) {
+        qd_med_hist_body(G, J0.x, J0.transform, J0.tparam, J0.pred, J0.hist, 1, 1, nb0, 0, (int)blockIdx.y);
+        return;
+    }
+    // job 1: as few, fat workgroups as job 0; six cells per thread in flight.  MEASURED, and off by default (QD_MED_FOLD): 30.0 us for this
+    // launch against 12.9 (k_med_hist2) + 13.4 (k_column<1>) -- a cell of the humidity column is two f64 exponentials, and a histogram
+    // pass wants few workgroups (every one flushes its non-zero bins with global atomics: one workgroup per row, 721 flushes, 32.8 us)
+    // while the exponentials want four waves per SIMD to hide their dependent latencies, not one
+    __shared__ unsigned int sh[QD_HIST_BINS + 2];
+    const int t = threadIdx.x, lane = t & 63;
+    const int nb1 = (int)gridDim.y - nb0, by = (int)blockIdx.y - nb0;
+    const bool valid = J1.pred[3] != 0.0;
+    const unsigned long long base = qd_med_window_base(valid, J1.pred[0]);
+    for (int k = t; k < QD_HIST_BINS + 2; k += QD_BLOCK) sh[k] = 0u;
+    __syncthreads();
+    unsigned int n_pos = 0, n_below = 0;
+    constexpr int NC = 6;
+    for (int i = G.row0 + by; i < G.row0 + G.nrows; i += nb1) {
+        const size_t b = (size_t)qd_lrow(G, i) * G.nlon;
+        for (int jb = 0; jb < G.nlon; jb += NC * QD_BLOCK) {
+            double u_[NC], v_[NC], h_[NC], t_[NC], q_[NC], hi_[NC]; int l_[NC];
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                const int j = jb + k * QD_BLOCK + t;
+                const size_t o = b + (j < G.nlon ? j : G.nlon - 1);
+                u_[k] = S.u[o]; v_[k] = S.v[o]; h_[k] = S.h[o]; t_[k] = S.Ts[o]; q_[k] = S.q[o]; hi_[k] = S.hice[o]; l_[k] = (int)S.land[o];
+            }
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                const int j = jb + k * QD_BLOCK + t;
+                if (j >= G.nlon) continue;
+                const double qsat_air = qd_qsat(288.0 + S.P.ga * h_[k], S.P.p0);
+                const double v = qd_humidity_column(S.P, u_[k], v_[k], t_[k], q_[k], qsat_air, l_[k] == 1, hi_[k]).Pc;
+                S.Pcond[b + j] = v;
+                const bool pos = v > 0.0;
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+                n_pos += pos ? 1u : 0u;
+                const bool below = pos && bits < base;
+                n_below += below ? 1u : 0u;
+                const unsigned long long idx = (bits - base) >> QD_MED_WSHIFT;
+                if (pos && !below && idx < (unsigned long long)QD_HIST_BINS) atomicAdd(&sh[(unsigned int)idx], 1u);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { n_pos += __shfl_down(n_pos, o, 64); n_below += __shfl_down(n_below, o, 64); }
+    if (lane == 0) {
+        if (n_pos) atomicAdd(&sh[QD_HIST_BINS], n_pos);
+        if (n_below) atomicAdd(&sh[QD_HIST_BINS + 1], n_below);
+    }
+    __syncthreads();
+    for (int k = t; k < QD_HIST_BINS + 2; k += QD_BLOCK) if (sh[k]) atomicAdd(&J1.hist[k], sh[k]);
+}
+
 __global__ void __launch_bounds__(QD_BLOCK)
 k_med_scan_bracket2(QdGeom G, QdMedJob J0, QdMedJob J1, unsigned int cap) {
     const QdMedJob& J = blockIdx.z ? J1 : J0;
@@ -1009,6 +1070,28 @@ __global__ void k_sel_finish(unsigned long long* st, double dflt, double* out, u
 
 // Two medians at once (see k_med_hist2): job 0 on the handle's first set of median buffers, job 1 on the second (hist_b ...).  Falls back to
 // two calls in a row when a site has no window yet, or the handle has no second set.
+// both sites have a window and the handle has the second set of buffers: the pair runs as ONE chain (else: two calls in a row)
+bool qd_median_pair_ready(const qd_ctx* c, int site0, int site1) {
+    return c->geo.full && c->sel_cand && c->med_pred && c->med_predict && c->hist_b && site0 >= 0 && site0 < QD_MED_SITES &&
+           site1 >= 0 && site1 < QD_MED_SITES && site0 != site1 && c->med_seen[site0] && c->med_seen[site1];
+}
+// the pair with job 1 = time_step's P_cond, produced by the histogram pass itself (k_med_hist2p); only when qd_median_pair_ready
+int qd_median_pair_pcond_dev(qd_ctx* c, const double* x0, double dflt0, int slot0, int tr0, double tp0, int site0,
+                             const QdColP& P, double dflt1, int slot1, int site1) {
+    if (!qd_median_pair_ready(c, site0, site1)) return qd_fail(c, "qd_median_pair_pcond_dev: the pair is not ready");
+    const QdGeom G = qd_segments(c, 0).g[0];
+    const int nb0 = std::min(G.nrows, c->tune.med_blocks);
+    double** F = c->f;
+    const QdMedJob J0{x0, tr0, tp0, dflt0, c->med_pred + 16 * site0, c->hist, c->sel_state, c->sel_cand, c->sel_ccount, c->dscal + slot0, c->dcount};
+    const QdMedJob J1{F[QD_F_PCOND], 0, 0.0, dflt1, c->med_pred + 16 * site1, c->hist_b, c->sel_state_b, c->sel_cand_b, c->sel_ccount_b,
+                      c->dscal + slot1, c->dcount + 8};
+    const QdPcondSrc S{P, F[QD_F_U], F[QD_F_V], F[QD_F_H], F[QD_F_TS], F[QD_F_Q], F[QD_F_HICE], c->land, F[QD_F_PCOND]};
+    hipLaunchKernelGGL(k_med_hist2p, dim3(1, 2 * nb0), dim3(QD_BLOCK), 0, c->stream, G, J0, J1, S, nb0);
+    hipLaunchKernelGGL(k_med_scan_bracket2, dim3(1, nb0, 2), dim3(QD_BLOCK), 0, c->stream, G, J0, J1, (unsigned int)c->geo.cells());
+    hipLaunchKernelGGL(k_med_final2, dim3(2), dim3(QD_FIN_BLOCK), 0, c->stream, J0, J1, (unsigned long long)c->geo.cells());
+    return 0;
+}
+
 int qd_median_pair_dev(qd_ctx* c, const double* x0, double dflt0, int slot0, int tr0, double tp0, int site0,
                        const double* x1, double dflt1, int slot1, int tr1, double tp1, int site1) {
     const bool ok = c->geo.full && c->sel_cand && c->med_pred && c->med_predict && c->hist_b && site0 >= 0 && site0 < QD_MED_SITES &&

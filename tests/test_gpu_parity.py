@@ -573,7 +573,7 @@ def test_lazy_diagnostics_and_the_merged_pcond_launch_change_nothing_at_the_end_
     st = _seed_state(nlat, nlon, 5)
     static = {"LAND_MASK": mask, "FRICTION": fric, "BASE_ALBEDO": alb}
 
-    def run(lazy, merge, side="0", pair="0"):
+    def run(lazy, merge, side="0", pair="0", fold="0"):
         # the flags of bench.py's span (ocean + driver physics + albedo handed to time_step, no hydrology commit): the ones both
         # switches act on.  side = QD_MED_SIDE: k_column<1> + the P_cond median on a second stream beside the driver physics' launches
         monkeypatch.setenv("QD_LAZY_DIAG", lazy)
@@ -582,6 +582,8 @@ def test_lazy_diagnostics_and_the_merged_pcond_launch_change_nothing_at_the_end_
         # pair = QD_MED_PAIR: k_column<1> in front of the cloud block, the precipitation median and the P_cond median in ONE chain of
         # three launches (k_med_hist2 / k_med_scan_bracket2 / k_med_final2)
         monkeypatch.setenv("QD_MED_PAIR", pair)
+        # fold = QD_MED_FOLD: no k_column<1> at all -- the pair's histogram pass computes, stores and bins P_cond (k_med_hist2p)
+        monkeypatch.setenv("QD_MED_FOLD", fold)
         dev = Device(grid, p)
         for k, v in {**static, **st}.items():
             dev.upload_now(k, v)
@@ -594,11 +596,12 @@ def test_lazy_diagnostics_and_the_merged_pcond_launch_change_nothing_at_the_end_
         dev.close()
         return out
     ref = run("0", "0")
-    for lazy, merge, side, pair in (("1", "1", "0", "0"), ("1", "0", "0", "0"), ("0", "1", "0", "0"), ("1", "1", "1", "0"), ("0", "0", "1", "0"),
-                                    ("1", "1", "0", "1"), ("0", "0", "0", "1")):
-        got = run(lazy, merge, side, pair)
+    for lazy, merge, side, pair, fold in (("1", "1", "0", "0", "0"), ("1", "0", "0", "0", "0"), ("0", "1", "0", "0", "0"), ("1", "1", "1", "0", "0"),
+                                          ("0", "0", "1", "0", "0"), ("1", "1", "0", "1", "0"), ("0", "0", "0", "1", "0"), ("1", "1", "0", "1", "1"),
+                                          ("0", "0", "0", "1", "1")):
+        got = run(lazy, merge, side, pair, fold)
         for k in names:
-            assert np.array_equal(got[k], ref[k], equal_nan=True), (lazy, merge, side, pair, k)
+            assert np.array_equal(got[k], ref[k], equal_nan=True), (lazy, merge, side, pair, fold, k)
 
 
 def test_cloud_source_propagates_nan_like_the_reference(gpu):
