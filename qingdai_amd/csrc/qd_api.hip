@@ -380,6 +380,7 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
     hipMemsetAsync(c->hist, 0, 2 * QD_HIST_BINS * sizeof(unsigned int), c->stream);
     hipMemsetAsync(c->sel_state, 0, 8 * sizeof(unsigned long long), c->stream);
     { const char* ef = std::getenv("QD_TAIL_FIX"); if (ef) c->tail_fix = ef[0] == '0' ? 0 : 1; }
+    c->fix_dense = 256.0 * (double)c->geo.cells() / (721.0 * 1440.0);        // measured at 721 x 1440; the patch loop's share of a launch goes with entries per cell
     { const char* ef = std::getenv("QD_TAIL_FIX_DENSE"); if (ef) c->fix_dense = std::atof(ef); }
     { const char* ef = std::getenv("QD_LAZY_DIAG"); if (ef) c->lazy_diag = ef[0] == '0' ? 0 : 1; }
     if (c->tail_fix) {                                        // list of the cells whose currents the ocean tail kernel changes (qd_ocntail.h)
