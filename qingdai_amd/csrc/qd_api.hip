@@ -416,6 +416,7 @@ extern "C" int qd_create(const qd_grid_desc* d, const qd_params* params, double 
         { const char* ef = std::getenv("QD_MED_SIDE"); if (ef) c->med_side = ef[0] == '0' ? 0 : 1; }
         { const char* ef = std::getenv("QD_MED_PAIR"); if (ef) c->med_pair = ef[0] == '0' ? 0 : 1; }
         { const char* ef = std::getenv("QD_MED_FOLD"); if (ef) c->med_fold = ef[0] == '0' ? 0 : 1; }
+        { const char* ef = std::getenv("QD_MERGE_SAF"); if (ef) c->merge_saf = ef[0] == '0' ? 0 : 1; }
         if (c->med_side) {
             if ((e = hipEventCreateWithFlags(&c->med_fork, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
             if ((e = hipEventCreateWithFlags(&c->med_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
@@ -476,6 +477,7 @@ extern "C" int qd_destroy(qd_handle c) {
     if (c->red_partial) hipFree(c->red_partial); if (c->dscal) hipFree(c->dscal);
     if (c->red_partial_b) hipFree(c->red_partial_b);
     if (c->wgmax) hipFree(c->wgmax);
+    qd_saf_drop(c);
     if (c->fix_count && std::getenv("QD_TAIL_FIX_DEBUG")) {
         unsigned int h[8] = {0};
         if (hipMemcpy(h, c->fix_count, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess)
@@ -681,7 +683,7 @@ extern "C" int qd_step_n(qd_handle c, int n, double dt, int flags, const double*
     if (with_eco && !with_phys) return qd_fail(c, "qd_step_n: the ecology sub-step (bit5) needs the driver physics (bit1)");
     if (with_eco && !c->eco.configured) return qd_fail(c, "qd_step_n: bit5 set but qd_eco_configure has not been called");
     // whatever way this call ends, the per-span switches are back to what a stand-alone qd_* call expects
-    struct SpanGuard { qd_ctx* c; ~SpanGuard() { c->diag_write = 1; c->want_pcond_ahead = 0; c->pcond_ahead = 0; c->defer_final = 0; c->final_pending.on = 0; } } span_guard{c};
+    struct SpanGuard { qd_ctx* c; ~SpanGuard() { c->diag_write = 1; c->want_pcond_ahead = 0; c->pcond_ahead = 0; c->defer_final = 0; c->final_pending.on = 0; qd_saf_drop(c); } } span_guard{c};
     for (int s = 0; s < n; ++s) {
         const double* st = stars + (size_t)7 * s;
         int rc;
@@ -709,6 +711,7 @@ extern "C" int qd_step_n(qd_handle c, int n, double dt, int flags, const double*
         rc = qd_atmos_step_impl(c, dt, pass_alb ? 1 : 0);
         c->defer_final = 0;
         if (rc) return rc;
+        if (c->saf_pending && (rc = qd_saf_flush(c))) return rc;          // (never: the column block takes or flushes it)
         // bit4: energy-budget means of the FIRST step, taken where the reference driver takes them -- after time_step, on the
         // fluxes of the coupling block (run_simulation.py:2199-2246) -- and kept for qd_energy_diagnostics_last
         if (with_ocean && want_diag && s == 0 && (rc = qd_energy_diag_impl(c, c->last_diag))) return rc;

@@ -13,6 +13,7 @@
 #include "qd_internal.h"
 #include "qd_pointwise.h"
 #include "qd_device.h"
+#include "qd_saf.h"
 
 #include "qd_fluxes.h"
 #include "qd_fused.h"
@@ -32,15 +33,13 @@ struct QdColPtrs {
 //          P_cond, LH and LH_release and phase 2 to read them back -- 33 MB more written and the same number read as it costs phase 2
 //          to take q, u, v, T_s once more and redo ~100 f64 instructions; the humidity arithmetic is the same in both phases, so the
 //          P_cond phase 2 writes is the one the median saw.)
-template <int PHASE, bool HAS_ALB>
-__global__ void __launch_bounds__(QD_BLOCK)
-k_column(QdGeom G, QdColP P, QdColPtrs A) {
-    const QdTile tl = qd_tile();
-    const int j = tl.seg * QD_BLOCK + threadIdx.x;
-    if (j >= G.nlon) return;
-    const int i = G.row0 + tl.row;
-    const size_t o = (size_t)qd_lrow(G, i) * G.nlon + j;
+// what a stage in front of the column hands it in registers instead of through memory (k_saf_column2): the cloud cover after the tracer
+// blend, the insolation, the albedo and Teq of the cell
+struct QdColIn { double cloud, isr, albedo, teq; };
 
+// one cell of the column; IN = nullptr: everything from memory
+template <int PHASE, bool HAS_ALB>
+__device__ __forceinline__ void qd_column_cell(const QdColP& P, const QdColPtrs& A, size_t o, const QdColIn* IN, int i, int nlat) {
     const double u = A.u[o], v = A.v[o], h = A.h[o], Ts = A.Ts[o];
     const double hice = A.hice[o];
     const bool land = (A.land[o] == 1);
@@ -57,7 +56,7 @@ k_column(QdGeom G, QdColP P, QdColPtrs A) {
     if (P.write_diag) { A.E[o] = E; A.LHrel[o] = LHrel; }    // nobody inside a span reads these two (the hydrology commit asks for them: qd_step_n)
 
     // ---- Newton path: dynamics.py:304-322
-    const double Teq = A.Teq[o];
+    const double Teq = IN ? IN->teq : A.Teq[o];
     const double olr_old = P.sigma * qd_pow4(Ts);
     const double net_old = P.sigma * qd_pow4(Teq) + P.gfs * qd_pow4(T_a) - olr_old;
     const double Ts_newton = Ts + (net_old / P.c_sfc_safe) * P.dt;
@@ -66,7 +65,7 @@ k_column(QdGeom G, QdColP P, QdColPtrs A) {
     QdFlux F;
     if (HAS_ALB) {
         // ---- cloud optical consistency: dynamics.py:329-353
-        const double cloud = A.cloud[o];
+        const double cloud = IN ? IN->cloud : A.cloud[o];
         double cloud_eff;
         if (P.couple) {
             const double RH = qd_clip(q / qd_max(1e-12, qsat_air), 0.0, 1.5);
@@ -76,7 +75,7 @@ k_column(QdGeom G, QdColP P, QdColPtrs A) {
             cloud_eff = qd_clip(cloud + P.k_q * rh_excess + P.k_p * p_term, 0.0, 1.0);
         } else cloud_eff = cloud;
         A.cloud_eff[o] = cloud_eff;
-        F = qd_surface_fluxes(P, A.isr[o], A.albedo[o], cloud_eff, Ts, T_a, u, v, land, hice);
+        F = qd_surface_fluxes(P, IN ? IN->isr : A.isr[o], IN ? IN->albedo : A.albedo[o], cloud_eff, Ts, T_a, u, v, land, hice);
         double Ts_energy;
         if (P.seaice) {
             // ---- energy.py:291-420
@@ -96,7 +95,7 @@ k_column(QdGeom G, QdColP P, QdColPtrs A) {
             double Cs = land ? P.Cs_land : (hi > 0.0 ? P.Cs_ice : P.Cs_ocean);
             Cs = (isfinite(Cs) && Cs > 1e3) ? Cs : 1e3;
             Tn = Tn + (Q / Cs) * P.dt;
-            if ((i == 0 && P.fix_s) || (i == G.nlat - 1 && P.fix_n)) {
+            if ((i == 0 && P.fix_s) || (i == nlat - 1 && P.fix_n)) {
                 if (ocean && Q < 0.0 && Tn > P.t_freeze) Tn = P.t_freeze;
             }
             if (hi > 0.0 && ocean) Tn = qd_min(Tn, P.t_freeze);
@@ -126,6 +125,32 @@ k_column(QdGeom G, QdColP P, QdColPtrs A) {
         h_new = qd_nn(h_new + P.atm_w * (F_atm / P.atm_denom) * P.dt);
     }
     A.h[o] = h_new;
+}
+
+template <int PHASE, bool HAS_ALB>
+__global__ void __launch_bounds__(QD_BLOCK)
+k_column(QdGeom G, QdColP P, QdColPtrs A) {
+    const QdTile tl = qd_tile();
+    const int j = tl.seg * QD_BLOCK + threadIdx.x;
+    if (j >= G.nlon) return;
+    const int i = G.row0 + tl.row;
+    qd_column_cell<PHASE, HAS_ALB>(P, A, (size_t)qd_lrow(G, i) * G.nlon + j, nullptr, i, G.nlat);
+}
+
+// The driver physics' last launch (snowpack -> cloud blend + albedo -> insolation + Teq: qd_saf.h) as the first STAGE of the column's
+// phase 2 (whole-globe qd_step_n, when the P_cond median has run ahead of the cloud block and nothing separates the two launches any
+// more): the cloud cover, the albedo, the insolation and Teq reach the column in registers -- four fields not read back, Teq not even
+// stored inside a span -- and h, h_ice and the land mask are read once.  Same per-cell bodies as the two kernels: same bits.
+__global__ void __launch_bounds__(QD_BLOCK)
+k_saf_column2(QdSafArgs K, QdColP P, QdColPtrs A) {
+    const QdTile tl = qd_tile();
+    const int j = tl.seg * QD_BLOCK + threadIdx.x;
+    if (j >= K.G.nlon) return;
+    const int i = K.G.row0 + tl.row;
+    const size_t o = (size_t)qd_lrow(K.G, i) * K.G.nlon + j;
+    const QdSafOut s = qd_saf_cell(K, i, j, o, K.write_diag != 0);
+    const QdColIn in{s.cloud, s.isr, s.albedo, s.teq};
+    qd_column_cell<2, true>(P, A, o, &in, i, K.G.nlat);
 }
 
 // ------------------------------------------------------------------ momentum: dynamics.py:482-530
@@ -333,6 +358,8 @@ int qd_atmos_step_impl(qd_ctx* c, double dt, int has_albedo) {
     QdColP P = qd_make_colp(c, dt);
     const int R = qd_adv_reach(c, dt, 250.0);      // lat reach of the gather for |v| <= 250 m/s
 
+    // (a launch the driver physics left for the column kernel is flushed by every path that does not merge it)
+    if (c->saf_pending && !(has_albedo && p.cloud_couple && !qd_isset(p.pcond_ref) && c->pcond_ahead == 3) && qd_saf_flush(c)) return -1;
     {
         QdScope sc(c, "column");
         // pointwise: every input at radius 0
@@ -365,7 +392,16 @@ int qd_atmos_step_impl(qd_ctx* c, double dt, int has_albedo) {
             if (!ahead) QD_ROWS(c, m, G, hipLaunchKernelGGL((k_column<1, true>), qd_grid2d(G), blk, 0, c->stream, G, P, A));
             if (ahead == 2) QD_HIP(c, hipStreamWaitEvent(c->stream, c->med_done, 0));
             else if (ahead != 3 && qd_median_positive_dev(c, F[QD_F_PCOND], 1e-6, QD_S_PREF, 0, 0.0, 1)) return -1;
-            QD_ROWS(c, m, G, hipLaunchKernelGGL((k_column<2, true>), qd_grid2d(G), blk, 0, c->stream, G, P, A));
+            if (c->saf_pending && ahead == 3 && c->geo.full) {
+                // the driver physics left its last launch for this one (qd_physics.hip): one kernel does both
+                QdSafArgs* K = (QdSafArgs*)c->saf_pending;
+                c->saf_pending = nullptr;
+                hipLaunchKernelGGL(k_saf_column2, qd_grid2d(K->G), blk, 0, c->stream, *K, P, A);
+                delete K;
+            } else {
+                if (qd_saf_flush(c)) return -1;
+                QD_ROWS(c, m, G, hipLaunchKernelGGL((k_column<2, true>), qd_grid2d(G), blk, 0, c->stream, G, P, A));
+            }
         }
         qd_mark(c, {F[QD_F_H], F[QD_F_TS], F[QD_F_Q], F[QD_F_EFLUX], F[QD_F_PCOND], F[QD_F_LH], F[QD_F_LHREL], F[QD_F_OLR]}, m);
         if (has_albedo) { qd_mark(c, {F[QD_F_HICE], F[QD_F_CLOUD_EFF]}, m); c->cloud_eff_valid = 1; }

@@ -246,6 +246,12 @@ struct qd_ctx {
     unsigned long long* fix_list = nullptr;      // [cells][3]
     double fix_avg = 0.0;                        // entries per launch in the last step that used the list (k_max2_publish / the bands' CFL reduce)
     double fix_dense = 256.0;                    // QD_TAIL_FIX_DENSE: longer lists on average -> the storing form
+    // whole-globe qd_step_n with the P_cond median ahead of the cloud block (pcond_ahead == 3): the driver physics' last launch
+    // (k_snow_albedo_forcing) and time_step's column kernel are back to back -- the first becomes the first STAGE of the second
+    // (k_saf_column2, qd_atmos.hip: cloud, albedo, isr, Teq in registers, h / h_ice / land read once).  saf_pending: its argument block
+    // (a QdSafArgs, qd_saf.h) between qd_driver_physics_impl and qd_atmos_step_impl
+    int merge_saf = 1;               // QD_MERGE_SAF=0: two launches
+    void* saf_pending = nullptr;
     int defer_final = 0;             // set by qd_step_n around qd_atmos_step_impl
     int merge_final = 1;             // QD_MERGE_FINAL=0: keep the three launches
     struct { int on = 0; double dt = 0, decay = 0, dfac = 0; } final_pending;
@@ -362,6 +368,10 @@ bool qd_median_pair_ready(const qd_ctx* c, int site0, int site1);
 struct QdColP;
 int qd_median_pair_pcond_dev(qd_ctx* c, const double* x0, double dflt0, int slot0, int tr0, double tp0, int site0,
                              const QdColP& P, double dflt1, int slot1, int site1);      // ... with time_step's P_cond produced by the histogram pass
+struct QdSafArgs;
+int qd_saf_launch(qd_ctx* c, const QdSafArgs& K);  // qd_physics.hip: k_snow_albedo_forcing on the handle's stream
+void qd_saf_drop(qd_ctx* c);                       // qd_physics.hip: forget a pending launch (error paths, destroy)
+int qd_saf_flush(qd_ctx* c);                       // qd_physics.hip: a pending launch of it that nobody merged: now (no-op when none)
 int qd_pcond_phase1(qd_ctx* c, double dt);        // qd_atmos.hip: k_column<1> on the handle's stream (whole globe)
 int qd_pcond_median_side(qd_ctx* c, double dt);   // qd_atmos.hip: k_column<1> + the P_cond median on the side stream (fork here, join in qd_atmos_step_impl)         // the main stream waits for what the side stream holds (no-op when nothing is pending)
 int qd_plan_begin(qd_ctx* c, const QdUse* in, int n, bool* pending);

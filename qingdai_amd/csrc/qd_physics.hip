@@ -16,6 +16,7 @@
 #include "qd_band.h"
 #include "qd_pointwise.h"
 #include "qd_device.h"
+#include "qd_saf.h"
 #include "qd_fluxes.h"
 QdColP qd_make_colp(const qd_ctx* c, double dt);   // qd_atmos.hip
 
@@ -273,43 +274,31 @@ k_snow_provisional(QdGeom G, QdTabs T, QdSnowP P, const double* __restrict__ pre
     P_rain[o] = r.Pr; S_next[o] = r.Sn; melt[o] = r.melt; C_snow[o] = r.Cs; glacier[o] = r.gl;
 }
 
-// extras of k_snow_albedo_forcing inside a qd_step_n span: lazy diagnostic stores, and phase 1 of time_step's column riding along
-struct QdSafExtra { int write_diag, col1; QdColP P; const double *u, *v, *Ts, *q; double* Pcond; };
-
 // The tail of the driver physics and the forcing of the same step in ONE launch (whole-globe handles inside qd_step_n): snowpack ->
 // cloud tracer blend + albedo -> two-star insolation + Teq are three pointwise kernels on the same cells (17 + 13 + 12 us as three
 // launches at 721 x 1440; each re-reads what its predecessor has just written: C_snow, the glacier mask, the albedo).  Same bodies,
 // same order, results handed on in registers.
 __global__ void __launch_bounds__(QD_BLOCK)
-k_snow_albedo_forcing(QdGeom G, QdTabs T, QdSnowP S, QdAlbP A, QdForcingP Fo,
-                      const double* __restrict__ precip, const double* __restrict__ h, const double* __restrict__ S_snow,
-                      const double* __restrict__ elev, const uint8_t* __restrict__ land, double* __restrict__ P_rain,
-                      double* __restrict__ S_next, double* __restrict__ melt, double* __restrict__ C_snow, double* __restrict__ glacier,
-                      const double* __restrict__ adv, double* __restrict__ cloud, const double* __restrict__ cloud_eff,
-                      const double* __restrict__ hice, const double* __restrict__ base, const double* __restrict__ eco_alpha,
-                      const double* __restrict__ banded, const double* __restrict__ water, double* __restrict__ albedo,
-                      double* __restrict__ isrA, double* __restrict__ isrB, double* __restrict__ isr, double* __restrict__ Teq,
-                      double* __restrict__ eday, double eday_dt, QdSafExtra X) {
+k_snow_albedo_forcing(QdSafArgs K) {
     const QdTile tl = qd_tile();
     const int j = tl.seg * QD_BLOCK + threadIdx.x;
-    if (j >= G.nlon) return;
-    const int i = G.row0 + tl.row;
-    const size_t o = (size_t)qd_lrow(G, i) * G.nlon + j;
-    const int landv = land[o];
-    const double hh = h[o];
-    if (X.col1) {
-        // phase 1 of time_step's column (k_column<1>, dynamics.py:282-297): this step's P_cond for the median time_step starts with
-        const double hi = hice[o];
-        const double qsat_air = qd_qsat(288.0 + X.P.ga * hh, X.P.p0);
-        X.Pcond[o] = qd_humidity_column(X.P, X.u[o], X.v[o], X.Ts[o], X.q[o], qsat_air, landv == 1, hi).Pc;
-    }
-    const QdSnowOut r = qd_snow_cell(T, S, i, landv == 1, hh, S_snow[o], elev[o], precip[o]);
-    if (X.write_diag) { P_rain[o] = r.Pr; S_next[o] = r.Sn; melt[o] = r.melt; C_snow[o] = r.Cs; glacier[o] = r.gl; }
-    double c = cloud[o];
-    if (A.do_adv) { c = qd_clip((1.0 - A.alpha) * c + A.alpha * adv[o], 0.0, 1.0); cloud[o] = c; }
-    const double alb = qd_albedo_cell(A, o, c, cloud_eff, hice, base, landv, r.Cs, r.gl, eco_alpha, banded, water);
-    albedo[o] = alb;
-    qd_forcing_cell(T, Fo, i, j, o, alb, X.write_diag ? isrA : nullptr, isrB, isr, Teq, eday, eday_dt);
+    if (j >= K.G.nlon) return;
+    const int i = K.G.row0 + tl.row;
+    qd_saf_cell(K, i, j, (size_t)qd_lrow(K.G, i) * K.G.nlon + j, true);
+}
+// a launch that qd_step_n left for time_step's column kernel and that did not happen there after all (qd_atmos.hip)
+int qd_saf_launch(qd_ctx* c, const QdSafArgs& K) {
+    hipLaunchKernelGGL(k_snow_albedo_forcing, qd_grid2d(K.G), dim3(QD_BLOCK), 0, c->stream, K);
+    return 0;
+}
+void qd_saf_drop(qd_ctx* c) { delete (QdSafArgs*)c->saf_pending; c->saf_pending = nullptr; }
+int qd_saf_flush(qd_ctx* c) {
+    if (!c->saf_pending) return 0;
+    QdSafArgs* K = (QdSafArgs*)c->saf_pending;
+    c->saf_pending = nullptr;
+    const int r = qd_saf_launch(c, *K);
+    delete K;
+    return r;
 }
 
 struct QdBucketP { double dt, tau_s, cap; };
@@ -577,21 +566,29 @@ int qd_driver_physics_impl(qd_ctx* c, double dt, const QdForcingCall* fc, int pa
                 // (bands: on the rows every input is valid on -- the margin the three separate launches end up with as well, since
                 //  the albedo needs the snow cover and the forcing the albedo)
                 const int mm = std::min(m, msn);
-                QdSafExtra X;
-                X.write_diag = c->diag_write;
+                QdSafArgs K;
+                K.T = c->tabs; K.S = S; K.A = A; K.Fo = Fo;
+                K.precip = F[QD_F_PRECIP]; K.h = F[QD_F_H]; K.S_snow = F[QD_F_S_SNOW]; K.elev = F[QD_F_ELEVATION]; K.land = c->land;
+                K.P_rain = F[QD_F_P_RAIN]; K.S_next = F[QD_F_S_SNOW_NEXT]; K.melt = F[QD_F_MELT]; K.C_snow = F[QD_F_C_SNOW]; K.glacier = F[QD_F_GLACIER];
+                K.adv = adv; K.cloud = F[QD_F_CLOUD]; K.cloud_eff = c->cloud_eff_valid ? F[QD_F_CLOUD_EFF] : (const double*)nullptr;
+                K.hice = F[QD_F_HICE]; K.base = F[QD_F_BASE_ALBEDO]; K.eco_alpha = F[QD_F_ECO_ALPHA]; K.banded = F[QD_F_ECO_ALPHA_BANDED];
+                K.water = F[QD_F_WATER_ALPHA]; K.albedo = F[QD_F_ALBEDO]; K.isrA = F[QD_F_ISR_A]; K.isrB = F[QD_F_ISR_B]; K.isr = F[QD_F_ISR];
+                K.Teq = F[QD_F_TEQ]; K.eday = c->eco.eday_dt > 0 ? F[QD_F_ECO_EDAY] : (double*)nullptr; K.eday_dt = c->eco.eday_dt;
+                K.write_diag = c->diag_write;
                 // time_step's column phase 1 rides along when qd_step_n says the next thing is time_step with the P_cond median
-                X.col1 = (c->want_pcond_ahead && !pcond_side && !pcond_pair && c->geo.full && p.cloud_couple && !isset(p.pcond_ref)) ? 1 : 0;
-                X.P = qd_make_colp(c, dt);
-                X.u = F[QD_F_U]; X.v = F[QD_F_V]; X.Ts = F[QD_F_TS]; X.q = F[QD_F_Q]; X.Pcond = F[QD_F_PCOND];
-                QD_ROWS(c, mm, G, hipLaunchKernelGGL(k_snow_albedo_forcing, qd_grid2d(G), blk, 0, c->stream, G, c->tabs, S, A, Fo, F[QD_F_PRECIP], F[QD_F_H],
-                                   F[QD_F_S_SNOW], F[QD_F_ELEVATION], c->land, F[QD_F_P_RAIN], F[QD_F_S_SNOW_NEXT], F[QD_F_MELT],
-                                   F[QD_F_C_SNOW], F[QD_F_GLACIER], adv, F[QD_F_CLOUD],
-                                   c->cloud_eff_valid ? F[QD_F_CLOUD_EFF] : (const double*)nullptr, F[QD_F_HICE], F[QD_F_BASE_ALBEDO],
-                                   F[QD_F_ECO_ALPHA], F[QD_F_ECO_ALPHA_BANDED], F[QD_F_WATER_ALPHA], F[QD_F_ALBEDO], F[QD_F_ISR_A],
-                                   F[QD_F_ISR_B], F[QD_F_ISR], F[QD_F_TEQ], c->eco.eday_dt > 0 ? F[QD_F_ECO_EDAY] : (double*)nullptr,
-                                   c->eco.eday_dt, X));
+                K.col1 = (c->want_pcond_ahead && !pcond_side && !pcond_pair && c->geo.full && p.cloud_couple && !isset(p.pcond_ref)) ? 1 : 0;
+                K.P = qd_make_colp(c, dt);
+                K.u = F[QD_F_U]; K.v = F[QD_F_V]; K.Ts = F[QD_F_TS]; K.q = F[QD_F_Q]; K.Pcond = F[QD_F_PCOND];
+                if (pcond_pair && c->merge_saf && c->pcond_ahead == 3 && c->geo.full) {
+                    // the P_cond median is done already, so NOTHING separates this launch from time_step's column kernel: left for it
+                    // (k_saf_column2, qd_atmos.hip: cloud, albedo, isr and Teq reach the column in registers)
+                    K.G = c->geo;
+                    delete (QdSafArgs*)c->saf_pending;
+                    c->saf_pending = new QdSafArgs(K);
+                } else
+                QD_ROWS(c, mm, G, K.G = G; hipLaunchKernelGGL(k_snow_albedo_forcing, qd_grid2d(G), blk, 0, c->stream, K));
                 c->eco.eday_dt = 0;
-                if (X.col1) c->pcond_ahead = 1;
+                if (K.col1) c->pcond_ahead = 1;
                 qd_mark(c, {F[QD_F_P_RAIN], F[QD_F_S_SNOW_NEXT], F[QD_F_MELT], F[QD_F_C_SNOW], F[QD_F_GLACIER]}, mm);
                 qd_mark(c, {F[QD_F_CLOUD], F[QD_F_ALBEDO], F[QD_F_ISR_A], F[QD_F_ISR_B], F[QD_F_ISR], F[QD_F_TEQ]}, mm);
                 return 0;

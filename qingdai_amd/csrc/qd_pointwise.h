@@ -81,10 +81,12 @@ __device__ __forceinline__ double qd_albedo_cell(const QdAlbP& P, size_t o, doub
 struct QdStar { double flux, sin_d, cos_d, alpha; };
 struct QdForcingP { QdStar A, B; double theta, sigma; int with_teq; };
 
-// alb: the cell's albedo (only read when P.with_teq)
-__device__ __forceinline__ void qd_forcing_cell(const QdTabs& T, const QdForcingP& P, int i, int j, size_t o, double alb,
-                                                double* __restrict__ isrA, double* __restrict__ isrB, double* __restrict__ isr,
-                                                double* __restrict__ Teq, double* __restrict__ eday, double eday_dt) {
+// alb: the cell's albedo (only read when P.with_teq).  Returns {total insolation, Teq} of the cell; Teq == nullptr: not stored (the
+// caller hands it on in a register)
+struct QdForcingOut { double tot, teq; };
+__device__ __forceinline__ QdForcingOut qd_forcing_cell(const QdTabs& T, const QdForcingP& P, int i, int j, size_t o, double alb,
+                                                        double* __restrict__ isrA, double* __restrict__ isrB, double* __restrict__ isr,
+                                                        double* __restrict__ Teq, double* __restrict__ eday, double eday_dt) {
     const double sl = T.sin_raw[i], cl = T.cos_raw[i], lon = T.lon_rad[j];
     const double hA = P.theta + lon - P.A.alpha;
     const double hB = P.theta + lon - P.B.alpha;
@@ -95,9 +97,12 @@ __device__ __forceinline__ void qd_forcing_cell(const QdTabs& T, const QdForcing
     if (isrA) { isrA[o] = a_; isrB[o] = b_; }                  // nullptr: a step inside a span whose per-star fluxes nobody reads (lazy diagnostics)
     isr[o] = tot;
     if (eday) eday[o] += qd_nn(tot) * eday_dt;                 // PopulationManager.step_subdaily (population.py:267-268)
+    QdForcingOut r{tot, 0.0};
     if (P.with_teq) {
         double num = tot * (1 - alb);
         if (num < 0) num = 0;
-        Teq[o] = sqrt(sqrt(num / P.sigma));        // (num / SIGMA) ** 0.25
+        r.teq = sqrt(sqrt(num / P.sigma));         // (num / SIGMA) ** 0.25
+        if (Teq) Teq[o] = r.teq;
     }
+    return r;
 }
