@@ -117,9 +117,12 @@ __device__ __forceinline__ int qt_ld8(qt_rsrc r, unsigned row_elems, unsigned vo
 // currents at the cap).  A strip with more notes than the stage holds appends the rest directly.
 #define QT_FIX_STAGE 512                   // entries of 24 bytes
 struct QtFixW { unsigned int* fixc; unsigned long long* fixl; unsigned long long* stage; unsigned int* nstage; };
+// (FIX is a template parameter all the way up to the kernel: with the list as a run-time branch in the row loop the STORING form carried
+//  the list's pointers through the loop -- 21 more spilled SGPRs -- and ran 8 us per step slower than before there was a list)
+template <bool FIX>
 __device__ __forceinline__ void qt_put_uv(const QtFixW& X, qt_rsrc UO, qt_rsrc VO, unsigned row_elems, unsigned vs,
                                           double u, double v, double uc, double vc) {
-    if (!X.fixc) { qt_st(UO, row_elems, vs, u); qt_st(VO, row_elems, vs, v); return; }
+    if (!FIX) { qt_st(UO, row_elems, vs, u); qt_st(VO, row_elems, vs, v); return; }
     const unsigned long long ub = (unsigned long long)__double_as_longlong(u), vb = (unsigned long long)__double_as_longlong(v);
     const bool ch = vs != 0x80000000u && (ub != (unsigned long long)__double_as_longlong(uc) || vb != (unsigned long long)__double_as_longlong(vc));
     const unsigned long long chm = __builtin_amdgcn_ballot_w64(ch);
@@ -173,6 +176,7 @@ __device__ __forceinline__ unsigned qt_row(const QtW& W, int g) {
 __device__ __forceinline__ unsigned qt_row_roll(const QtW& W, int g) { if (g < 0) g += W.n; else if (g >= W.n) g -= W.n; return qt_row(W, g); }
 
 // ---- wave 0: continuity (ocean.py:365-374) + outlier filter and caps (ocean.py:409-434)
+template <bool FIX = false>
 __device__ __forceinline__ double qt_currents_wave(const QdTabs& T, const QdTailArgs& P, const QtW& W, const QtFixW& FX = QtFixW{nullptr, nullptr, nullptr, nullptr}) {
     const unsigned sb = W.slab;
     const qt_rsrc U = qt_make_rsrc(P.uo, sb), V = qt_make_rsrc(P.vo, sb), E = qt_make_rsrc(P.eta, sb), L = qt_make_rsrc(P.land, sb / 8u);
@@ -224,7 +228,7 @@ __device__ __forceinline__ double qt_currents_wave(const QdTabs& T, const QdTail
                 u = u * sc; v = v * sc;
             }
         }
-        qt_put_uv(FX, UO, VO, r0, W.vs, u, v, uc, vc);
+        qt_put_uv<FIX>(FX, UO, VO, r0, W.vs, u, v, uc, vc);
         us = uc; uc = un; vs = vc; vc = vn;
     }
     return acc;
@@ -461,7 +465,7 @@ struct QtCurK { double dlon2, r_2dlon, dlat2, r_2dlat, msdtH, cap, cap81; int me
 
 // one row of the continuity + caps wave away from the poles; `ro`: element offset of row g in the slab
 // RING: u, v of row g + 1 and eta of row g come from the LDS ring of k_ocn_fused (R), everything else as before
-template <bool RING = false>
+template <bool RING = false, bool FIX = false>
 __device__ __forceinline__ void qt_cur_fast_step(const QtCurK& P, const QtW& W, qt_rsrc U, qt_rsrc V, qt_rsrc E, qt_rsrc L,
                                                  qt_rsrc UO, qt_rsrc VO, qt_rsrc KT, double& us, double& uc, double& vs, double& vc, double& acc,
                                                  QtCurSlot& sl, int g, unsigned ro, const QfuRing* R = nullptr) {
@@ -498,7 +502,7 @@ __device__ __forceinline__ void qt_cur_fast_step(const QtCurK& P, const QtW& W, 
             u = u * sc; v = v * sc;
         }
     }
-    qt_put_uv(P.fx, UO, VO, ro, W.vs, u, v, uc, vc);
+    qt_put_uv<FIX>(P.fx, UO, VO, ro, W.vs, u, v, uc, vc);
     us = uc; uc = un; vs = vc; vc = vn;
     if (RING) { if (W.lane == 0) __hip_atomic_store(R->prog + 3, g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }     // rows <= g are done with
     __builtin_amdgcn_sched_barrier(0);
@@ -509,6 +513,7 @@ __device__ __forceinline__ void qt_cur_fast_step(const QtCurK& P, const QtW& W, 
     __builtin_amdgcn_sched_barrier(0);                       // (else the next step's arithmetic is scheduled in front of these loads)
 }
 
+template <bool FIX = false>
 __device__ __forceinline__ double qt_currents_fast(const QdTailArgs& P, const QtW& W, const QtFixW& FX = QtFixW{nullptr, nullptr, nullptr, nullptr}) {
     const unsigned sb = W.slab, m = (unsigned)W.m;
     const qt_rsrc U = qt_make_rsrc(P.uo, sb), V = qt_make_rsrc(P.vo, sb), E = qt_make_rsrc(P.eta, sb), L = qt_make_rsrc(P.land, sb / 8u);
@@ -520,7 +525,7 @@ __device__ __forceinline__ double qt_currents_fast(const QdTailArgs& P, const Qt
     QtCurK K;
     K.dlon2 = qt_vreg(2 * P.dlon); K.r_2dlon = qt_vreg(P.r_2dlon); K.dlat2 = qt_vreg(2 * P.dlat); K.r_2dlat = qt_vreg(P.r_2dlat);
     K.msdtH = qt_vreg(P.msdtH); K.cap = qt_vreg(P.cap); K.cap81 = qt_vreg(0.81 * (P.cap * P.cap)); K.mean4 = P.mean4;
-    K.fx = FX;
+    if (FIX) K.fx = FX;
     QtCurSlot a, b;
     a.u = qt_ld(U, ro + m, W.vo); a.v = qt_ld(V, ro + m, W.vo); a.e = qt_ld(E, ro, W.vo); a.l = qt_ld8(L, ro, W.vo8);
     a.k0 = qt_ldk(KT, 16u * (unsigned)W.o0, 4u); a.k1 = qt_ldk(KT, 16u * (unsigned)W.o0, 5u);
@@ -529,11 +534,11 @@ __device__ __forceinline__ double qt_currents_fast(const QdTailArgs& P, const Qt
     __builtin_amdgcn_s_waitcnt(0x0F70);                      // the loop is entered with nothing in flight (exact counts inside: qd_stream.h)
     int g = W.o0;
     for (; g + 1 < W.o1; g += 2) {
-        qt_cur_fast_step(K, W, U, V, E, L, UO, VO, KT, us, uc, vs, vc, acc, a, g, ro);
-        qt_cur_fast_step(K, W, U, V, E, L, UO, VO, KT, us, uc, vs, vc, acc, b, g + 1, ro + m);
+        qt_cur_fast_step<false, FIX>(K, W, U, V, E, L, UO, VO, KT, us, uc, vs, vc, acc, a, g, ro);
+        qt_cur_fast_step<false, FIX>(K, W, U, V, E, L, UO, VO, KT, us, uc, vs, vc, acc, b, g + 1, ro + m);
         ro += 2u * m;
     }
-    if (g < W.o1) qt_cur_fast_step(K, W, U, V, E, L, UO, VO, KT, us, uc, vs, vc, acc, a, g, ro);
+    if (g < W.o1) qt_cur_fast_step<false, FIX>(K, W, U, V, E, L, UO, VO, KT, us, uc, vs, vc, acc, a, g, ro);
     return acc;
 }
 
@@ -662,6 +667,7 @@ __device__ __forceinline__ bool qt_sst_fast(const QdTailArgs& P, const QtW& W) {
     return __builtin_amdgcn_ballot_w64(bad) != 0ull;
 }
 
+template <bool FIX>
 __global__ void __launch_bounds__(128)
 k_ocn_tail_fast(QdGeom G, QdTabs T, QdTailArgs P) {
     const unsigned w = qd_xcd_chunk(blockIdx.x, gridDim.x);
@@ -697,18 +703,18 @@ k_ocn_tail_fast(QdGeom G, QdTabs T, QdTailArgs P) {
         }
         if (general) qt_sst_wave(G, T, P, W);
         QT_STAMP(2);
-        if (!P.fix_count) return;
+        if (!FIX) return;
         __syncthreads();                                     // fix list: this strip's ticket is taken when BOTH its waves have read their uo', vo'
         return;
     }
-    __shared__ unsigned long long s_fix[3 * QT_FIX_STAGE];
+    __shared__ unsigned long long s_fix[FIX ? 3 * QT_FIX_STAGE : 1];
     __shared__ unsigned int s_nfix;
     const QtFixW FX{P.fix_count, P.fix_list, s_fix, &s_nfix};
-    if (P.fix_count && W.lane == 0) __hip_atomic_store(&s_nfix, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);             // (this wave is the only one that touches the stage: its LDS accesses are in order)
-    double acc = (plain && W.o0 >= 1 && W.o1 <= W.n - 1) ? qt_currents_fast(P, W, FX) : qt_currents_wave(T, P, W, FX);
-    qt_fix_flush(FX);
+    if (FIX && W.lane == 0) __hip_atomic_store(&s_nfix, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);             // (this wave is the only one that touches the stage: its LDS accesses are in order)
+    double acc = (plain && W.o0 >= 1 && W.o1 <= W.n - 1) ? qt_currents_fast<FIX>(P, W, FX) : qt_currents_wave<FIX>(T, P, W, FX);
+    if (FIX) qt_fix_flush(FX);
     QT_STAMP(2);
-    if (P.fix_count) __syncthreads();
+    if (FIX) __syncthreads();
     acc = qt_wave_sum(acc);
     if (W.lane == 0) __hip_atomic_store(P.partial + w, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // coherent: the finisher may read it
     if (P.acc) {                                             // eta mean inside this launch: the last workgroup to arrive finishes it
@@ -717,7 +723,7 @@ k_ocn_tail_fast(QdGeom G, QdTabs T, QdTailArgs P) {
             double mm = qd_acc_finish(P.acc, P.partial, (int)gridDim.x, P.wsum);
             if (P.pf.pbox) mm = qp_fold_sum(P.pf, mm);        // bands over the peer exchange: the sum over the ranks, here and now
             if (W.lane == 0) *P.mean_out = mm;
-            if (P.fix_count) {
+            if (FIX) {
                 // every wave of the launch is done with uo', vo': the noted cells get their uo'' / vo'' in place (entries and count were
                 // written with agent-scope atomics before their strips' tickets: qd_acc_arrive waits for them)
                 const unsigned nfix = __hip_atomic_load(P.fix_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1098,7 +1104,8 @@ int qd_launch_ocn_tail(qd_ctx* c, const QdGeom& G, QdTailArgs& P) {
     hipMemsetAsync(stamps, 0, stamp_words * 8, c->stream);
 #endif
     if (!fast || !P.acc) { P.fix_count = nullptr; P.fix_list = nullptr; }          // the fix list is applied by k_ocn_tail_fast's finishing wave
-    if (fast) QD_LAUNCH_TIMED(sc, k_ocn_tail_fast, dim3(nrs * P.ntc), dim3(128), c->stream, G, c->tabs, P);
+    if (fast && P.fix_count) QD_LAUNCH_TIMED(sc, k_ocn_tail_fast<true>, dim3(nrs * P.ntc), dim3(128), c->stream, G, c->tabs, P);
+    else if (fast) QD_LAUNCH_TIMED(sc, k_ocn_tail_fast<false>, dim3(nrs * P.ntc), dim3(128), c->stream, G, c->tabs, P);
     else QD_LAUNCH_TIMED(sc, k_ocn_tail_stream<1>, dim3(nrs * P.ntc), dim3(128), c->stream, G, c->tabs, P);
 #ifdef QT_STAMPS
     if (const char* f = std::getenv("QD_STAMPS_FILE")) {     // developer build (-DQT_STAMPS) only
