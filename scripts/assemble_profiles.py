@@ -69,10 +69,16 @@ def main():
     fk = {"grid": [nlat, nlon], "kernel_sources_sha256_16": stamp, "device_code_sha256_16": _codehash.device_code_stamp(), "source": f"rocprofv3 kernel trace + FETCH_SIZE / WRITE_SIZE passes of bench.py (scripts/profile_round.sh {tag}, "
                                          f"scripts/assemble_profiles.py); profiles/README.md", "kernels": {}}
     dyn = next(k for k in tr if "k_dyn_stream" in k)
-    tail = next(k for k in tr if "k_ocn_tail_fast" in k or "k_ocn_tail_stream" in k)      # round 3b: k_ocn_tail_fast; before: "void k_ocn_tail_stream<1>"
-    for grp, kn in (("k_dyn_hyper", dyn), ("k_ocn_hyper", "k_ocn_stream"), ("ocean_tail", tail)):
-        fk["kernels"][grp] = {"trace_kernel": kn, "traffic_bytes": traffic["kernels"][kn]["traffic_bytes"],
-                              "read_bytes": traffic["kernels"][kn]["read_bytes"], "write_bytes": traffic["kernels"][kn]["write_bytes"],
+    # round 4: the tail kernel has two instantiations -- k_ocn_tail_fast<true> (changed currents through the fix list) while few cells
+    # change, <false> (stored) otherwise; the 16-step PMC passes only see the first.  Trace time: launch-weighted over both
+    tails = [k for k in tr if "k_ocn_tail_fast" in k or "k_ocn_tail_stream" in k]
+    ntl = sum(tr[k][0] for k in tails)
+    tr["ocean_tail(all)"] = (ntl, sum(tr[k][0] * tr[k][1] for k in tails) / max(1, ntl))
+    tail_pmc = next((k for k in tails if k in traffic["kernels"]), tails[0])
+    for grp, kn, kp in (("k_dyn_hyper", dyn, dyn), ("k_ocn_hyper", "k_ocn_stream", "k_ocn_stream"), ("ocean_tail", "ocean_tail(all)", tail_pmc)):
+        fk["kernels"][grp] = {"trace_kernel": kn if kn in traffic["kernels"] else " + ".join(tails), "pmc_kernel": kp,
+                              "traffic_bytes": traffic["kernels"][kp]["traffic_bytes"],
+                              "read_bytes": traffic["kernels"][kp]["read_bytes"], "write_bytes": traffic["kernels"][kp]["write_bytes"],
                               "avg_kernel_ms_rocprof": tr[kn][1] / 1e3, "launches_in_trace": tr[kn][0]}
     json.dump(fk, open(os.path.join(P, f"{tag}_fused_kernels.json"), "w"), indent=1)
     print(json.dumps(fk, indent=1))
