@@ -315,6 +315,7 @@ static void qd_read_tuning(qd_ctx* c) {
     t.fused_r = std::max(0, geti("QD_FUSED_R", 0));
     t.fused_seq = geti("QD_FUSED_SEQ", 0) == 1 ? 1 : 0;
     t.fused_norot = geti("QD_FUSED_NOROT", 0) == 1 ? 1 : 0;
+    t.stream_no_pair = geti("QD_STREAM_NO_PAIR", 0) == 1 ? 1 : 0;
 }
 extern "C" int qd_tune_reload(qd_handle c) { if (!c) return -1; qd_read_tuning(c); c->tile = QdTileShape{0, 0, 0, 0}; return 0; }
 

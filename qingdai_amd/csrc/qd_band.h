@@ -52,7 +52,9 @@ bool qd_peer_hooks(const qd_ctx* c);                                     // the 
 int  qd_peer_halo_begin(qd_ctx* c, const QdUse* slots, int n, bool defer = false);           // push only (n <= qd_peer_max_slabs()) ...
 struct QdPeerPush;
 struct QsOcnArgs;
+void qd_launch_ocn_stream_pair(qd_ctx* c, const QsOcnArgs& A, const QdGeom& G2, int vb2, int nrs2, int ntc2);   // qd_stream_push.hip: two row segments, one launch
 bool qd_launch_ocn_stream_push(qd_ctx* c, const QsOcnArgs& A);           // qd_stream_push.hip: the strips of A behind a waiting push (false: none waiting)
+bool qd_peer_job_waiting(const qd_ctx* c);                               // a deferred push is waiting for a launch to carry it
 bool qd_peer_take_job(qd_ctx* c, QdPeerPush* J);                         // a deferred push, for the launch that will carry it
 int  qd_peer_halo_end(qd_ctx* c);                                        // ... wait + unpack
 int  qd_peer_max_slabs();

@@ -168,6 +168,7 @@ struct QdTune {
     int tile_tr = 0;          // QD_TILE_TR: tile height of the LDS fallback kernels
     int fused_r = 0;          // QD_FUSED_R: strip height of k_ocn_fused
     int fused_norot = 0;      // QD_FUSED_NOROT=1: no rotation of the wave roles (A/B)
+    int stream_no_pair = 0;   // QD_STREAM_NO_PAIR=1: the two boundary segments of a split ocean momentum launch as two launches (A/B)
     int fused_seq = 0;        // QD_FUSED_SEQ=1: every strip of k_ocn_fused takes its sequential form (tests)
 };
 struct QdTileShape { int tr, tc, ntr, ntc; };

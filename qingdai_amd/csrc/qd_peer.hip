@@ -389,6 +389,7 @@ int qd_peer_halo(qd_ctx* c, const QdUse* slots, int n) {
 // own launch (qd_peer_take_job; k_ocn_stream_push) -- a push kernel of its own ends only when everything it sent has been
 // acknowledged over the links, and the stream starts nothing before that: the interior rows would not overlap the transfer at all
 int qd_peer_halo_begin(qd_ctx* c, const QdUse* slots, int n, bool defer) { return qp_halo_push(c, slots, n, defer); }
+bool qd_peer_job_waiting(const qd_ctx* c) { return c->peer && c->peer->job_waiting; }
 bool qd_peer_take_job(qd_ctx* c, QdPeerPush* J) {
     QdPeer* P = c->peer;
     if (!P || !P->job_waiting) return false;

@@ -263,6 +263,13 @@ bool qd_ocn_stream_ok_list(const qd_ctx* c, const QdSegList& S) {
 int qd_launch_ocn_stream_list(qd_ctx* c, const QdOcnArgs& P, const QdSegList& S) {
     QsOcnArgs A;
     if (!qd_stream_ocn_args(c, P, A)) return qd_fail(c, "fused kernel: coefficient row tables");
+    if (S.n == 2 && !c->tune.stream_no_pair && !qd_peer_job_waiting(c)) {                // the two boundary segments of a split launch: one launch (k_ocn_stream_pair)
+        const QsShape s0 = qs_shape(c, S.g[0].nrows, S.g[0].nlon, 2, S.g[0].row0 + S.g[0].nrows == S.g[0].nlat);
+        const QsShape s1 = qs_shape(c, S.g[1].nrows, S.g[1].nlon, 2, S.g[1].row0 + S.g[1].nrows == S.g[1].nlat);
+        A.G = S.g[0]; A.vb = s0.vb; A.nrs = s0.nrs; A.ntc = (S.g[0].nlon + QS_TC - 1) / QS_TC;
+        qd_launch_ocn_stream_pair(c, A, S.g[1], s1.vb, s1.nrs, (S.g[1].nlon + QS_TC - 1) / QS_TC);
+        return 0;
+    }
     for (int k = 0; k < S.n; ++k) {
         const QdGeom& G = S.g[k];
         const QsShape sh = qs_shape(c, G.nrows, G.nlon, 2, G.row0 + G.nrows == G.nlat);
