@@ -1,4 +1,5 @@
-// qd_stream_push.hip -- the ocean momentum kernel of a latitude band with a halo push in front (peer exchange, QD_PEER_OVERLAP=2).
+// qd_stream_push.hip -- the two launches of the ocean momentum kernel of a latitude band AROUND a split halo exchange (peer exchange,
+// QD_PEER_OVERLAP=2): k_ocn_stream_push (the interior rows with the push in front) and k_ocn_stream_pair (the two boundary segments).
 //
 // A sub-step whose halos are due splits its momentum launch into the interior rows (computable from the margins the slabs still
 // have) and two boundary strips (after the unpack; qd_ocean.hip).  For the interior to overlap the transfer, the transfer must be
