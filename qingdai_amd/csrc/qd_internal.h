@@ -247,6 +247,8 @@ struct qd_ctx {
     unsigned long long* fix_list = nullptr;      // [cells][3]
     double fix_avg = 0.0;                        // entries per launch in the last step that used the list (k_max2_publish / the bands' CFL reduce)
     double fix_dense = 256.0;                    // QD_TAIL_FIX_DENSE: longer lists on average -> the storing form
+    int64_t fix_probe_at = 0;                    // while the storing form is on: the ocean step that tries the list again ...
+    int fix_probe_every = 32;                    // ... 32 steps after the last try, doubling up to 256 while the tries keep finding long lists
     // whole-globe qd_step_n with the P_cond median ahead of the cloud block (pcond_ahead == 3): the driver physics' last launch
     // (k_snow_albedo_forcing) and time_step's column kernel are back to back -- the first becomes the first STAGE of the second
     // (k_saf_column2, qd_atmos.hip: cloud, albedo, isr, Teq in registers, h / h_ice / land read once).  saf_pending: its argument block

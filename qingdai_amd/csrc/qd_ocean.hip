@@ -909,8 +909,15 @@ int qd_ocean_step_impl(qd_ctx* c, double dt, int compute_qnet, int use_ice_mask,
     // the ocean tail's fix list (QD_TAIL_FIX) pays while few cells change (a run from rest: ~40 per launch, -1.2 us per launch on the whole
     // globe, -2.5 on a 1/8 band) and costs once the polar currents sit at the cap (~700 per launch at step 240 of the benchmark: the
     // finishing wave's patch loop, +1.3 us): taken while the lists of the last step that had any averaged <= fix_dense entries, probed
-    // again every 32nd step while it is off
-    const bool fix_now = c->tail_fix && c->fix_count && (c->fix_avg <= c->fix_dense || (step & 31) == 0) && (!band || band_fix_stats);
+    // again 32, 64, ... 256 steps later while it is off
+    bool fix_now = c->tail_fix && c->fix_count && (!band || band_fix_stats);
+    if (fix_now) {
+        if (c->fix_avg <= c->fix_dense) c->fix_probe_every = 32;                          // short lists: the list stays on
+        else if (step >= c->fix_probe_at) {                                                 // long lists: a probe is due (its result arrives with the next step's maxima)
+            c->fix_probe_at = step + c->fix_probe_every;
+            c->fix_probe_every = std::min(256, c->fix_probe_every * 2);
+        } else fix_now = false;
+    }
     const double sub_dt = dt / n_sub;
     QdOcnP OP{p.a, p.g_ocean, c->dlat, c->dlon, sub_dt, p.rho_w * H, p.r_bot};
     QdHeatP HP{sub_dt, p.K_h, p.rho_w * p.cp_w * H, p.ocean_ice_qfac, p.ocean_use_qnet ? 1 : 0, use_ice_mask ? 1 : 0};
